@@ -1,0 +1,1009 @@
+/*
+ * lyra_oracle.c -- CPU restatement of the Lyra v1.3.2 encode/decode hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product
+ * (lyra_amd/csrc) never links or calls it.
+ *
+ * What it restates (reference file:line, relative to /root/reference):
+ *   - SoundStreamEncoder::Extract          lyra/soundstream_encoder.cc:53-64
+ *     + graph lyra/model_coeffs/soundstream_encoder.tflite
+ *   - ResidualVectorQuantizer::Quantize    lyra/residual_vector_quantizer.cc:77-110
+ *     ResidualVectorQuantizer::DecodeToLossyFeatures            ...:112-168
+ *     + graph lyra/model_coeffs/quantizer.tflite
+ *   - LyraGanModel::RunConditioning/RunModel lyra/lyra_gan_model.cc:53-64
+ *     + graph lyra/model_coeffs/lyragan.tflite
+ *   - LogMelSpectrogramExtractorImpl::Extract
+ *                                lyra/log_mel_spectrogram_extractor_impl.cc:96-126
+ *   - Int16ToUnitScalar / UnitToInt16Scalar lyra/dsp_utils.h:54-108
+ *   - Packet<>::Pack bit layout             lyra/packet.h:91-122
+ *
+ * The arithmetic of the three graphs lives in TensorFlow Lite v2.11.0 +
+ * XNNPACK (WORKSPACE:168-174), an un-vendored third-party dependency that
+ * cannot be built offline; its published builtin-kernel semantics are restated
+ * here.  The coefficients come from tools/pack_weights.py,
+ * which re-keys the reference's flatbuffers by role.
+ *
+ * PINNING: oracle/tflite_interp.py (a generic numpy interpreter that executes
+ * the reference's own flatbuffers op by op) produced the golden vectors under
+ * tests/golden/; tests/test_oracle_*.py check this file against them, against
+ * the reference's log-mel golden (log_mel_spectrogram_extractor_impl_test.cc:
+ * 37-59) and its RVQ fixture/threshold (residual_vector_quantizer_test.cc:
+ * 43-54,104-111).  Parity with a real TFLite binary is pinned only at the
+ * level the reference itself tests (LSD < 2.0, lyra_integration_test.cc:
+ * 131-142): no reference test holds an expected feature/packet/PCM value.
+ *
+ * Canonical fp32 order (so "bit-exact vs oracle" is well defined; it is the
+ * TFLite reference-kernel loop order with fused multiply-add):
+ *   conv      acc = 0; for tap (outer) for in-channel (inner):
+ *                 acc = fmaf(x, w, acc);            y = acc + bias
+ *   depthwise acc = 0; for tap: acc = fmaf(x, w, acc);  y = acc + bias
+ *   tconv     per output element acc = 0; for in-pos t ascending, for
+ *             in-channel ascending: acc = fmaf(x, w, acc);  y = acc + bias
+ *   RVQ       d = r - c; dist = sum_{d=0..63} (d*d) sequential, separate
+ *             mul and add (SQUARED_DIFFERENCE then SUM); first minimum wins.
+ * gfx950's v_mfma_f32_16x16x4_f32 is bitwise a k-ordered fmaf chain, which is
+ * why the fused order was chosen as canonical.
+ *
+ * Requantisation modes for int8 conv/depthwise/transpose-conv:
+ *   0 "exact"            (int64(acc)*M + 2^(30-shift)) >> (31-shift)
+ *   1 "gemmlowp_double"  RoundingDivideByPOT(SRDHM(acc << left, M), right)
+ * int8 LEAKY_RELU and ADD always use the gemmlowp form.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define LRELU_ALPHA 0.30000001192092896f
+#define NUM_FEATURES 64
+#define HOP 320
+#define RVQ_STAGES 46
+#define RVQ_CODES 16
+
+/* ------------------------------------------------------------------------ */
+/* pack container                                                            */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  char name[56];
+  uint32_t dtype, ndim, shape[4];
+  uint64_t offset, nbytes;
+} pk_entry;
+
+typedef struct {
+  uint8_t* blob;
+  size_t size;
+  uint32_t n;
+  pk_entry* e;
+} pk_file;
+
+static int pk_open(pk_file* p, const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  p->blob = (uint8_t*)aligned_alloc(64, ((size_t)sz + 63) / 64 * 64);
+  if (fread(p->blob, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return -2; }
+  fclose(f);
+  p->size = (size_t)sz;
+  if (memcmp(p->blob, "LYRAPK01", 8) != 0) return -3;
+  memcpy(&p->n, p->blob + 8, 4);
+  p->e = (pk_entry*)(p->blob + 16);
+  return 0;
+}
+
+static const pk_entry* pk_find(const pk_file* p, const char* name) {
+  for (uint32_t i = 0; i < p->n; ++i)
+    if (strncmp(p->e[i].name, name, 56) == 0) return &p->e[i];
+  fprintf(stderr, "lyra_oracle: missing tensor %s\n", name);
+  abort();
+}
+
+static const void* pk_data(const pk_file* p, const char* fmt, const char* pre, const char* kind,
+                           int idx, const char* leaf) {
+  char name[96];
+  (void)fmt;
+  snprintf(name, sizeof name, "%s.%s.%d.%s", pre, kind, idx, leaf);
+  return p->blob + pk_find(p, name)->offset;
+}
+#define PKF(pre, kind, idx, leaf) ((const float*)pk_data(pk, 0, pre, kind, idx, leaf))
+#define PKI(pre, kind, idx, leaf) ((const int32_t*)pk_data(pk, 0, pre, kind, idx, leaf))
+#define PKB(pre, kind, idx, leaf) ((const int8_t*)pk_data(pk, 0, pre, kind, idx, leaf))
+
+/* ------------------------------------------------------------------------ */
+/* fixed-point helpers (TFLite common.h semantics)            */
+/* ------------------------------------------------------------------------ */
+typedef struct { int32_t m; int shift; } qmul;
+
+static qmul quantize_multiplier(double d) {
+  qmul r = {0, 0};
+  if (d == 0.0) return r;
+  int sh;
+  double q = frexp(d, &sh);
+  int64_t m = (int64_t)llround(q * (double)(1ll << 31));
+  if (m == (1ll << 31)) { m /= 2; ++sh; }
+  if (sh < -31) { r.m = 0; r.shift = 0; return r; }
+  r.m = (int32_t)m;
+  r.shift = sh;
+  return r;
+}
+
+static inline int32_t srdhm(int32_t a, int32_t b) {
+  if (a == INT32_MIN && b == INT32_MIN) return INT32_MAX;
+  int64_t ab = (int64_t)a * (int64_t)b;
+  int64_t nudge = ab >= 0 ? (1ll << 30) : (1 - (1ll << 30));
+  return (int32_t)((ab + nudge) / (1ll << 31)); /* C '/' truncates toward zero */
+}
+
+static inline int32_t rdivpot(int32_t x, int e) {
+  int32_t mask = (int32_t)((1ll << e) - 1);
+  int32_t rem = x & mask;
+  int32_t thr = (mask >> 1) + (x < 0 ? 1 : 0);
+  return (x >> e) + (rem > thr ? 1 : 0);
+}
+
+static inline int32_t mbqm_double(int32_t x, qmul q) {
+  int left = q.shift > 0 ? q.shift : 0;
+  int right = q.shift > 0 ? 0 : -q.shift;
+  return rdivpot(srdhm((int32_t)((int64_t)x * (1ll << left)), q.m), right);
+}
+
+static inline int32_t mbqm_exact(int32_t x, qmul q) {
+  int total = 31 - q.shift;
+  return (int32_t)(((int64_t)x * (int64_t)q.m + (1ll << (total - 1))) >> total);
+}
+
+static inline int8_t clamp8(int32_t v) { return (int8_t)(v < -128 ? -128 : (v > 127 ? 127 : v)); }
+
+static inline int8_t quantize_f(float x, float s, int32_t z) {
+  /* TFLite AffineQuantize: round-half-away(x / s) + z, clamped */
+  float r = roundf(x / s);
+  int32_t q = (int32_t)r + z;
+  return clamp8(q);
+}
+static inline float dequantize_f(int8_t q, float s, int32_t z) {
+  return (float)((double)s * (double)((int32_t)q - z));
+}
+static inline float lrelu_f(float x) { return x > 0.f ? x : x * LRELU_ALPHA; }
+
+/* ------------------------------------------------------------------------ */
+/* layers                                                                    */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int cout, k, cig, groups, stride, cog;
+  float* wt;      /* [g][k*cig][cog] */
+  const float* b; /* [cout] */
+} conv_f;
+
+typedef struct {
+  int cout, k, cig, groups, stride, cog;
+  int16_t* wt;      /* [g][k*cig][cog] */
+  const int32_t* b; /* [cout] */
+  int32_t zin, zout;
+  float sin, sout;
+  qmul* q; /* [cout] */
+} conv_q;
+
+typedef struct { int c, k, dil; const float* w; const float* b; } dw_f;
+typedef struct {
+  int c, k, dil;
+  const int8_t* w;
+  const int32_t* b;
+  int32_t zin, zout;
+  float sin, sout;
+  qmul* q;
+} dw_q;
+
+typedef struct { int cout, k, cin, stride; const float* w /*[cout][k][cin]*/; const float* b; } tconv_f;
+typedef struct {
+  int cout, k, cin, stride;
+  const int8_t* w;
+  const int32_t* b;
+  int32_t zin, zout;
+  float sin, sout;
+  qmul q;
+} tconv_q;
+
+typedef struct { int32_t zin, zout; float sin, sout; qmul pos, neg; } lrelu_q;
+typedef struct { int32_t z1, z2, zo; float s1, s2, so; qmul m1, m2, mo; } add_q;
+
+static void load_conv_f(const pk_file* pk, const char* pre, int idx, conv_f* L) {
+  const int32_t* opt = PKI(pre, "conv", idx, "opt");
+  char name[96];
+  snprintf(name, sizeof name, "%s.conv.%d.w", pre, idx);
+  const pk_entry* e = pk_find(pk, name);
+  if (e->dtype != 0) { fprintf(stderr, "%s not f32\n", name); abort(); }
+  L->cout = (int)e->shape[0]; L->k = (int)e->shape[1]; L->cig = (int)e->shape[2];
+  L->stride = opt[0]; L->groups = opt[2]; L->cog = L->cout / L->groups;
+  const float* w = (const float*)(pk->blob + e->offset);
+  L->b = PKF(pre, "conv", idx, "b");
+  int K = L->k * L->cig;
+  L->wt = (float*)malloc(sizeof(float) * (size_t)L->cout * K);
+  for (int g = 0; g < L->groups; ++g)
+    for (int kk = 0; kk < K; ++kk)
+      for (int co = 0; co < L->cog; ++co)
+        L->wt[((size_t)g * K + kk) * L->cog + co] = w[((size_t)(g * L->cog + co)) * K + kk];
+}
+
+static void load_conv_q(const pk_file* pk, const char* pre, int idx, conv_q* L) {
+  const int32_t* opt = PKI(pre, "conv", idx, "opt");
+  char name[96];
+  snprintf(name, sizeof name, "%s.conv.%d.w", pre, idx);
+  const pk_entry* e = pk_find(pk, name);
+  if (e->dtype != 1) { fprintf(stderr, "%s not i8\n", name); abort(); }
+  L->cout = (int)e->shape[0]; L->k = (int)e->shape[1]; L->cig = (int)e->shape[2];
+  L->stride = opt[0]; L->groups = opt[2]; L->cog = L->cout / L->groups;
+  const int8_t* w = (const int8_t*)(pk->blob + e->offset);
+  L->b = PKI(pre, "conv", idx, "b");
+  const float* q = PKF(pre, "conv", idx, "q");
+  const float* ws = PKF(pre, "conv", idx, "wscale");
+  L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
+  int K = L->k * L->cig;
+  L->wt = (int16_t*)malloc(sizeof(int16_t) * (size_t)L->cout * K);
+  for (int g = 0; g < L->groups; ++g)
+    for (int kk = 0; kk < K; ++kk)
+      for (int co = 0; co < L->cog; ++co)
+        L->wt[((size_t)g * K + kk) * L->cog + co] = w[((size_t)(g * L->cog + co)) * K + kk];
+  L->q = (qmul*)malloc(sizeof(qmul) * L->cout);
+  for (int c = 0; c < L->cout; ++c)
+    L->q[c] = quantize_multiplier((double)L->sin * (double)ws[c] / (double)L->sout);
+}
+
+static void load_dw_f(const pk_file* pk, const char* pre, int idx, dw_f* L) {
+  const int32_t* opt = PKI(pre, "dw", idx, "opt");
+  char name[96];
+  snprintf(name, sizeof name, "%s.dw.%d.w", pre, idx);
+  const pk_entry* e = pk_find(pk, name);
+  if (e->dtype != 0) { fprintf(stderr, "%s not f32\n", name); abort(); }
+  L->k = (int)e->shape[0]; L->c = (int)e->shape[1]; L->dil = opt[1];
+  L->w = (const float*)(pk->blob + e->offset);
+  L->b = PKF(pre, "dw", idx, "b");
+}
+
+static void load_dw_q(const pk_file* pk, const char* pre, int idx, dw_q* L) {
+  const int32_t* opt = PKI(pre, "dw", idx, "opt");
+  char name[96];
+  snprintf(name, sizeof name, "%s.dw.%d.w", pre, idx);
+  const pk_entry* e = pk_find(pk, name);
+  if (e->dtype != 1) { fprintf(stderr, "%s not i8\n", name); abort(); }
+  L->k = (int)e->shape[0]; L->c = (int)e->shape[1]; L->dil = opt[1];
+  L->w = (const int8_t*)(pk->blob + e->offset);
+  L->b = PKI(pre, "dw", idx, "b");
+  const float* q = PKF(pre, "dw", idx, "q");
+  const float* ws = PKF(pre, "dw", idx, "wscale");
+  L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
+  L->q = (qmul*)malloc(sizeof(qmul) * L->c);
+  for (int c = 0; c < L->c; ++c)
+    L->q[c] = quantize_multiplier((double)L->sin * (double)ws[c] / (double)L->sout);
+}
+
+static void load_tconv_f(const pk_file* pk, const char* pre, int idx, tconv_f* L) {
+  const int32_t* opt = PKI(pre, "tconv", idx, "opt");
+  char name[96];
+  snprintf(name, sizeof name, "%s.tconv.%d.w", pre, idx);
+  const pk_entry* e = pk_find(pk, name);
+  if (e->dtype != 0) { fprintf(stderr, "%s not f32\n", name); abort(); }
+  L->cout = (int)e->shape[0]; L->k = (int)e->shape[1]; L->cin = (int)e->shape[2];
+  L->stride = opt[0];
+  L->w = (const float*)(pk->blob + e->offset);
+  L->b = PKF(pre, "tconv", idx, "b");
+}
+
+static void load_tconv_q(const pk_file* pk, const char* pre, int idx, tconv_q* L) {
+  const int32_t* opt = PKI(pre, "tconv", idx, "opt");
+  char name[96];
+  snprintf(name, sizeof name, "%s.tconv.%d.w", pre, idx);
+  const pk_entry* e = pk_find(pk, name);
+  if (e->dtype != 1) { fprintf(stderr, "%s not i8\n", name); abort(); }
+  L->cout = (int)e->shape[0]; L->k = (int)e->shape[1]; L->cin = (int)e->shape[2];
+  L->stride = opt[0];
+  L->w = (const int8_t*)(pk->blob + e->offset);
+  L->b = PKI(pre, "tconv", idx, "b");
+  const float* q = PKF(pre, "tconv", idx, "q");
+  const float* ws = PKF(pre, "tconv", idx, "wscale");
+  L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
+  L->q = quantize_multiplier((double)L->sin * (double)ws[0] / (double)L->sout);
+}
+
+static void load_lrelu_q(const pk_file* pk, const char* pre, int idx, lrelu_q* L) {
+  const float* q = PKF(pre, "lrelu8", idx, "q");
+  L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
+  L->pos = quantize_multiplier((double)L->sin / (double)L->sout);
+  L->neg = quantize_multiplier((double)L->sin * (double)LRELU_ALPHA / (double)L->sout);
+}
+
+static void load_add_q(const pk_file* pk, const char* pre, int idx, add_q* L) {
+  const float* q = PKF(pre, "add8", idx, "q");
+  L->s1 = q[0]; L->z1 = (int32_t)q[1]; L->s2 = q[2]; L->z2 = (int32_t)q[3];
+  L->so = q[4]; L->zo = (int32_t)q[5];
+  double twice = 2.0 * ((double)L->s1 > (double)L->s2 ? (double)L->s1 : (double)L->s2);
+  L->m1 = quantize_multiplier((double)L->s1 / twice);
+  L->m2 = quantize_multiplier((double)L->s2 / twice);
+  L->mo = quantize_multiplier(twice / ((double)(1 << 20) * (double)L->so));
+}
+
+/* out[Tout][Cout]; in[Tin][Cin]; Tout = (Tin-k)/stride+1 */
+static void conv_f_run(const conv_f* L, const float* in, int Tin, float* out) {
+  int Cin = L->cig * L->groups, K = L->k * L->cig;
+  int Tout = (Tin - L->k) / L->stride + 1;
+  float acc[512];
+  for (int t = 0; t < Tout; ++t) {
+    for (int g = 0; g < L->groups; ++g) {
+      const float* wt = L->wt + (size_t)g * K * L->cog;
+      for (int co = 0; co < L->cog; ++co) acc[co] = 0.f;
+      for (int tap = 0; tap < L->k; ++tap) {
+        const float* xr = in + (size_t)(t * L->stride + tap) * Cin + g * L->cig;
+        for (int c = 0; c < L->cig; ++c) {
+          float x = xr[c];
+          const float* w = wt + (size_t)(tap * L->cig + c) * L->cog;
+          for (int co = 0; co < L->cog; ++co) acc[co] = fmaf(x, w[co], acc[co]);
+        }
+      }
+      float* o = out + (size_t)t * L->cout + g * L->cog;
+      const float* b = L->b + g * L->cog;
+      for (int co = 0; co < L->cog; ++co) o[co] = acc[co] + b[co];
+    }
+  }
+}
+
+static void conv_q_run(const conv_q* L, const int8_t* in, int Tin, int8_t* out, int mode) {
+  int Cin = L->cig * L->groups, K = L->k * L->cig;
+  int Tout = (Tin - L->k) / L->stride + 1;
+  int32_t acc[512];
+  for (int t = 0; t < Tout; ++t) {
+    for (int g = 0; g < L->groups; ++g) {
+      const int16_t* wt = L->wt + (size_t)g * K * L->cog;
+      for (int co = 0; co < L->cog; ++co) acc[co] = 0;
+      for (int tap = 0; tap < L->k; ++tap) {
+        const int8_t* xr = in + (size_t)(t * L->stride + tap) * Cin + g * L->cig;
+        for (int c = 0; c < L->cig; ++c) {
+          int32_t x = (int32_t)xr[c] - L->zin;
+          const int16_t* w = wt + (size_t)(tap * L->cig + c) * L->cog;
+          for (int co = 0; co < L->cog; ++co) acc[co] += x * (int32_t)w[co];
+        }
+      }
+      int8_t* o = out + (size_t)t * L->cout + g * L->cog;
+      for (int co = 0; co < L->cog; ++co) {
+        int c = g * L->cog + co;
+        int32_t a = acc[co] + L->b[c];
+        int32_t r = mode ? mbqm_double(a, L->q[c]) : mbqm_exact(a, L->q[c]);
+        o[co] = clamp8(r + L->zout);
+      }
+    }
+  }
+}
+
+/* in[Tin][C] with Tin = Tout + (k-1)*dil */
+static void dw_f_run(const dw_f* L, const float* in, int Tout, float* out) {
+  for (int t = 0; t < Tout; ++t)
+    for (int c = 0; c < L->c; ++c) {
+      float acc = 0.f;
+      for (int k = 0; k < L->k; ++k) acc = fmaf(in[(size_t)(t + k * L->dil) * L->c + c], L->w[k * L->c + c], acc);
+      out[(size_t)t * L->c + c] = acc + L->b[c];
+    }
+}
+
+static void dw_q_run(const dw_q* L, const int8_t* in, int Tout, int8_t* out, int mode) {
+  for (int t = 0; t < Tout; ++t)
+    for (int c = 0; c < L->c; ++c) {
+      int32_t acc = 0;
+      for (int k = 0; k < L->k; ++k)
+        acc += ((int32_t)in[(size_t)(t + k * L->dil) * L->c + c] - L->zin) * (int32_t)L->w[k * L->c + c];
+      acc += L->b[c];
+      int32_t r = mode ? mbqm_double(acc, L->q[c]) : mbqm_exact(acc, L->q[c]);
+      out[(size_t)t * L->c + c] = clamp8(r + L->zout);
+    }
+}
+
+/* out[(Tin-1)*s+k][Cout] (bias included) */
+static void tconv_f_run(const tconv_f* L, const float* in, int Tin, float* out) {
+  int Tout = (Tin - 1) * L->stride + L->k;
+  for (int tau = 0; tau < Tout; ++tau)
+    for (int co = 0; co < L->cout; ++co) {
+      float acc = 0.f;
+      for (int t = 0; t < Tin; ++t) {
+        int j = tau - t * L->stride;
+        if (j < 0 || j >= L->k) continue;
+        const float* x = in + (size_t)t * L->cin;
+        const float* w = L->w + ((size_t)co * L->k + j) * L->cin;
+        for (int c = 0; c < L->cin; ++c) acc = fmaf(x[c], w[c], acc);
+      }
+      out[(size_t)tau * L->cout + co] = acc + L->b[co];
+    }
+}
+
+static void tconv_q_run(const tconv_q* L, const int8_t* in, int in_stride, int Tin, int8_t* out, int mode) {
+  int Tout = (Tin - 1) * L->stride + L->k;
+  for (int tau = 0; tau < Tout; ++tau)
+    for (int co = 0; co < L->cout; ++co) {
+      int32_t acc = 0;
+      for (int t = 0; t < Tin; ++t) {
+        int j = tau - t * L->stride;
+        if (j < 0 || j >= L->k) continue;
+        const int8_t* x = in + (size_t)t * in_stride;
+        const int8_t* w = L->w + ((size_t)co * L->k + j) * L->cin;
+        for (int c = 0; c < L->cin; ++c) acc += ((int32_t)x[c] - L->zin) * (int32_t)w[c];
+      }
+      acc += L->b[co];
+      int32_t r = mode ? mbqm_double(acc, L->q) : mbqm_exact(acc, L->q);
+      out[(size_t)tau * L->cout + co] = clamp8(r + L->zout);
+    }
+}
+
+static inline int8_t lrelu_q_run1(const lrelu_q* L, int8_t x) {
+  int32_t v = (int32_t)x - L->zin;
+  int32_t r = v >= 0 ? mbqm_double(v, L->pos) : mbqm_double(v, L->neg);
+  return clamp8(r + L->zout);
+}
+static void lrelu_q_run(const lrelu_q* L, const int8_t* in, int n, int8_t* out) {
+  for (int i = 0; i < n; ++i) out[i] = lrelu_q_run1(L, in[i]);
+}
+static void add_q_run(const add_q* L, const int8_t* a, const int8_t* b, int n, int8_t* out) {
+  for (int i = 0; i < n; ++i) {
+    int32_t va = ((int32_t)a[i] - L->z1) * (1 << 20);
+    int32_t vb = ((int32_t)b[i] - L->z2) * (1 << 20);
+    int32_t sa = mbqm_double(va, L->m1);
+    int32_t sb = mbqm_double(vb, L->m2);
+    int32_t r = mbqm_double(sa + sb, L->mo) + L->zo;
+    out[i] = clamp8(r);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* model                                                                     */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  conv_f first;                         /* enc.conv.0 */
+  dw_f dw[7]; conv_f pw[7]; conv_f cv[6]; /* float resblocks: 0-2 @64, 3-5 @128, 6 = @256 (dw+pw only) */
+  conv_f down0, down1;                  /* enc.conv.7 (k10 s5), enc.conv.14 (k4 s2 g2) */
+  lrelu_q lr[7];
+  conv_q r0b;                           /* enc.conv.16 */
+  dw_q dwq[2]; conv_q pwq[2]; conv_q cvq[2]; /* int8 resblocks 1,2 */
+  add_q add[2];
+  conv_q down2, bott;                   /* enc.conv.21, enc.conv.22 */
+  float q_r0_s; int32_t q_r0_z;         /* quant.0 */
+  float q_x1_s; int32_t q_x1_z;         /* quant.1 */
+  float dq_r0_s; int32_t dq_r0_z;       /* dequant.0 */
+  float out_s; int32_t out_z;           /* dequant.9 */
+} enc_model;
+
+typedef struct {
+  conv_f head;                  /* dec.conv.0 k3 g4 */
+  float q0_s; int32_t q0_z;     /* quant.0 */
+  tconv_q up0[4]; const float* sub0[4];
+  float q1_s; int32_t q1_z;     /* quant.1 */
+  dw_q dwq[3]; conv_q pwq[3]; conv_q cvq[3]; lrelu_q lr[6]; add_q add[2];
+  float q3_s; int32_t q3_z;     /* quant.3 (X1) */
+  tconv_q up1[2]; const float* sub1[2];
+  dw_f dw[6]; conv_f pw[6]; conv_f cv[6]; /* float resblocks 0-2 @128, 3-5 @64 */
+  tconv_f up2; const float* sub2;
+  tconv_f up3; const float* sub3;
+} dec_model;
+
+typedef struct {
+  pk_file pk;
+  int mode;
+  enc_model enc;
+  dec_model dec;
+  const float* cb; /* [46][16][64] */
+  /* log-mel tables (window 640, fft 1024, 160 bands) */
+  double hann[640];
+  int mel_start, mel_end;
+  int mel_band[513];
+  double mel_w[513];
+} lo_model;
+
+typedef struct {
+  /* encoder state (floats, as the reference's resource variables) */
+  float e_first[48];
+  float e_r0[3][18 * 64];   /* 2/6/18 rows x 64 */
+  float e_d0[5 * 64];
+  float e_r1[3][18 * 128];
+  float e_d1[2 * 128];
+  float e_r2[3][18 * 256];  /* 2 (float region), 6, 18 */
+  float e_d2[2 * 256];
+  float e_bott[2 * 512];
+  /* decoder state */
+  float d_head[2 * 64];
+  float d_up0[4][2 * 64];
+  float d_r0[3][18 * 256];
+  float d_up1[2][2 * 64];
+  float d_r1[3][18 * 128];
+  float d_up2[5 * 64];
+  float d_r2[3][18 * 64];
+  float d_up3[48];
+  /* log-mel state: previous hop */
+  double mel_prev[320];
+  /* trace taps (optional) */
+  float* trace;
+  int trace_cap, trace_len;
+  int trace_off[64], trace_n;
+} lo_stream;
+
+static void tap(lo_stream* s, const float* p, int n) {
+  if (!s->trace || s->trace_n >= 64) return;
+  if (s->trace_len + n > s->trace_cap) return;
+  memcpy(s->trace + s->trace_len, p, sizeof(float) * (size_t)n);
+  s->trace_off[s->trace_n++] = s->trace_len;
+  s->trace_len += n;
+}
+static void tap8(lo_stream* s, const int8_t* p, int n) {
+  if (!s->trace || s->trace_n >= 64) return;
+  if (s->trace_len + n > s->trace_cap) return;
+  for (int i = 0; i < n; ++i) s->trace[s->trace_len + i] = (float)p[i];
+  s->trace_off[s->trace_n++] = s->trace_len;
+  s->trace_len += n;
+}
+
+static void init_logmel(lo_model* m);
+
+lo_model* lo_load(const char* pack_path, int requant_mode) {
+  lo_model* m = (lo_model*)calloc(1, sizeof(lo_model));
+  if (pk_open(&m->pk, pack_path) != 0) { free(m); return NULL; }
+  const pk_file* pk = &m->pk;
+  m->mode = requant_mode;
+  m->cb = (const float*)(pk->blob + pk_find(pk, "rvq.codebooks")->offset);
+  enc_model* E = &m->enc;
+  load_conv_f(pk, "enc", 0, &E->first);
+  for (int r = 0; r < 3; ++r) {
+    load_dw_f(pk, "enc", r, &E->dw[r]);
+    load_conv_f(pk, "enc", 1 + 2 * r, &E->pw[r]);
+    load_conv_f(pk, "enc", 2 + 2 * r, &E->cv[r]);
+    load_dw_f(pk, "enc", 3 + r, &E->dw[3 + r]);
+    load_conv_f(pk, "enc", 8 + 2 * r, &E->pw[3 + r]);
+    load_conv_f(pk, "enc", 9 + 2 * r, &E->cv[3 + r]);
+  }
+  load_conv_f(pk, "enc", 7, &E->down0);
+  load_conv_f(pk, "enc", 14, &E->down1);
+  load_dw_f(pk, "enc", 6, &E->dw[6]);
+  load_conv_f(pk, "enc", 15, &E->pw[6]);
+  for (int i = 0; i < 7; ++i) load_lrelu_q(pk, "enc", i, &E->lr[i]);
+  load_conv_q(pk, "enc", 16, &E->r0b);
+  for (int r = 0; r < 2; ++r) {
+    load_dw_q(pk, "enc", 7 + r, &E->dwq[r]);
+    load_conv_q(pk, "enc", 17 + 2 * r, &E->pwq[r]);
+    load_conv_q(pk, "enc", 18 + 2 * r, &E->cvq[r]);
+    load_add_q(pk, "enc", r, &E->add[r]);
+  }
+  load_conv_q(pk, "enc", 21, &E->down2);
+  load_conv_q(pk, "enc", 22, &E->bott);
+  { const float* q = PKF("enc", "quant", 0, "q"); E->q_r0_s = q[0]; E->q_r0_z = (int32_t)q[1]; }
+  { const float* q = PKF("enc", "quant", 1, "q"); E->q_x1_s = q[0]; E->q_x1_z = (int32_t)q[1]; }
+  { const float* q = PKF("enc", "dequant", 0, "q"); E->dq_r0_s = q[0]; E->dq_r0_z = (int32_t)q[1]; }
+  { const float* q = PKF("enc", "dequant", 9, "q"); E->out_s = q[0]; E->out_z = (int32_t)q[1]; }
+
+  dec_model* D = &m->dec;
+  load_conv_f(pk, "dec", 0, &D->head);
+  { const float* q = PKF("dec", "quant", 0, "q"); D->q0_s = q[0]; D->q0_z = (int32_t)q[1]; }
+  { const float* q = PKF("dec", "quant", 1, "q"); D->q1_s = q[0]; D->q1_z = (int32_t)q[1]; }
+  { const float* q = PKF("dec", "quant", 3, "q"); D->q3_s = q[0]; D->q3_z = (int32_t)q[1]; }
+  for (int g = 0; g < 4; ++g) { load_tconv_q(pk, "dec", g, &D->up0[g]); D->sub0[g] = PKF("dec", "sub", g, "c"); }
+  for (int r = 0; r < 3; ++r) {
+    load_dw_q(pk, "dec", r, &D->dwq[r]);
+    load_conv_q(pk, "dec", 1 + 2 * r, &D->pwq[r]);
+    load_conv_q(pk, "dec", 2 + 2 * r, &D->cvq[r]);
+  }
+  for (int i = 0; i < 6; ++i) load_lrelu_q(pk, "dec", i, &D->lr[i]);
+  for (int i = 0; i < 2; ++i) load_add_q(pk, "dec", i, &D->add[i]);
+  for (int g = 0; g < 2; ++g) { load_tconv_q(pk, "dec", 4 + g, &D->up1[g]); D->sub1[g] = PKF("dec", "sub", 4 + g, "c"); }
+  for (int r = 0; r < 3; ++r) {
+    load_dw_f(pk, "dec", 3 + r, &D->dw[r]);
+    load_conv_f(pk, "dec", 7 + 2 * r, &D->pw[r]);
+    load_conv_f(pk, "dec", 8 + 2 * r, &D->cv[r]);
+    load_dw_f(pk, "dec", 6 + r, &D->dw[3 + r]);
+    load_conv_f(pk, "dec", 13 + 2 * r, &D->pw[3 + r]);
+    load_conv_f(pk, "dec", 14 + 2 * r, &D->cv[3 + r]);
+  }
+  load_tconv_f(pk, "dec", 6, &D->up2); D->sub2 = PKF("dec", "sub", 6, "c");
+  load_tconv_f(pk, "dec", 7, &D->up3); D->sub3 = PKF("dec", "sub", 7, "c");
+  init_logmel(m);
+  return m;
+}
+
+void lo_free(lo_model* m) { if (m) { free(m->pk.blob); free(m); } }
+
+lo_stream* lo_stream_new(void) { return (lo_stream*)calloc(1, sizeof(lo_stream)); }
+void lo_stream_reset(lo_stream* s) {
+  float* tr = s->trace; int cap = s->trace_cap;
+  memset(s, 0, sizeof *s);
+  s->trace = tr; s->trace_cap = cap;
+}
+void lo_stream_free(lo_stream* s) { free(s); }
+void lo_stream_set_trace(lo_stream* s, float* buf, int cap) { s->trace = buf; s->trace_cap = cap; s->trace_len = 0; s->trace_n = 0; }
+int lo_stream_trace_count(const lo_stream* s) { return s->trace_n; }
+int lo_stream_trace_offset(const lo_stream* s, int i) { return i < s->trace_n ? s->trace_off[i] : s->trace_len; }
+size_t lo_stream_sizeof(void) { return sizeof(lo_stream); }
+
+/* x' = concat(state[S][C], x[T][C]) -> buf[(S+T)][C]; state <- last S rows of buf */
+static void push_state(float* state, int S, const float* x, int T, int C, float* buf) {
+  memcpy(buf, state, sizeof(float) * (size_t)S * C);
+  memcpy(buf + (size_t)S * C, x, sizeof(float) * (size_t)T * C);
+  memcpy(state, buf + (size_t)T * C, sizeof(float) * (size_t)S * C);
+}
+
+/* float residual block: x[T][C] updated in place */
+static void resblock_f(const dw_f* dw, const conv_f* pw, const conv_f* cv, float* state, float* x, int T,
+                       float* s0, float* s1, float* s2) {
+  int C = dw->c, S = 2 * dw->dil;
+  for (int i = 0; i < T * C; ++i) s0[i] = lrelu_f(x[i]);
+  push_state(state, S, s0, T, C, s1);
+  dw_f_run(dw, s1, T, s0);
+  conv_f_run(pw, s0, T, s2);
+  for (int i = 0; i < T * C; ++i) s2[i] = lrelu_f(s2[i]);
+  conv_f_run(cv, s2, T, s0);
+  for (int i = 0; i < T * C; ++i) x[i] = s0[i] + x[i];
+}
+
+/* int8 state plumbing: float state, dequantised new rows, re-quantised concat (graph ops 108-114) */
+static void push_state_q(float* state, int S, const int8_t* a, int T, int C, float s, int32_t z, int8_t* buf8) {
+  float tmp[20 * 512];
+  memcpy(tmp, state, sizeof(float) * (size_t)S * C);
+  for (int i = 0; i < T * C; ++i) tmp[(size_t)S * C + i] = dequantize_f(a[i], s, z);
+  for (int i = 0; i < (S + T) * C; ++i) buf8[i] = quantize_f(tmp[i], s, z);
+  for (int i = 0; i < S * C; ++i) state[i] = dequantize_f(buf8[(size_t)T * C + i], s, z);
+}
+
+void lo_encode_frame(const lo_model* m, lo_stream* s, const int16_t* pcm, float* feat) {
+  const enc_model* E = &m->enc;
+  float x[20 * 64], s0[38 * 64], s1[38 * 64], s2[20 * 64];
+  float in[368];
+  memcpy(in, s->e_first, sizeof(float) * 48);
+  for (int i = 0; i < HOP; ++i) in[48 + i] = -(float)pcm[i] / -32768.f; /* dsp_utils.h:106-108 */
+  memcpy(s->e_first, in + 320, sizeof(float) * 48);
+  conv_f_run(&E->first, in, 368, x);                      /* [20][64] */
+  tap(s, x, 20 * 64);
+  for (int r = 0; r < 3; ++r) { resblock_f(&E->dw[r], &E->pw[r], &E->cv[r], s->e_r0[r], x, 20, s0, s1, s2); tap(s, x, 20 * 64); }
+  for (int i = 0; i < 20 * 64; ++i) s0[i] = lrelu_f(x[i]);
+  push_state(s->e_d0, 5, s0, 20, 64, s1);
+  float y[4 * 128];
+  conv_f_run(&E->down0, s1, 25, y);                       /* [4][128] */
+  tap(s, y, 4 * 128);
+  for (int r = 0; r < 3; ++r) { resblock_f(&E->dw[3 + r], &E->pw[3 + r], &E->cv[3 + r], s->e_r1[r], y, 4, s0, s1, s2); tap(s, y, 4 * 128); }
+  for (int i = 0; i < 4 * 128; ++i) s0[i] = lrelu_f(y[i]);
+  push_state(s->e_d1, 2, s0, 4, 128, s1);
+  float z[2 * 256];
+  conv_f_run(&E->down1, s1, 6, z);                        /* x148 [2][256] */
+  tap(s, z, 2 * 256);
+  /* resblock 0 @256: float dw + pw, then int8 */
+  for (int i = 0; i < 2 * 256; ++i) s0[i] = lrelu_f(z[i]);
+  push_state(s->e_r2[0], 2, s0, 2, 256, s1);
+  dw_f_run(&E->dw[6], s1, 2, s0);
+  conv_f_run(&E->pw[6], s0, 2, s2);
+  tap(s, s2, 2 * 256);
+  int8_t a8[20 * 256], b8[20 * 256], c8[2 * 512], X[2 * 256], X2[2 * 256];
+  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(s2[i], E->q_r0_s, E->q_r0_z);
+  lrelu_q_run(&E->lr[0], a8, 512, b8);
+  conv_q_run(&E->r0b, b8, 2, a8, m->mode);
+  for (int i = 0; i < 512; ++i) {
+    float v = dequantize_f(a8[i], E->dq_r0_s, E->dq_r0_z) + z[i];
+    X[i] = quantize_f(v, E->q_x1_s, E->q_x1_z);
+  }
+  tap8(s, X, 512);
+  for (int r = 0; r < 2; ++r) {
+    const lrelu_q* la = &E->lr[1 + 2 * r];
+    lrelu_q_run(la, X, 512, a8);
+    int S = 2 * E->dwq[r].dil;
+    push_state_q(s->e_r2[1 + r], S, a8, 2, 256, la->sout, la->zout, b8);
+    dw_q_run(&E->dwq[r], b8, 2, a8, m->mode);
+    conv_q_run(&E->pwq[r], a8, 2, b8, m->mode);
+    lrelu_q_run(&E->lr[2 + 2 * r], b8, 512, a8);
+    conv_q_run(&E->cvq[r], a8, 2, b8, m->mode);
+    add_q_run(&E->add[r], b8, X, 512, X2);
+    memcpy(X, X2, 512);
+    tap8(s, X, 512);
+  }
+  lrelu_q_run(&E->lr[5], X, 512, a8);
+  push_state_q(s->e_d2, 2, a8, 2, 256, E->lr[5].sout, E->lr[5].zout, b8);
+  conv_q_run(&E->down2, b8, 4, c8, m->mode);              /* [1][512] */
+  lrelu_q_run(&E->lr[6], c8, 512, a8);
+  push_state_q(s->e_bott, 2, a8, 1, 512, E->lr[6].sout, E->lr[6].zout, b8);
+  int8_t f8[64];
+  conv_q_run(&E->bott, b8, 3, f8, m->mode);               /* [1][64] */
+  tap8(s, f8, 64);
+  for (int i = 0; i < 64; ++i) feat[i] = dequantize_f(f8[i], E->out_s, E->out_z);
+}
+
+/* ------------------------------------------------------------------------ */
+/* RVQ (quantizer.tflite encode/decode subgraphs)             */
+/* ------------------------------------------------------------------------ */
+void lo_rvq_encode(const lo_model* m, const float* feat, int num_stages, int32_t* idx) {
+  float r[64];
+  memcpy(r, feat, sizeof r);
+  for (int k = 0; k < RVQ_STAGES; ++k) {
+    const float* C = m->cb + (size_t)k * RVQ_CODES * 64;
+    int best = 0;
+    float bestd = 0.f;
+    for (int j = 0; j < RVQ_CODES; ++j) {
+      float sum = 0.f;
+      for (int d = 0; d < 64; ++d) {
+        float df = r[d] - C[j * 64 + d];
+        float sq = df * df;
+        sum = sum + sq;
+      }
+      if (j == 0 || sum < bestd) { best = j; bestd = sum; }
+    }
+    idx[k] = k < num_stages ? best : -1;
+    if (k + 1 < RVQ_STAGES) {
+      const float* q = C + best * 64;
+      for (int d = 0; d < 64; ++d) {
+        float t1 = q[d] - r[d];
+        float t2 = r[d] + t1;
+        r[d] = r[d] - t2;
+      }
+    }
+  }
+}
+
+void lo_rvq_decode(const lo_model* m, const int32_t* idx, float* feat) {
+  for (int d = 0; d < 64; ++d) {
+    float acc = 0.f;
+    for (int k = 0; k < RVQ_STAGES; ++k) {
+      int i = idx[k] < 0 ? 0 : idx[k];
+      float mask = idx[k] != -1 ? 1.f : 0.f;
+      float v = m->cb[((size_t)k * RVQ_CODES + i) * 64 + d] * mask;
+      acc = k == 0 ? v : acc + v;
+    }
+    feat[d] = acc;
+  }
+}
+
+/* packet.h:91-122 with zero header bits: byte j = idx[2j] << 4 | idx[2j+1] */
+void lo_pack(const int32_t* idx, int num_stages, uint8_t* packet) {
+  int nbytes = (num_stages * 4 + 7) / 8;
+  memset(packet, 0, (size_t)nbytes);
+  for (int k = 0; k < num_stages; ++k) {
+    int v = idx[k] & 15;
+    packet[k >> 1] |= (uint8_t)((k & 1) ? v : (v << 4));
+  }
+}
+void lo_unpack(const uint8_t* packet, int num_stages, int32_t* idx) {
+  for (int k = 0; k < RVQ_STAGES; ++k)
+    idx[k] = k < num_stages ? ((packet[k >> 1] >> ((k & 1) ? 0 : 4)) & 15) : -1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* decoder                                                                   */
+/* ------------------------------------------------------------------------ */
+/* y = t (+bias, from tconv) + concat(state[S], zeros); state <- last S rows - bias; out = first T rows */
+static void overlap_state(float* y, int rows, int C, float* state, int S, const float* bias) {
+  for (int i = 0; i < S * C; ++i) y[i] = y[i] + state[i];
+  for (int i = S * C; i < rows * C; ++i) y[i] = y[i] + 0.f;
+  for (int r = 0; r < S; ++r)
+    for (int c = 0; c < C; ++c) state[r * C + c] = y[(size_t)(rows - S + r) * C + c] - bias[c];
+}
+
+void lo_decode_frame(const lo_model* m, lo_stream* s, const float* feat, int16_t* pcm, float* pcm_f) {
+  const dec_model* D = &m->dec;
+  float s0[38 * 128], s1[38 * 128], s2[25 * 128];
+  float in[3 * 64], h[512];
+  push_state(s->d_head, 2, feat, 1, 64, in);
+  conv_f_run(&D->head, in, 3, h);
+  tap(s, h, 512);
+  int8_t h8[512], t8[6 * 64];
+  for (int i = 0; i < 512; ++i) h8[i] = quantize_f(lrelu_f(h[i]), D->q0_s, D->q0_z);
+  float x164[2 * 256];
+  for (int g = 0; g < 4; ++g) {
+    float y[4 * 64];
+    tconv_q_run(&D->up0[g], h8 + g * 128, 128, 1, t8, m->mode);
+    for (int i = 0; i < 4 * 64; ++i) y[i] = dequantize_f(t8[i], D->up0[g].sout, D->up0[g].zout);
+    overlap_state(y, 4, 64, s->d_up0[g], 2, D->sub0[g]);
+    for (int t = 0; t < 2; ++t) memcpy(x164 + t * 256 + g * 64, y + t * 64, sizeof(float) * 64);
+  }
+  tap(s, x164, 512);
+  int8_t a8[20 * 256], b8[20 * 256], X[512], X2[512];
+  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(lrelu_f(x164[i]), D->q1_s, D->q1_z);
+  /* resblock 0 (skip is the float x164) */
+  push_state_q(s->d_r0[0], 2, a8, 2, 256, D->q1_s, D->q1_z, b8);
+  dw_q_run(&D->dwq[0], b8, 2, a8, m->mode);
+  conv_q_run(&D->pwq[0], a8, 2, b8, m->mode);
+  lrelu_q_run(&D->lr[0], b8, 512, a8);
+  conv_q_run(&D->cvq[0], a8, 2, b8, m->mode);
+  for (int i = 0; i < 512; ++i) {
+    float v = dequantize_f(b8[i], D->cvq[0].sout, D->cvq[0].zout) + x164[i];
+    X[i] = quantize_f(v, D->q3_s, D->q3_z);
+  }
+  tap8(s, X, 512);
+  for (int r = 1; r < 3; ++r) {
+    const lrelu_q* la = &D->lr[2 * r - 1];
+    lrelu_q_run(la, X, 512, a8);
+    int S = 2 * D->dwq[r].dil;
+    push_state_q(s->d_r0[r], S, a8, 2, 256, la->sout, la->zout, b8);
+    dw_q_run(&D->dwq[r], b8, 2, a8, m->mode);
+    conv_q_run(&D->pwq[r], a8, 2, b8, m->mode);
+    lrelu_q_run(&D->lr[2 * r], b8, 512, a8);
+    conv_q_run(&D->cvq[r], a8, 2, b8, m->mode);
+    add_q_run(&D->add[r - 1], b8, X, 512, X2);
+    memcpy(X, X2, 512);
+    tap8(s, X, 512);
+  }
+  lrelu_q_run(&D->lr[5], X, 512, a8); /* [2][256] */
+  float x231[4 * 128];
+  for (int g = 0; g < 2; ++g) {
+    float y[6 * 64];
+    tconv_q_run(&D->up1[g], a8 + g * 128, 256, 2, t8, m->mode);
+    for (int i = 0; i < 6 * 64; ++i) y[i] = dequantize_f(t8[i], D->up1[g].sout, D->up1[g].zout);
+    overlap_state(y, 6, 64, s->d_up1[g], 2, D->sub1[g]);
+    for (int t = 0; t < 4; ++t) memcpy(x231 + t * 128 + g * 64, y + t * 64, sizeof(float) * 64);
+  }
+  tap(s, x231, 4 * 128);
+  for (int r = 0; r < 3; ++r) { resblock_f(&D->dw[r], &D->pw[r], &D->cv[r], s->d_r1[r], x231, 4, s0, s1, s2); tap(s, x231, 4 * 128); }
+  for (int i = 0; i < 4 * 128; ++i) s0[i] = lrelu_f(x231[i]);
+  float y25[25 * 64];
+  tconv_f_run(&D->up2, s0, 4, y25);
+  overlap_state(y25, 25, 64, s->d_up2, 5, D->sub2);
+  tap(s, y25, 20 * 64);
+  for (int r = 0; r < 3; ++r) { resblock_f(&D->dw[3 + r], &D->pw[3 + r], &D->cv[3 + r], s->d_r2[r], y25, 20, s0, s1, s2); tap(s, y25, 20 * 64); }
+  for (int i = 0; i < 20 * 64; ++i) s0[i] = lrelu_f(y25[i]);
+  float out[368];
+  tconv_f_run(&D->up3, s0, 20, out);
+  overlap_state(out, 368, 1, s->d_up3, 48, D->sub3);
+  for (int i = 0; i < HOP; ++i) {
+    if (pcm_f) pcm_f[i] = out[i];
+    /* dsp_utils.h:54-88: scale, clip, C truncation */
+    float v = out[i] * 32768.f;
+    v = v < -32768.f ? -32768.f : v;
+    v = v > 32767.f ? 32767.f : v;
+    pcm[i] = (int16_t)v;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* log-mel (log_mel_spectrogram_extractor_impl.cc:96-126)     */
+/* ------------------------------------------------------------------------ */
+#define MEL_WIN 640
+#define MEL_FFT 1024
+#define MEL_BINS 513
+#define MEL_BANDS 160
+
+static double hz_to_mel(double f) { return 1127.0 * log1p(f / 700.0); }
+
+static void init_logmel(lo_model* m) {
+  const double PI = 3.14159265358979323846;
+  for (int i = 0; i < MEL_WIN; ++i) m->hann[i] = 0.5 - 0.5 * cos(2.0 * PI * i / MEL_WIN);
+  double lo = 0.0, hi = 0.495 * 16000.0;
+  double mel_lo = hz_to_mel(lo), mel_hi = hz_to_mel(hi);
+  double spacing = (mel_hi - mel_lo) / (MEL_BANDS + 1);
+  double center[MEL_BANDS + 1];
+  for (int i = 0; i <= MEL_BANDS; ++i) center[i] = mel_lo + spacing * (i + 1);
+  double hz_per_bin = 0.5 * 16000.0 / (MEL_BINS - 1);
+  m->mel_start = (int)(1.5 + lo / hz_per_bin);
+  m->mel_end = (int)(hi / hz_per_bin);
+  int channel = 0;
+  for (int i = 0; i < MEL_BINS; ++i) {
+    double melf = hz_to_mel(i * hz_per_bin);
+    if (i < m->mel_start || i > m->mel_end) { m->mel_band[i] = -2; m->mel_w[i] = 0.0; continue; }
+    while (channel < MEL_BANDS && center[channel] < melf) ++channel;
+    m->mel_band[i] = channel - 1;
+    int ch = channel - 1;
+    if (ch >= 0) m->mel_w[i] = (center[ch + 1] - melf) / (center[ch + 1] - center[ch]);
+    else m->mel_w[i] = (center[0] - melf) / (center[0] - mel_lo);
+  }
+}
+
+static void fft1024(double* re, double* im) {
+  const int N = MEL_FFT;
+  const double PI = 3.14159265358979323846;
+  for (int i = 1, j = 0; i < N; ++i) {
+    int bit = N >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+  }
+  for (int len = 2; len <= N; len <<= 1) {
+    double ang = -2.0 * PI / len;
+    for (int i = 0; i < N; i += len)
+      for (int k = 0; k < len / 2; ++k) {
+        double wr = cos(ang * k), wi = sin(ang * k);
+        double ur = re[i + k], ui = im[i + k];
+        double vr = re[i + k + len / 2] * wr - im[i + k + len / 2] * wi;
+        double vi = re[i + k + len / 2] * wi + im[i + k + len / 2] * wr;
+        re[i + k] = ur + vr; im[i + k] = ui + vi;
+        re[i + k + len / 2] = ur - vr; im[i + k + len / 2] = ui - vi;
+      }
+  }
+}
+
+void lo_logmel(const lo_model* m, lo_stream* s, const int16_t* pcm, float* mel) {
+  double re[MEL_FFT], im[MEL_FFT];
+  memset(re, 0, sizeof re);
+  memset(im, 0, sizeof im);
+  for (int i = 0; i < 320; ++i) re[i] = s->mel_prev[i] * m->hann[i];
+  for (int i = 0; i < 320; ++i) { double v = (double)pcm[i]; re[320 + i] = v * m->hann[320 + i]; s->mel_prev[i] = v; }
+  fft1024(re, im);
+  double out[MEL_BANDS];
+  memset(out, 0, sizeof out);
+  for (int i = m->mel_start; i <= m->mel_end; ++i) {
+    double v = sqrt(re[i] * re[i] + im[i] * im[i]);
+    double w = v * m->mel_w[i];
+    int ch = m->mel_band[i];
+    if (ch >= 0) out[ch] += w;
+    ++ch;
+    if (ch < MEL_BANDS) out[ch] += v - w;
+  }
+  for (int b = 0; b < MEL_BANDS; ++b) {
+    float v = (float)out[b];
+    v = v > 500.f ? v : 500.f;
+    mel[b] = logf(v) / 10.f;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* batched drivers (one stream per row; threads split streams)               */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const lo_model* m;
+  lo_stream** streams;
+  int lo, hi, steps, num_stages, do_encode, do_decode;
+  const int16_t* pcm_in; /* [steps][B][320] */
+  int B;
+  uint8_t* packets;      /* [steps][B][nbytes] or NULL */
+  int16_t* pcm_out;      /* [steps][B][320] or NULL */
+  float* feats;          /* [steps][B][64] or NULL */
+  double sec[4];         /* extract, quantize, dequantize, generate */
+} job;
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+static void* worker(void* arg) {
+  job* j = (job*)arg;
+  int nbytes = j->num_stages / 2;
+  for (int t = 0; t < j->steps; ++t)
+    for (int b = j->lo; b < j->hi; ++b) {
+      size_t row = (size_t)t * j->B + b;
+      float feat[64], lossy[64];
+      int32_t idx[RVQ_STAGES];
+      uint8_t pkt[23];
+      int16_t out[HOP];
+      double t0 = now_s();
+      lo_encode_frame(j->m, j->streams[b], j->pcm_in + row * HOP, feat);
+      double t1 = now_s();
+      lo_rvq_encode(j->m, feat, j->num_stages, idx);
+      lo_pack(idx, j->num_stages, pkt);
+      double t2 = now_s();
+      if (j->feats) memcpy(j->feats + row * 64, feat, sizeof feat);
+      if (j->packets) memcpy(j->packets + row * nbytes, pkt, (size_t)nbytes);
+      j->sec[0] += t1 - t0; j->sec[1] += t2 - t1;
+      if (j->do_decode) {
+        lo_unpack(pkt, j->num_stages, idx);
+        lo_rvq_decode(j->m, idx, lossy);
+        double t3 = now_s();
+        lo_decode_frame(j->m, j->streams[b], lossy, out, NULL);
+        double t4 = now_s();
+        if (j->pcm_out) memcpy(j->pcm_out + row * HOP, out, sizeof out);
+        j->sec[2] += t3 - t2; j->sec[3] += t4 - t3;
+      }
+    }
+  return NULL;
+}
+
+/* Encode(+decode) `steps` frames of B streams with `threads` threads.
+ * Returns wall seconds; stage_sec[4] (summed over threads) if non-NULL. */
+double lo_run_batch(const lo_model* m, lo_stream** streams, int B, int steps, int num_stages, int do_decode,
+                    const int16_t* pcm_in, uint8_t* packets, float* feats, int16_t* pcm_out, int threads,
+                    double* stage_sec) {
+  if (threads < 1) threads = 1;
+  if (threads > B) threads = B;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  job* jobs = (job*)calloc((size_t)threads, sizeof(job));
+  double t0 = now_s();
+  for (int i = 0; i < threads; ++i) {
+    job* j = &jobs[i];
+    j->m = m; j->streams = streams; j->B = B; j->steps = steps; j->num_stages = num_stages;
+    j->do_decode = do_decode; j->pcm_in = pcm_in; j->packets = packets; j->feats = feats; j->pcm_out = pcm_out;
+    j->lo = (int)((long long)B * i / threads); j->hi = (int)((long long)B * (i + 1) / threads);
+    pthread_create(&th[i], NULL, worker, j);
+  }
+  for (int i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+  double dt = now_s() - t0;
+  if (stage_sec) {
+    for (int k = 0; k < 4; ++k) { stage_sec[k] = 0; for (int i = 0; i < threads; ++i) stage_sec[k] += jobs[i].sec[k]; }
+  }
+  free(th); free(jobs);
+  return dt;
+}

@@ -1,0 +1,181 @@
+"""ctypes binding of oracle/liblyra_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  See oracle/lyra_oracle.c for what it restates and how it is
+pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "liblyra_oracle.so")
+DEFAULT_PACK = os.path.join(HERE, "..", "lyra_amd", "assets", "lyra_v1.lyrapack")
+
+MODES = {"exact": 0, "gemmlowp_double": 1}
+
+
+def build(force=False):
+    src = os.path.join(HERE, "lyra_oracle.c")
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "liblyra_oracle.so"], stdout=subprocess.DEVNULL)
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            build()
+        L = C.CDLL(SO)
+        L.lo_load.restype = C.c_void_p
+        L.lo_load.argtypes = [C.c_char_p, C.c_int]
+        L.lo_free.argtypes = [C.c_void_p]
+        L.lo_stream_new.restype = C.c_void_p
+        L.lo_stream_reset.argtypes = [C.c_void_p]
+        L.lo_stream_free.argtypes = [C.c_void_p]
+        L.lo_stream_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.lo_stream_trace_count.argtypes = [C.c_void_p]
+        L.lo_stream_trace_offset.argtypes = [C.c_void_p, C.c_int]
+        L.lo_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_rvq_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.lo_rvq_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.lo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.lo_decode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_logmel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_run_batch.restype = C.c_double
+        L.lo_run_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """The model (weights + requantisation mode)."""
+
+    def __init__(self, pack=DEFAULT_PACK, mode="exact"):
+        self.L = lib()
+        self.h = self.L.lo_load(os.path.abspath(pack).encode(), MODES[mode])
+        if not self.h:
+            raise RuntimeError(f"cannot load {pack}")
+        self.mode = mode
+
+    def __del__(self):
+        try:
+            self.L.lo_free(self.h)
+        except Exception:
+            pass
+
+    def rvq_encode(self, feat, num_stages):
+        feat = np.ascontiguousarray(feat, np.float32).reshape(-1, 64)
+        idx = np.empty((feat.shape[0], 46), np.int32)
+        for i in range(feat.shape[0]):
+            self.L.lo_rvq_encode(self.h, _p(feat[i]), num_stages, _p(idx[i]))
+        return idx
+
+    def rvq_decode(self, idx):
+        idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 46)
+        out = np.empty((idx.shape[0], 64), np.float32)
+        for i in range(idx.shape[0]):
+            self.L.lo_rvq_decode(self.h, _p(idx[i]), _p(out[i]))
+        return out
+
+    def pack(self, idx, num_stages):
+        idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 46)
+        out = np.zeros((idx.shape[0], num_stages // 2), np.uint8)
+        for i in range(idx.shape[0]):
+            self.L.lo_pack(_p(idx[i]), num_stages, _p(out[i]))
+        return out
+
+    def unpack(self, packets, num_stages):
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, num_stages // 2)
+        out = np.empty((packets.shape[0], 46), np.int32)
+        for i in range(packets.shape[0]):
+            self.L.lo_unpack(_p(packets[i]), num_stages, _p(out[i]))
+        return out
+
+
+class Stream:
+    """Per-stream codec state (encoder + decoder + log-mel history)."""
+
+    def __init__(self, oracle, trace_cap=0):
+        self.o = oracle
+        self.L = oracle.L
+        self.h = self.L.lo_stream_new()
+        self.trace = None
+        if trace_cap:
+            self.trace = np.zeros(trace_cap, np.float32)
+            self.L.lo_stream_set_trace(self.h, _p(self.trace), trace_cap)
+
+    def __del__(self):
+        try:
+            self.L.lo_stream_free(self.h)
+        except Exception:
+            pass
+
+    def reset(self):
+        self.L.lo_stream_reset(self.h)
+
+    def _rearm(self):
+        if self.trace is not None:
+            self.L.lo_stream_set_trace(self.h, _p(self.trace), self.trace.size)
+
+    def taps(self):
+        n = self.L.lo_stream_trace_count(self.h)
+        offs = [self.L.lo_stream_trace_offset(self.h, i) for i in range(n + 1)]
+        return [self.trace[offs[i]:offs[i + 1]].copy() for i in range(n)]
+
+    def encode(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        assert pcm.size == 320
+        feat = np.empty(64, np.float32)
+        self._rearm()
+        self.L.lo_encode_frame(self.o.h, self.h, _p(pcm), _p(feat))
+        return feat
+
+    def decode(self, feat, want_float=False):
+        feat = np.ascontiguousarray(feat, np.float32)
+        assert feat.size == 64
+        pcm = np.empty(320, np.int16)
+        pf = np.empty(320, np.float32)
+        self._rearm()
+        self.L.lo_decode_frame(self.o.h, self.h, _p(feat), _p(pcm), _p(pf))
+        return (pcm, pf) if want_float else pcm
+
+    def logmel(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        mel = np.empty(160, np.float32)
+        self.L.lo_logmel(self.o.h, self.h, _p(pcm), _p(mel))
+        return mel
+
+
+def run_batch(oracle, pcm, num_stages, do_decode=True, threads=1, want_feats=False):
+    """pcm int16 [steps][B][320] -> dict(packets, pcm, feats, seconds, stage_seconds).
+
+    Fresh zero state per stream; one stream per row, threads split the streams.
+    """
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    steps, B, hop = pcm.shape
+    assert hop == 320
+    L = oracle.L
+    streams = [L.lo_stream_new() for _ in range(B)]
+    arr = (C.c_void_p * B)(*streams)
+    packets = np.zeros((steps, B, num_stages // 2), np.uint8)
+    out = np.zeros((steps, B, 320), np.int16) if do_decode else None
+    feats = np.zeros((steps, B, 64), np.float32) if want_feats else None
+    stage = np.zeros(4, np.float64)
+    sec = L.lo_run_batch(oracle.h, arr, B, steps, num_stages, int(do_decode), _p(pcm), _p(packets), _p(feats),
+                         _p(out), threads, _p(stage))
+    for s in streams:
+        L.lo_stream_free(s)
+    return dict(packets=packets, pcm=out, feats=feats, seconds=sec, stage_seconds=stage)

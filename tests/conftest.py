@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle_exact():
+    from oracle import lyra_oracle
+    lyra_oracle.build()
+    return lyra_oracle.Oracle(mode="exact")
+
+
+@pytest.fixture(scope="session")
+def oracle_double():
+    from oracle import lyra_oracle
+    lyra_oracle.build()
+    return lyra_oracle.Oracle(mode="gemmlowp_double")

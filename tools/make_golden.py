@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by executing the reference's own TFLite
+flatbuffers with oracle/tflite_interp.py (needs /root/reference; run in the
+build container only).  The committed fixtures are what tests compare the C
+oracle and the HIP path against on the GPU box.
+
+    python tools/make_golden.py
+
+Float accumulation in the interpreter is float64 (acc64=True), the closest to
+exact arithmetic; SURVEY.md 8(c): int8 codes downstream of a float layer can
+flip by one LSB when a pre-quantisation value sits within ~1e-6 of a rounding
+boundary, so fixtures are only kept for inputs where fp32 and fp64 accumulation
+agree on every int8 code (checked below).
+"""
+import hashlib
+import os
+import re
+import sys
+import wave
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from oracle.tflite_interp import Interpreter  # noqa: E402
+
+REF = "/root/reference/lyra"
+MC = REF + "/model_coeffs/"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def synth_pcm(stream_id, steps):
+    """Bench input: UnitToInt16Scalar(U(-1,1)) i.i.d. (lyra_benchmark_lib.cc:233-239),
+    seeded 0x4C797261 + stream_id."""
+    rng = np.random.Generator(np.random.PCG64(0x4C797261 + stream_id))
+    u = rng.uniform(-1.0, 1.0, size=steps * 320).astype(np.float32)
+    v = np.clip(u * np.float32(32768.0), -32768.0, 32767.0)
+    return np.trunc(v).astype(np.int16).reshape(steps, 320)
+
+
+def run_codec(pcm_frames, mode, acc64):
+    enc = Interpreter(MC + "soundstream_encoder.tflite", requant=mode, acc64=acc64)
+    gan = Interpreter(MC + "lyragan.tflite", requant=mode, acc64=acc64)
+    q = Interpreter(MC + "quantizer.tflite")
+    feats, idxs, lossy_all, pcm_out, pcm_f = [], [], [], [], []
+    for hop in pcm_frames:
+        x = (-hop.astype(np.float32)) / np.float32(-32768.0)
+        feat = enc.run_signature("serving_default", {"input_audio": x.reshape(1, 320)})["output_0"].reshape(-1)
+        idx = q.run_signature("encode", {"input_frames": feat.reshape(1, 1, 64),
+                                         "num_quantizers": np.int32(46)})["output_0"].reshape(-1)
+        lossy = q.run_signature("decode", {"encoding_indices": idx.reshape(46, 1, 1)})["output_0"].reshape(-1)
+        y = gan.run_signature("serving_default", {"input_audio": lossy.reshape(1, 1, 64)})["output_0"].reshape(-1)
+        v = np.minimum(np.maximum(y * np.float32(32768.0), np.float32(-32768)), np.float32(32767))
+        feats.append(feat); idxs.append(idx); lossy_all.append(lossy)
+        pcm_out.append(np.trunc(v).astype(np.int16)); pcm_f.append(y)
+    return dict(feats=np.array(feats, np.float32), idx=np.array(idxs, np.int32),
+                lossy=np.array(lossy_all, np.float32), pcm=np.array(pcm_out, np.int16),
+                pcm_f=np.array(pcm_f, np.float32))
+
+
+def packets_of(idx, n):
+    return np.array([[(int(r[2 * j]) << 4) | int(r[2 * j + 1]) for j in range(n // 2)] for r in idx], np.uint8)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # --- 1. real speech -----------------------------------------------------
+    w = wave.open(REF + "/testdata/sample1_16kHz.wav")
+    pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+    NF = 50  # (hop 53 of this file flips an int8 code between fp32 and fp64 accumulation in gemmlowp_double mode)
+    frames = pcm[:NF * 320].reshape(NF, 320)
+    g = {}
+    for mode in ("exact", "gemmlowp_double"):
+        r64 = run_codec(frames, mode, True)
+        r32 = run_codec(frames, mode, False)
+        assert np.array_equal(r64["feats"], r32["feats"]) and np.array_equal(r64["idx"], r32["idx"]), mode
+        d = np.abs(r64["pcm"].astype(int) - r32["pcm"].astype(int)).max()
+        print(mode, "speech: fp32-vs-fp64 accumulation pcm max diff", d)
+        assert d <= 1, "pick another excerpt: float order flips an int8 code here"
+        g[mode] = r64
+    # known answers from BASELINE.md section 4 (first 150 hops) are checked in tests via hashes of
+    # the first 60; here we just record.
+    np.savez_compressed(os.path.join(OUT, "speech_sample1.npz"),
+                        pcm_in=frames,
+                        feats_exact=g["exact"]["feats"], idx_exact=g["exact"]["idx"],
+                        lossy_exact=g["exact"]["lossy"], pcm_exact=g["exact"]["pcm"],
+                        pcmf_exact=g["exact"]["pcm_f"],
+                        feats_double=g["gemmlowp_double"]["feats"], idx_double=g["gemmlowp_double"]["idx"],
+                        pcm_double=g["gemmlowp_double"]["pcm"])
+    for n in (16, 30, 46):
+        h = hashlib.sha256(packets_of(g["exact"]["idx"], n).tobytes()).hexdigest()[:16]
+        print("speech exact", n * 4, "bits sha256[:16] of first", NF, "packets", h)
+    # --- 2. synthetic white noise (bench input), 4 streams x 6 steps ---------
+    S, T = 4, 6
+    pin = np.stack([synth_pcm(s, T) for s in range(S)], axis=1)  # [T][S][320]
+    outs = []
+    for s in range(S):
+        r64 = run_codec(pin[:, s], "exact", True)
+        r32 = run_codec(pin[:, s], "exact", False)
+        assert np.array_equal(r64["feats"], r32["feats"]) and np.array_equal(r64["idx"], r32["idx"])
+        d = np.abs(r64["pcm"].astype(int) - r32["pcm"].astype(int)).max()
+        print("noise stream", s, "fp32-vs-fp64 pcm max diff", d)
+        assert d <= 1
+        outs.append(r64)
+    np.savez_compressed(os.path.join(OUT, "noise_4x6.npz"), pcm_in=pin,
+                        feats=np.stack([o["feats"] for o in outs], 1), idx=np.stack([o["idx"] for o in outs], 1),
+                        pcm=np.stack([o["pcm"] for o in outs], 1), pcmf=np.stack([o["pcm_f"] for o in outs], 1))
+    # --- 3. RVQ fixture of the reference test --------------------------------
+    src = open(REF + "/residual_vector_quantizer_test.cc").read()
+    m = re.search(r"features_\{([^}]*)\}", src, re.S)
+    feat = np.array([float(x) for x in m.group(1).replace("\n", " ").split(",")], np.float32)
+    q = Interpreter(MC + "quantizer.tflite")
+    idx = q.run_signature("encode", {"input_frames": feat.reshape(1, 1, 64),
+                                     "num_quantizers": np.int32(46)})["output_0"].reshape(-1)
+    dec = {}
+    for n in (16, 30, 46):
+        i2 = idx.copy(); i2[n:] = -1
+        dec[n] = q.run_signature("decode", {"encoding_indices": i2.reshape(46, 1, 1)})["output_0"].reshape(-1)
+    # random feature vectors on the encoder's output grid + off-grid
+    rng = np.random.Generator(np.random.PCG64(7))
+    rnd = np.concatenate([(rng.integers(-128, 128, size=(64, 64)) - 20) * np.float32(0.26349151134490967),
+                          rng.normal(0, 3, size=(64, 64))]).astype(np.float32)
+    ridx = np.stack([q.run_signature("encode", {"input_frames": f.reshape(1, 1, 64), "num_quantizers": np.int32(46)}
+                                     )["output_0"].reshape(-1) for f in rnd])
+    rdec = np.stack([q.run_signature("decode", {"encoding_indices": i.reshape(46, 1, 1)})["output_0"].reshape(-1)
+                     for i in ridx])
+    np.savez_compressed(os.path.join(OUT, "rvq.npz"), fixture=feat, fixture_idx=idx.astype(np.int32),
+                        fixture_dec16=dec[16], fixture_dec30=dec[30], fixture_dec46=dec[46],
+                        rnd=rnd, rnd_idx=ridx.astype(np.int32), rnd_dec=rdec)
+    print("rvq fixture idx", list(map(int, idx)))
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()
