@@ -200,7 +200,12 @@ typedef struct {
   qmul* q;
 } dw_q;
 
-typedef struct { int cout, k, cin, stride; const float* w /*[cout][k][cin]*/; const float* b; } tconv_f;
+typedef struct {
+  int cout, k, cin, stride;
+  const float* w; /* [cout][k][cin] */
+  float* wp;      /* polyphase [k/stride][cin][stride*cout] */
+  const float* b;
+} tconv_f;
 typedef struct {
   int cout, k, cin, stride;
   const int8_t* w;
@@ -293,6 +298,14 @@ static void load_tconv_f(const pk_file* pk, const char* pre, int idx, tconv_f* L
   L->stride = opt[0];
   L->w = (const float*)(pk->blob + e->offset);
   L->b = PKF(pre, "tconv", idx, "b");
+  int taps = L->k / L->stride, N = L->stride * L->cout;
+  L->wp = (float*)malloc(sizeof(float) * (size_t)taps * L->cin * N);
+  for (int i = 0; i < taps; ++i)
+    for (int c = 0; c < L->cin; ++c)
+      for (int j = 0; j < L->stride; ++j)
+        for (int co = 0; co < L->cout; ++co)
+          L->wp[((size_t)i * L->cin + c) * N + j * L->cout + co] =
+              L->w[((size_t)co * L->k + (j + i * L->stride)) * L->cin + c];
 }
 
 static void load_tconv_q(const pk_file* pk, const char* pre, int idx, tconv_q* L) {
@@ -401,21 +414,29 @@ static void dw_q_run(const dw_q* L, const int8_t* in, int Tout, int8_t* out, int
     }
 }
 
-/* out[(Tin-1)*s+k][Cout] (bias included) */
+/* out[(Tin-1)*s+k][Cout] (bias included).  Polyphase form of the scatter loop: output block b
+ * (rows b*s..b*s+s-1) receives input rows t = b-(k/s-1) .. b in ascending order, channels ascending --
+ * per output element exactly the canonical chain; vectorises over the s*Cout outputs of a block. */
 static void tconv_f_run(const tconv_f* L, const float* in, int Tin, float* out) {
-  int Tout = (Tin - 1) * L->stride + L->k;
-  for (int tau = 0; tau < Tout; ++tau)
-    for (int co = 0; co < L->cout; ++co) {
-      float acc = 0.f;
-      for (int t = 0; t < Tin; ++t) {
-        int j = tau - t * L->stride;
-        if (j < 0 || j >= L->k) continue;
-        const float* x = in + (size_t)t * L->cin;
-        const float* w = L->w + ((size_t)co * L->k + j) * L->cin;
-        for (int c = 0; c < L->cin; ++c) acc = fmaf(x[c], w[c], acc);
+  int taps = L->k / L->stride, N = L->stride * L->cout;
+  int blocks = Tin + taps - 1;
+  float acc[512];
+  for (int b = 0; b < blocks; ++b) {
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    for (int i = taps - 1; i >= 0; --i) {
+      int t = b - i;
+      if (t < 0 || t >= Tin) continue;
+      const float* x = in + (size_t)t * L->cin;
+      for (int c = 0; c < L->cin; ++c) {
+        float xv = x[c];
+        const float* w = L->wp + ((size_t)i * L->cin + c) * N;
+        for (int n = 0; n < N; ++n) acc[n] = fmaf(xv, w[n], acc[n]);
       }
-      out[(size_t)tau * L->cout + co] = acc + L->b[co];
     }
+    float* o = out + (size_t)b * N;
+    for (int j = 0; j < L->stride; ++j)
+      for (int co = 0; co < L->cout; ++co) o[j * L->cout + co] = acc[j * L->cout + co] + L->b[co];
+  }
 }
 
 static void tconv_q_run(const tconv_q* L, const int8_t* in, int in_stride, int Tin, int8_t* out, int mode) {
