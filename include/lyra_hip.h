@@ -1,0 +1,137 @@
+/*
+ * lyra_hip.h -- C ABI of the MI355X-native Lyra encode/decode hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Each entry point names the reference interface it replaces (file:line
+ * relative to the google/lyra v1.3.2 tree).  The C++ plugin adapters in
+ * lyra_amd/host/ (FeatureExtractorInterface / VectorQuantizerInterface /
+ * GenerativeModelInterface) and the Python mirror lyra_amd/codec.py are thin
+ * callers of these functions; INTEGRATION.md shows the binding a reference
+ * maintainer would add in lyra/lyra_components.cc:42-65.
+ *
+ * Model: one context = one GPU + one HIP stream + per-stream codec state for
+ * `max_streams` independent audio streams.  A "frame" is one 20 ms hop of
+ * 16 kHz audio (320 samples); the codec is streaming/causal, so stream `id`
+ * must be fed its frames in order (the reference keeps this state inside the
+ * TFLite interpreter's resource variables: lyra/tflite_model_wrapper.cc:36-121).
+ *
+ * Threading: calls on one context must be serialised by the caller (as for one
+ * reference codec object); distinct contexts are independent.  A batch must not
+ * name the same stream id twice.  All functions return 0 on success or a
+ * negative LYRA_HIP_E* code; lyra_hip_last_error() describes the last failure.
+ * There is NO CPU fallback: creating a context without a usable gfx950 device
+ * fails.
+ *
+ * Pointer flavours: functions without suffix take HOST pointers (they copy
+ * H2D/D2H on the context's stream and synchronise); `_dev` variants take DEVICE
+ * pointers, enqueue on the context's stream and do not synchronise.
+ */
+#ifndef LYRA_HIP_H_
+#define LYRA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LYRA_HIP_HOP 320          /* samples per 20 ms frame at 16 kHz (lyra_config.h:70-168) */
+#define LYRA_HIP_NUM_FEATURES 64  /* kNumFeatures */
+#define LYRA_HIP_NUM_MEL 160      /* kNumMelBins */
+#define LYRA_HIP_MAX_STAGES 46    /* 184 bits / 4 bits per RVQ stage (lyra_config.cc:44-48) */
+
+#define LYRA_HIP_EINVAL (-1)   /* bad argument (bit count, batch size, stream id, null pointer) */
+#define LYRA_HIP_ENODEV (-2)   /* no usable gfx950 device */
+#define LYRA_HIP_EMODEL (-3)   /* model directory / weight container unreadable or wrong version */
+#define LYRA_HIP_EHIP (-4)     /* HIP runtime error */
+#define LYRA_HIP_ENOMEM (-5)
+
+/* requantisation flavour of the int8 conv layers (oracle/lyra_oracle.c) */
+#define LYRA_HIP_REQUANT_EXACT 0
+#define LYRA_HIP_REQUANT_GEMMLOWP_DOUBLE 1
+
+typedef struct lyra_hip_ctx lyra_hip_ctx;
+
+/* Replaces CreateFeatureExtractor / CreateQuantizer / CreateGenerativeModel
+ * (lyra/lyra_components.cc:42-55) + TfLiteModelWrapper::Create
+ * (lyra/tflite_model_wrapper.cc:36-95).  `model_dir` must contain
+ * lyra_v1.lyrapack (tools/pack_weights.py output for the reference's
+ * model_coeffs directory; version identifier 3 as lyra_config.h:145-166). */
+int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
+void lyra_hip_destroy(lyra_hip_ctx* ctx);
+const char* lyra_hip_last_error(const lyra_hip_ctx* ctx); /* ctx may be NULL: last create() error */
+
+/* Replaces TfLiteModelWrapper::ResetVariableTensors (tflite_model_wrapper.cc:111-113) /
+ * constructing fresh codec objects.  ids == NULL resets every stream. */
+int lyra_hip_reset_streams(lyra_hip_ctx* ctx, const int32_t* stream_ids, int n);
+
+/* ---- per-plugin entry points (the three reference interfaces) -------------------------------- */
+
+/* FeatureExtractorInterface::Extract as implemented by SoundStreamEncoder::Extract
+ * (lyra/soundstream_encoder.cc:53-64): pcm [B][320] int16 -> features [B][64] f32. */
+int lyra_hip_extract(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, float* features);
+
+/* VectorQuantizerInterface::Quantize (lyra/residual_vector_quantizer.cc:77-110), stateless:
+ * features [B][64] -> indices [B][46] int32 (-1 beyond num_bits/4 stages).  num_bits <= 184, % 4 == 0. */
+int lyra_hip_rvq_encode(lyra_hip_ctx* ctx, int B, const float* features, int num_bits, int32_t* indices);
+
+/* VectorQuantizerInterface::DecodeToLossyFeatures (residual_vector_quantizer.cc:112-168), stateless:
+ * indices [B][46] (-1 = unused stage) -> lossy features [B][64]. */
+int lyra_hip_rvq_decode(lyra_hip_ctx* ctx, int B, const int32_t* indices, float* features);
+
+/* GenerativeModel::AddFeatures + GenerateSamples(320) as implemented by LyraGanModel
+ * (lyra/generative_model_interface.h:50-101, lyra/lyra_gan_model.cc:53-64):
+ * features [B][64] -> pcm [B][320] int16 (x32768, clamp, truncate: dsp_utils.h:54-88). */
+int lyra_hip_generate(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const float* features, int16_t* pcm);
+
+/* FeatureExtractorInterface::Extract as implemented by LogMelSpectrogramExtractorImpl::Extract
+ * (lyra/log_mel_spectrogram_extractor_impl.cc:96-126), the NoiseEstimator front end
+ * (noise_estimator.cc:157-160): pcm [B][320] int16 -> log-mel [B][160] f32.  Keeps its own
+ * per-stream 320-sample history. */
+int lyra_hip_logmel(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, float* mel);
+
+/* ---- fused paths -------------------------------------------------------------------------------- */
+
+/* LyraEncoder::Encode without resampling/DTX (lyra/lyra_encoder.cc:143-155): Extract -> Quantize ->
+ * Packet<>::PackQuantized (lyra/packet.h:91-122, zero header bits).
+ * pcm [B][320] -> packets [B][num_bits/8 rounded up] (8 / 15 / 23 bytes for 64 / 120 / 184 bits). */
+int lyra_hip_encode(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, int num_bits,
+                    uint8_t* packets);
+
+/* LyraDecoder::SetEncodedPacket + DecodeSamples(320) steady state, no loss/PLC
+ * (lyra/lyra_decoder.cc:172-226,284-326): unpack -> DecodeToLossyFeatures -> generative model. */
+int lyra_hip_decode(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const uint8_t* packets, int num_bits,
+                    int16_t* pcm);
+
+/* ---- device-pointer variants (benchmark / pipelines that keep data resident in HBM) ------------- */
+int lyra_hip_extract_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const int16_t* d_pcm,
+                         float* d_features);
+int lyra_hip_rvq_encode_dev(lyra_hip_ctx* ctx, int B, const float* d_features, int num_bits, int32_t* d_indices);
+int lyra_hip_rvq_decode_dev(lyra_hip_ctx* ctx, int B, const int32_t* d_indices, float* d_features);
+int lyra_hip_generate_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const float* d_features,
+                          int16_t* d_pcm);
+int lyra_hip_logmel_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const int16_t* d_pcm, float* d_mel);
+int lyra_hip_encode_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const int16_t* d_pcm, int num_bits,
+                        uint8_t* d_packets);
+int lyra_hip_decode_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const uint8_t* d_packets,
+                        int num_bits, int16_t* d_pcm);
+
+/* The context's HIP stream (hipStream_t as void*), for event timing / ordering by the caller. */
+void* lyra_hip_stream(lyra_hip_ctx* ctx);
+int lyra_hip_synchronize(lyra_hip_ctx* ctx);
+
+/* Per-stream state footprint in HBM (bytes) and the context's stream capacity. */
+size_t lyra_hip_state_bytes_per_stream(void);
+int lyra_hip_max_streams(const lyra_hip_ctx* ctx);
+
+/* Test hook: copies stage-boundary activations of the LAST extract/generate call (device scratch) to host.
+ * which: 0 enc stage0 out [B][4][128], 1 enc stage1 out [B][2][256], 2 enc int8 codes [B][64] (as f32),
+ *        3 dec head out [B][4][128], 4 dec stage1 out [B][20][64].  Channel order is the library's
+ *        internal one; returns the number of floats written or a negative error. */
+long lyra_hip_debug_read(lyra_hip_ctx* ctx, int which, float* host_out, long capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LYRA_HIP_H_ */

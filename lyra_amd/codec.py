@@ -1,0 +1,342 @@
+"""Python mirror of the reference plugin surface over the C ABI (include/lyra_hip.h).
+
+Batched, array-in/array-out versions of
+  FeatureExtractorInterface::Extract            lyra/feature_extractor_interface.h:32-39
+  VectorQuantizerInterface::Quantize / DecodeToLossyFeatures
+                                                lyra/vector_quantizer_interface.h:28-41
+  GenerativeModelInterface::AddFeatures / GenerateSamples
+                                                lyra/generative_model_interface.h:32-42
+with the same names, argument meaning and error behaviour (None on failure, like std::nullopt), plus the
+fused LyraEncoder::Encode / LyraDecoder::DecodeSamples steady-state path.  numpy arrays go through the
+host-pointer entry points; torch CUDA tensors through the `_dev` ones (no copies, no sync).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOP = 320
+NUM_FEATURES = 64
+NUM_MEL = 160
+MAX_BITS = 184
+
+_BITRATES = {3200: 64, 6000: 120, 9200: 184}  # lyra_config.cc:44-48
+
+
+def bitrate_to_num_bits(bitrate):
+    return _BITRATES[bitrate]
+
+
+def packet_size(num_bits):
+    return (num_bits + 7) // 8  # lyra_config.h: 8 / 15 / 23 bytes
+
+
+def library_path():
+    return os.path.join(HERE, "liblyra_hip.so")
+
+
+def default_model_dir():
+    return os.path.join(HERE, "assets")
+
+
+def build_library(force=False):
+    """Compile lyra_amd/csrc for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(HERE, "csrc")
+    args = ["make", "-C", src, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+class LyraHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise LyraHipError(f"{path} not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, ci, cp = C.c_void_p, C.c_int, C.c_char_p
+    L.lyra_hip_create.argtypes = [cp, ci, ci, ci, C.POINTER(vp)]
+    L.lyra_hip_destroy.argtypes = [vp]
+    L.lyra_hip_last_error.restype = cp
+    L.lyra_hip_last_error.argtypes = [vp]
+    L.lyra_hip_reset_streams.argtypes = [vp, vp, ci]
+    for name in ("extract", "generate", "logmel"):
+        for suf in ("", "_dev"):
+            getattr(L, f"lyra_hip_{name}{suf}").argtypes = [vp, vp, ci, vp, vp]
+    for suf in ("", "_dev"):
+        getattr(L, f"lyra_hip_rvq_encode{suf}").argtypes = [vp, ci, vp, ci, vp]
+        getattr(L, f"lyra_hip_rvq_decode{suf}").argtypes = [vp, ci, vp, vp]
+        getattr(L, f"lyra_hip_encode{suf}").argtypes = [vp, vp, ci, vp, ci, vp]
+        getattr(L, f"lyra_hip_decode{suf}").argtypes = [vp, vp, ci, vp, ci, vp]
+    L.lyra_hip_stream.restype = vp
+    L.lyra_hip_stream.argtypes = [vp]
+    L.lyra_hip_synchronize.argtypes = [vp]
+    L.lyra_hip_state_bytes_per_stream.restype = C.c_size_t
+    L.lyra_hip_max_streams.argtypes = [vp]
+    L.lyra_hip_debug_read.restype = C.c_long
+    L.lyra_hip_debug_read.argtypes = [vp, ci, vp, C.c_long]
+    _lib = L
+    return L
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _np(a, dtype, shape):
+    a = np.ascontiguousarray(a, dtype)
+    return a.reshape(shape)
+
+
+class LyraHip:
+    """One GPU context: weights + per-stream state for `max_streams` streams."""
+
+    def __init__(self, model_dir=None, device=0, max_streams=4096, requant="exact"):
+        self.L = _load()
+        h = C.c_void_p()
+        mode = {"exact": 0, "gemmlowp_double": 1}[requant]
+        rc = self.L.lyra_hip_create((model_dir or default_model_dir()).encode(), device, max_streams, mode, C.byref(h))
+        if rc != 0:
+            raise LyraHipError(f"lyra_hip_create failed ({rc}): {self.L.lyra_hip_last_error(None).decode()}")
+        self.h = h
+        self.device = device
+        self.max_streams = max_streams
+        self.requant = requant
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lyra_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def last_error(self):
+        return self.L.lyra_hip_last_error(self.h).decode()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LyraHipError(f"lyra_hip error {rc}: {self.last_error()}")
+
+    def stream_handle(self):
+        return self.L.lyra_hip_stream(self.h)
+
+    def synchronize(self):
+        self._chk(self.L.lyra_hip_synchronize(self.h))
+
+    def state_bytes_per_stream(self):
+        return self.L.lyra_hip_state_bytes_per_stream()
+
+    def reset(self, stream_ids=None):
+        if stream_ids is None:
+            self._chk(self.L.lyra_hip_reset_streams(self.h, None, 0))
+            self.synchronize()
+        else:
+            ids = _np(stream_ids, np.int32, (-1,))
+            self._chk(self.L.lyra_hip_reset_streams(self.h, ids.ctypes.data, ids.size))
+
+    @staticmethod
+    def _ids(stream_ids, B):
+        if stream_ids is None:
+            return np.arange(B, dtype=np.int32)
+        return _np(stream_ids, np.int32, (B,))
+
+    # -- numpy (host pointer) API --------------------------------------------------------------------
+    def extract(self, pcm, stream_ids=None):
+        """pcm int16 [B][320] -> features float32 [B][64] (SoundStreamEncoder::Extract)."""
+        pcm = _np(pcm, np.int16, (-1, HOP))
+        B = pcm.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.empty((B, NUM_FEATURES), np.float32)
+        self._chk(self.L.lyra_hip_extract(self.h, ids.ctypes.data, B, pcm.ctypes.data, out.ctypes.data))
+        return out
+
+    def rvq_encode(self, features, num_bits):
+        features = _np(features, np.float32, (-1, NUM_FEATURES))
+        B = features.shape[0]
+        idx = np.empty((B, 46), np.int32)
+        self._chk(self.L.lyra_hip_rvq_encode(self.h, B, features.ctypes.data, num_bits, idx.ctypes.data))
+        return idx
+
+    def rvq_decode(self, indices):
+        indices = _np(indices, np.int32, (-1, 46))
+        B = indices.shape[0]
+        out = np.empty((B, NUM_FEATURES), np.float32)
+        self._chk(self.L.lyra_hip_rvq_decode(self.h, B, indices.ctypes.data, out.ctypes.data))
+        return out
+
+    def generate(self, features, stream_ids=None):
+        """features [B][64] -> pcm int16 [B][320] (AddFeatures + GenerateSamples(320))."""
+        features = _np(features, np.float32, (-1, NUM_FEATURES))
+        B = features.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.empty((B, HOP), np.int16)
+        self._chk(self.L.lyra_hip_generate(self.h, ids.ctypes.data, B, features.ctypes.data, out.ctypes.data))
+        return out
+
+    def logmel(self, pcm, stream_ids=None):
+        pcm = _np(pcm, np.int16, (-1, HOP))
+        B = pcm.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.empty((B, NUM_MEL), np.float32)
+        self._chk(self.L.lyra_hip_logmel(self.h, ids.ctypes.data, B, pcm.ctypes.data, out.ctypes.data))
+        return out
+
+    def encode(self, pcm, num_bits, stream_ids=None):
+        """pcm int16 [B][320] -> packets uint8 [B][num_bits/8] (LyraEncoder::Encode, 16 kHz, no DTX)."""
+        pcm = _np(pcm, np.int16, (-1, HOP))
+        B = pcm.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.empty((B, packet_size(num_bits)), np.uint8)
+        self._chk(self.L.lyra_hip_encode(self.h, ids.ctypes.data, B, pcm.ctypes.data, num_bits, out.ctypes.data))
+        return out
+
+    def decode(self, packets, num_bits, stream_ids=None):
+        """packets uint8 [B][num_bits/8] -> pcm int16 [B][320] (SetEncodedPacket + DecodeSamples(320))."""
+        packets = _np(packets, np.uint8, (-1, packet_size(num_bits)))
+        B = packets.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.empty((B, HOP), np.int16)
+        self._chk(self.L.lyra_hip_decode(self.h, ids.ctypes.data, B, packets.ctypes.data, num_bits, out.ctypes.data))
+        return out
+
+    def debug_read(self, which, n):
+        out = np.empty(n, np.float32)
+        got = self.L.lyra_hip_debug_read(self.h, which, out.ctypes.data, n)
+        if got < 0:
+            raise LyraHipError(self.last_error())
+        return out[:got]
+
+    # -- torch (device pointer) API: tensors must live on this context's device ------------------------------
+    def encode_dev(self, d_ids, d_pcm, num_bits, d_packets):
+        B = d_pcm.shape[0]
+        self._chk(self.L.lyra_hip_encode_dev(self.h, d_ids.data_ptr(), B, d_pcm.data_ptr(), num_bits,
+                                             d_packets.data_ptr()))
+
+    def decode_dev(self, d_ids, d_packets, num_bits, d_pcm):
+        B = d_pcm.shape[0]
+        self._chk(self.L.lyra_hip_decode_dev(self.h, d_ids.data_ptr(), B, d_packets.data_ptr(), num_bits,
+                                             d_pcm.data_ptr()))
+
+    def extract_dev(self, d_ids, d_pcm, d_feat):
+        self._chk(self.L.lyra_hip_extract_dev(self.h, d_ids.data_ptr(), d_pcm.shape[0], d_pcm.data_ptr(),
+                                              d_feat.data_ptr()))
+
+    def generate_dev(self, d_ids, d_feat, d_pcm):
+        self._chk(self.L.lyra_hip_generate_dev(self.h, d_ids.data_ptr(), d_feat.shape[0], d_feat.data_ptr(),
+                                               d_pcm.data_ptr()))
+
+    def logmel_dev(self, d_ids, d_pcm, d_mel):
+        self._chk(self.L.lyra_hip_logmel_dev(self.h, d_ids.data_ptr(), d_pcm.shape[0], d_pcm.data_ptr(),
+                                             d_mel.data_ptr()))
+
+    def rvq_encode_dev(self, d_feat, num_bits, d_idx):
+        self._chk(self.L.lyra_hip_rvq_encode_dev(self.h, d_feat.shape[0], d_feat.data_ptr(), num_bits,
+                                                 d_idx.data_ptr()))
+
+    def rvq_decode_dev(self, d_idx, d_feat):
+        self._chk(self.L.lyra_hip_rvq_decode_dev(self.h, d_idx.shape[0], d_idx.data_ptr(), d_feat.data_ptr()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# single-stream plugin objects with the reference's method names and error behaviour
+# ---------------------------------------------------------------------------------------------------
+class _Plugin:
+    def __init__(self, ctx, stream_id=0):
+        self.ctx = ctx
+        self.sid = np.array([stream_id], np.int32)
+
+
+class SoundStreamEncoder(_Plugin):
+    """FeatureExtractorInterface (lyra/soundstream_encoder.h)."""
+
+    def Extract(self, audio):
+        audio = np.asarray(audio)
+        if audio.size != HOP:
+            return None
+        return self.ctx.extract(audio.astype(np.int16), self.sid)[0]
+
+
+class ResidualVectorQuantizer(_Plugin):
+    """VectorQuantizerInterface (lyra/residual_vector_quantizer.h): bit strings of '0'/'1', first
+    quantizer in the most significant position."""
+
+    def Quantize(self, features, num_bits):
+        if num_bits > MAX_BITS or num_bits % 4 != 0 or num_bits < 0:
+            return None  # residual_vector_quantizer.cc:79-89
+        if num_bits == 0:
+            return ""
+        idx = self.ctx.rvq_encode(np.asarray(features, np.float32).reshape(1, 64), num_bits)[0]
+        return "".join(format(int(i), "04b") for i in idx[:num_bits // 4])
+
+    def DecodeToLossyFeatures(self, quantized_features):
+        n = len(quantized_features)
+        if n > MAX_BITS or n % 4 != 0:
+            return None  # residual_vector_quantizer.cc:116-126
+        idx = np.full(46, -1, np.int32)
+        for i in range(n // 4):
+            idx[i] = int(quantized_features[4 * i:4 * i + 4], 2)
+        return self.ctx.rvq_decode(idx.reshape(1, 46))[0]
+
+
+class LyraGanModel(_Plugin):
+    """GenerativeModel FIFO semantics (lyra/generative_model_interface.h:45-134)."""
+
+    def __init__(self, ctx, stream_id=0):
+        super().__init__(ctx, stream_id)
+        self._queue = []
+        self._next = 0
+        self._hop = None
+
+    def AddFeatures(self, features):
+        features = np.asarray(features, np.float32)
+        if features.size != NUM_FEATURES:
+            return False
+        self._queue.append(features.copy())
+        return True
+
+    def num_samples_available(self):
+        return len(self._queue) * HOP - self._next
+
+    def GenerateSamples(self, num_samples):
+        if num_samples < 0:
+            return None
+        if num_samples == 0:
+            return np.zeros(0, np.int16)
+        if self.num_samples_available() == 0:
+            return None
+        if self._next == 0:
+            self._hop = self.ctx.generate(self._queue[0].reshape(1, 64), self.sid)[0]  # RunConditioning
+        if num_samples > HOP - self._next:
+            return None
+        out = self._hop[self._next:self._next + num_samples].copy()  # RunModel
+        self._next += num_samples
+        if self._next == HOP:
+            self._next = 0
+            self._queue.pop(0)
+        return out
+
+
+class LogMelSpectrogramExtractor(_Plugin):
+    """FeatureExtractorInterface (lyra/log_mel_spectrogram_extractor_impl.h), NoiseEstimator instantiation."""
+
+    def Extract(self, audio):
+        audio = np.asarray(audio)
+        if audio.size != HOP:
+            return None
+        return self.ctx.logmel(audio.astype(np.int16), self.sid)[0]

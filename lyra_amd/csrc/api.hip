@@ -1,0 +1,457 @@
+// api.hip -- the C ABI of include/lyra_hip.h: context, scratch, launches.  No CPU fallback anywhere:
+// every entry point either runs the gfx950 kernels or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lyra_hip.h"
+#include "model.h"
+
+using namespace lyra;
+
+namespace {
+std::string g_create_error;
+std::mutex g_create_mu;
+}  // namespace
+
+struct lyra_hip_ctx {
+  int device = 0;
+  int max_streams = 0;
+  int mode = 0;
+  hipStream_t stream = nullptr;
+  Model model;
+  uint8_t* d_state = nullptr;
+  // scratch, sized for `cap` frames
+  int cap = 0;
+  int32_t* d_ids = nullptr;
+  int16_t* d_pcm_in = nullptr;
+  float* d_e0 = nullptr;     // [cap][4][128]
+  float* d_e1 = nullptr;     // [cap][2][256]
+  float* d_feat = nullptr;   // [cap][64]
+  float* d_codes = nullptr;  // [cap][64]
+  int32_t* d_idx = nullptr;  // [cap][46]
+  uint8_t* d_pkt = nullptr;  // [cap][23]
+  float* d_lossy = nullptr;  // [cap][64]
+  float* d_d0 = nullptr;     // [cap][4][128]
+  float* d_d1 = nullptr;     // [cap][20][64]
+  int16_t* d_pcm_out = nullptr;
+  float* d_mel = nullptr;    // [cap][160]
+  int last_B_enc = 0, last_B_dec = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(lyra_hip_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  else { std::lock_guard<std::mutex> l(g_create_mu); g_create_error = buf; }
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(c, LYRA_HIP_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
+
+void free_scratch(lyra_hip_ctx* c) {
+  void* ps[] = {c->d_ids, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_codes, c->d_idx, c->d_pkt,
+                c->d_lossy, c->d_d0, c->d_d1, c->d_pcm_out, c->d_mel};
+  for (void* p : ps)
+    if (p) (void)hipFree(p);
+  c->d_ids = nullptr; c->d_pcm_in = nullptr; c->d_e0 = nullptr; c->d_e1 = nullptr; c->d_feat = nullptr;
+  c->d_codes = nullptr; c->d_idx = nullptr; c->d_pkt = nullptr; c->d_lossy = nullptr; c->d_d0 = nullptr;
+  c->d_d1 = nullptr; c->d_pcm_out = nullptr; c->d_mel = nullptr;
+  c->cap = 0;
+}
+
+int ensure_scratch(lyra_hip_ctx* c, int B) {
+  if (B <= c->cap) return 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_scratch(c);
+  size_t n = (size_t)B;
+  HIPCHK(c, dalloc(&c->d_ids, n));
+  HIPCHK(c, dalloc(&c->d_pcm_in, n * 320));
+  HIPCHK(c, dalloc(&c->d_e0, n * 4 * 128));
+  HIPCHK(c, dalloc(&c->d_e1, n * 2 * 256));
+  HIPCHK(c, dalloc(&c->d_feat, n * 64));
+  HIPCHK(c, dalloc(&c->d_codes, n * 64));
+  HIPCHK(c, dalloc(&c->d_idx, n * 46));
+  HIPCHK(c, dalloc(&c->d_pkt, n * 23));
+  HIPCHK(c, dalloc(&c->d_lossy, n * 64));
+  HIPCHK(c, dalloc(&c->d_d0, n * 4 * 128));
+  HIPCHK(c, dalloc(&c->d_d1, n * 20 * 64));
+  HIPCHK(c, dalloc(&c->d_pcm_out, n * 320));
+  HIPCHK(c, dalloc(&c->d_mel, n * 160));
+  c->cap = B;
+  return 0;
+}
+
+int check_batch(lyra_hip_ctx* c, int B) {
+  if (!c) return LYRA_HIP_EINVAL;
+  if (B <= 0 || B > c->max_streams) return fail(c, LYRA_HIP_EINVAL, "batch %d outside 1..max_streams (%d)", B, c->max_streams);
+  return 0;
+}
+
+int check_bits(lyra_hip_ctx* c, int num_bits) {
+  // residual_vector_quantizer.cc:79-89,116-126
+  if (num_bits > 4 * LYRA_HIP_MAX_STAGES)
+    return fail(c, LYRA_HIP_EINVAL, "The number of bits cannot exceed maximum (%d).", 4 * LYRA_HIP_MAX_STAGES);
+  if (num_bits <= 0 || num_bits % 4 != 0)
+    return fail(c, LYRA_HIP_EINVAL, "The number of bits (%d) has to be divisible by the number of bits per quantizer (4).", num_bits);
+  return 0;
+}
+
+int check_ids_host(lyra_hip_ctx* c, const int32_t* ids, int B) {
+  if (!ids) return fail(c, LYRA_HIP_EINVAL, "stream_ids is null");
+  for (int i = 0; i < B; ++i)
+    if (ids[i] < 0 || ids[i] >= c->max_streams)
+      return fail(c, LYRA_HIP_EINVAL, "stream id %d at position %d outside 0..%d", ids[i], i, c->max_streams - 1);
+  return 0;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- launches (all on c->stream) ---------------------------------------------------------------------
+int launch_extract(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
+  const Model& M = c->model;
+  hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(512), enc_s0_lds_bytes(), c->stream,
+                     M.enc0, d_pcm, d_ids, B, c->d_state, c->d_e0);
+  hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(512), enc_s1_lds_bytes(), c->stream,
+                     M.enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1);
+  hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), c->stream,
+                     M.enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes);
+  HIPCHK(c, hipGetLastError());
+  c->last_B_enc = B;
+  return 0;
+}
+
+int launch_rvq_encode(lyra_hip_ctx* c, int B, const float* d_feat, int num_stages, int32_t* d_idx, uint8_t* d_pkt) {
+  hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->stream, c->model.cbt, d_feat, B,
+                     num_stages, d_idx, d_pkt);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int launch_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* d_idx, const uint8_t* d_pkt, int num_stages,
+                      float* d_feat) {
+  hipLaunchKernelGGL(rvq_decode_kernel, dim3(cdiv(B, 4)), dim3(256), 0, c->stream, c->model.cb, d_idx, d_pkt,
+                     num_stages, B, d_feat);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int launch_generate(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
+  const Model& M = c->model;
+  hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), c->stream,
+                     M.dec0, d_feat, d_ids, B, c->d_state, c->d_d0);
+  hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(512), dec_s1_lds_bytes(), c->stream,
+                     M.dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1);
+  hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(512), dec_s2_lds_bytes(), c->stream,
+                     M.dec2, c->d_d1, d_ids, B, c->d_state, d_pcm);
+  HIPCHK(c, hipGetLastError());
+  c->last_B_dec = B;
+  return 0;
+}
+
+int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
+  hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->stream, c->model.mel, d_pcm, d_ids, B,
+                     c->d_state, d_mel);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+template <class K>
+hipError_t set_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out) {
+  if (!out || !model_dir || max_streams <= 0 || (requant_mode != 0 && requant_mode != 1))
+    return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create: bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+    return fail(nullptr, LYRA_HIP_ENODEV, "no HIP device %d (count %d); this library has no CPU path", device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, LYRA_HIP_ENODEV, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, LYRA_HIP_ENODEV, "device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, LYRA_HIP_EHIP, "hipSetDevice failed");
+
+  Pack pk;
+  std::string err;
+  std::string path = std::string(model_dir) + "/lyra_v1.lyrapack";
+  if (!pk.open(path, &err)) return fail(nullptr, LYRA_HIP_EMODEL, "%s", err.c_str());
+  lyra_hip_ctx* c = new lyra_hip_ctx();
+  c->device = device;
+  c->max_streams = max_streams;
+  c->mode = requant_mode;
+  if (!build_model(pk, requant_mode, &c->model, &err)) {
+    delete c;
+    return fail(nullptr, LYRA_HIP_EMODEL, "%s", err.c_str());
+  }
+  auto bail = [&](int code, const char* what) {
+    std::string msg = what;
+    lyra_hip_destroy(c);
+    return fail(nullptr, code, "%s", msg.c_str());
+  };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
+  if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
+    return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
+  if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
+      set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
+      set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
+      set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess)
+    return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
+  *out = c;
+  int rc = lyra_hip_reset_streams(c, nullptr, 0);
+  if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = LYRA_HIP_EHIP;
+  if (rc != 0) { *out = nullptr; return bail(rc, "initial state reset failed"); }
+  return 0;
+}
+
+void lyra_hip_destroy(lyra_hip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_scratch(c);
+  if (c->d_state) (void)hipFree(c->d_state);
+  free_model(&c->model);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* lyra_hip_last_error(const lyra_hip_ctx* c) {
+  if (c) return c->err.c_str();
+  std::lock_guard<std::mutex> l(g_create_mu);
+  return g_create_error.c_str();
+}
+
+void* lyra_hip_stream(lyra_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int lyra_hip_synchronize(lyra_hip_ctx* c) {
+  if (!c) return LYRA_HIP_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+size_t lyra_hip_state_bytes_per_stream(void) { return (size_t)st::BYTES; }
+int lyra_hip_max_streams(const lyra_hip_ctx* c) { return c ? c->max_streams : 0; }
+
+int lyra_hip_reset_streams(lyra_hip_ctx* c, const int32_t* ids, int n) {
+  if (!c) return LYRA_HIP_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!ids) {
+    hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->stream, c->model.reset,
+                       (const int32_t*)nullptr, c->max_streams, 1, c->d_state);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  int rc = check_batch(c, n);
+  if (rc) return rc;
+  if ((rc = check_ids_host(c, ids, n))) return rc;
+  if ((rc = ensure_scratch(c, n))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->stream, c->model.reset, (const int32_t*)c->d_ids, n, 0,
+                     c->d_state);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- device-pointer variants ------------------------------------------------------------------------------
+int lyra_hip_extract_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = ensure_scratch(c, B))) return rc;
+  return launch_extract(c, d_ids, B, d_pcm, d_feat);
+}
+
+int lyra_hip_rvq_encode_dev(lyra_hip_ctx* c, int B, const float* d_feat, int num_bits, int32_t* d_idx) {
+  if (!c) return LYRA_HIP_EINVAL;
+  int rc = check_bits(c, num_bits);
+  if (rc) return rc;
+  if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
+  return launch_rvq_encode(c, B, d_feat, num_bits / 4, d_idx, nullptr);
+}
+
+int lyra_hip_rvq_decode_dev(lyra_hip_ctx* c, int B, const int32_t* d_idx, float* d_feat) {
+  if (!c) return LYRA_HIP_EINVAL;
+  if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
+  return launch_rvq_decode(c, B, d_idx, nullptr, 46, d_feat);
+}
+
+int lyra_hip_generate_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = ensure_scratch(c, B))) return rc;
+  return launch_generate(c, d_ids, B, d_feat, d_pcm);
+}
+
+int lyra_hip_logmel_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if (!d_ids || !d_pcm || !d_mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  return launch_logmel(c, d_ids, B, d_pcm, d_mel);
+}
+
+int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, int num_bits,
+                        uint8_t* d_packets) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if ((rc = check_bits(c, num_bits))) return rc;
+  if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = ensure_scratch(c, B))) return rc;
+  if ((rc = launch_extract(c, d_ids, B, d_pcm, c->d_feat))) return rc;
+  return launch_rvq_encode(c, B, c->d_feat, num_bits / 4, nullptr, d_packets);
+}
+
+int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint8_t* d_packets, int num_bits,
+                        int16_t* d_pcm) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if ((rc = check_bits(c, num_bits))) return rc;
+  if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = ensure_scratch(c, B))) return rc;
+  if ((rc = launch_rvq_decode(c, B, nullptr, d_packets, num_bits / 4, c->d_lossy))) return rc;
+  return launch_generate(c, d_ids, B, c->d_lossy, d_pcm);
+}
+
+// ---- host-pointer variants ---------------------------------------------------------------------------------
+#define PROLOGUE(c, B)                      \
+  int rc = check_batch(c, B);               \
+  if (rc) return rc;                        \
+  HIPCHK(c, hipSetDevice(c->device));       \
+  if ((rc = ensure_scratch(c, B))) return rc
+
+int lyra_hip_extract(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, float* features) {
+  PROLOGUE(c, B);
+  if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_extract(c, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
+  HIPCHK(c, hipMemcpyAsync(features, c->d_feat, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int lyra_hip_rvq_encode(lyra_hip_ctx* c, int B, const float* features, int num_bits, int32_t* indices) {
+  if (!c) return LYRA_HIP_EINVAL;
+  int rc = check_bits(c, num_bits);
+  if (rc) return rc;
+  if (B <= 0 || !features || !indices) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = ensure_scratch(c, B))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_feat, features, (size_t)B * 256, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, c->d_idx, nullptr))) return rc;
+  HIPCHK(c, hipMemcpyAsync(indices, c->d_idx, (size_t)B * 46 * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int lyra_hip_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* indices, float* features) {
+  if (!c) return LYRA_HIP_EINVAL;
+  if (B <= 0 || !features || !indices) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure_scratch(c, B))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_idx, indices, (size_t)B * 46 * 4, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_rvq_decode(c, B, c->d_idx, nullptr, 46, c->d_lossy))) return rc;
+  HIPCHK(c, hipMemcpyAsync(features, c->d_lossy, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int lyra_hip_generate(lyra_hip_ctx* c, const int32_t* ids, int B, const float* features, int16_t* pcm) {
+  PROLOGUE(c, B);
+  if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_lossy, features, (size_t)B * 256, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_generate(c, c->d_ids, B, c->d_lossy, c->d_pcm_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int lyra_hip_logmel(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, float* mel) {
+  PROLOGUE(c, B);
+  if (!pcm || !mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_logmel(c, c->d_ids, B, c->d_pcm_in, c->d_mel))) return rc;
+  HIPCHK(c, hipMemcpyAsync(mel, c->d_mel, (size_t)B * 160 * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int lyra_hip_encode(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, int num_bits, uint8_t* packets) {
+  PROLOGUE(c, B);
+  if ((rc = check_bits(c, num_bits))) return rc;
+  if (!pcm || !packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  const int nbytes = (num_bits + 7) / 8;
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_extract(c, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
+  if ((rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, nullptr, c->d_pkt))) return rc;
+  HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* packets, int num_bits, int16_t* pcm) {
+  PROLOGUE(c, B);
+  if ((rc = check_bits(c, num_bits))) return rc;
+  if (!pcm || !packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  const int nbytes = (num_bits + 7) / 8;
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pkt, packets, (size_t)B * nbytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_rvq_decode(c, B, nullptr, c->d_pkt, num_bits / 4, c->d_lossy))) return rc;
+  if ((rc = launch_generate(c, c->d_ids, B, c->d_lossy, c->d_pcm_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+long lyra_hip_debug_read(lyra_hip_ctx* c, int which, float* host_out, long capacity) {
+  if (!c || !host_out) return LYRA_HIP_EINVAL;
+  const float* src = nullptr;
+  long n = 0;
+  switch (which) {
+    case 0: src = c->d_e0; n = (long)c->last_B_enc * 4 * 128; break;
+    case 1: src = c->d_e1; n = (long)c->last_B_enc * 2 * 256; break;
+    case 2: src = c->d_codes; n = (long)c->last_B_enc * 64; break;
+    case 3: src = c->d_d0; n = (long)c->last_B_dec * 4 * 128; break;
+    case 4: src = c->d_d1; n = (long)c->last_B_dec * 20 * 64; break;
+    default: return fail(c, LYRA_HIP_EINVAL, "unknown debug buffer %d", which);
+  }
+  if (n > capacity) return fail(c, LYRA_HIP_EINVAL, "debug buffer needs %ld floats", n);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(host_out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,441 @@
+// dec_kernels.hip -- LyraGAN decoder (replaces lyragan.tflite as run by LyraGanModel::RunConditioning /
+// RunModel, lyra/lyra_gan_model.cc:53-64, incl. the float->int16 conversion of dsp_utils.h:54-88) as three
+// stream-tiled gfx950 kernels.
+//
+//   dec_s0  S=16  features -> conv k3 g4 (fp32) -> int8: 4x tconv k4/s2, 3 resblocks @256ch x 2 rows,
+//                 2x tconv k4/s2 -> [4][128] fp32
+//   dec_s1  S=16  3 fp32 resblocks @128ch x 4 rows -> tconv k10/s5 -> [20][64]
+//   dec_s2  S=8   3 fp32 resblocks @64ch x 20 rows -> tconv k64/s16 -> 320 samples -> int16 PCM
+//
+// Transposed convs run in polyphase form: output block b (s rows) = [x[b-taps+1] .. x[b]] (K = taps*Cin,
+// oldest input first) times W[K][s*Cout] -- per output element exactly the oracle's chain (input position
+// ascending, channel ascending).  The tail rows that belong to the next frame are carried in the state with
+// the bias removed, as the graph does.
+#include "resblocks.h"
+
+namespace lyra {
+
+// =============================================================================================
+// stage 0
+// =============================================================================================
+namespace {
+constexpr int SD0 = 16;
+constexpr int FS = 72;      // feature row stride (64 + 8) floats
+constexpr int CS2 = 264;    // 256 + 8 floats
+constexpr int QS = 288;     // int8 row stride, C = 256
+constexpr int QS5 = 544;    // int8 row stride, C = 512
+constexpr int NTD0 = 512;
+constexpr int FB_FLOATS = 3 * SD0 * FS;
+constexpr int XF_FLOATS = 2 * SD0 * CS2;
+constexpr int QB_BYTES = 2 * SD0 * QS;
+}  // namespace
+
+size_t dec_s0_lds_bytes() { return (size_t)(FB_FLOATS + XF_FLOATS) * 4 + SD0 * QS5 + 4 * QB_BYTES + 2 * SD0 * 4; }
+int dec_s0_streams_per_wg() { return SD0; }
+
+__global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __restrict__ feats,
+                                                       const int32_t* __restrict__ ids, int B,
+                                                       uint8_t* __restrict__ state, float* __restrict__ out0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* FB = smem;                                   // [3][16][72]: two history rows + new features
+  float* XF = FB + FB_FLOATS;                         // [2][16][264]: x164 (float skip of resblock 0)
+  int8_t* H8 = reinterpret_cast<int8_t*>(XF + XF_FLOATS);  // [16][544]
+  int8_t* QX = H8 + SD0 * QS5;
+  int8_t* QA = QX + QB_BYTES;
+  int8_t* QD = QA + QB_BYTES;
+  int8_t* QP = QD + QB_BYTES;
+  int* sids = reinterpret_cast<int*>(QP + QB_BYTES);
+  int* sphase = sids + SD0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * SD0;
+  const int mode = P.mode;
+  if (tid < SD0) {
+    int id = ids[min(b0 + tid, B - 1)];
+    sids[tid] = id;
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
+  }
+  __syncthreads();
+  TileCtx cx{state, sids, sphase, B - b0};
+
+  // ---- feature window [f-2, f-1, f] (history ring R=2, T=1) ----------------------------------------
+  for (int idx = tid; idx < SD0 * 64; idx += NTD0) {
+    int c = idx & 63, s = idx >> 6;
+    int b = min(b0 + s, B - 1);
+    FB[(2 * SD0 + s) * FS + at16(c)] = feats[(size_t)b * 64 + c];
+  }
+  for (int idx = tid; idx < 2 * SD0 * 16; idx += NTD0) {
+    int p4 = idx & 15, s = (idx >> 4) & 15, j = idx >> 8;
+    int slot = (sphase[s] + j) & 1;
+    *reinterpret_cast<f32x4*>(&FB[(j * SD0 + s) * FS + p4 * 4]) =
+        *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < SD0 * 16; idx += NTD0) {
+    int p4 = idx & 15, s = idx >> 4;
+    int slot = sphase[s] & 1;
+    if (cx.valid(s))
+      *reinterpret_cast<f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4) =
+          *reinterpret_cast<const f32x4*>(&FB[(2 * SD0 + s) * FS + p4 * 4]);
+  }
+  {  // conv k3 g4: per group [16 rows] x K=48 x N=128; LeakyReLU; QUANTIZE -> H8
+    f32x4 acc[1][4];
+    const int g = wave >> 1;
+    auto aoff = [&](int i, int c) { return (c * SD0 + m) * FS + g * 16 + q * 4; };
+    gemm_f32<1, 4, 3>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = (wave * 4 + j) * 16 + (lane & 15);
+      float bias = P.head.b[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        H8[(q * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0.s, P.q0.z);
+    }
+  }
+  __syncthreads();
+  {  // 4 grouped int8 transposed convs k4/s2 (one input row -> 4 output rows), carried tail of 2 rows
+    i32x4 acc[1][8];
+    const int g = wave >> 1;
+    const TconvQ U = P.up0[g];
+    auto aoff = [&](int i, int c) { return m * QS5 + g * 128 + c * 64 + q * 16; };
+    gemm_i8<1, 8, 2>(H8, aoff, U.w + ((wave & 1) * 8) * 2 * 64, acc);
+    float* stp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) stp[e] = reinterpret_cast<float*>(cx.sbase(q * 4 + e) + st::D_UP0 + g * 512);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ct = (wave & 1) * 2 + (j >> 2), tap = j & 3;
+      const int co = ct * 16 + (lane & 15);
+      const int zf = U.zfold[tap * 64 + co], bias = U.bias[co];
+      const float sub = P.up0_sub[g][co];
+      const int pc = at16(g * 64 + co);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int s = q * 4 + e;
+        int c8 = clamp8(requant(acc[0][j][e] + zf + bias, U.M, U.sh, mode) + U.zout);
+        float y = dequantize_f(c8, P.up0_dq[g].s, P.up0_dq[g].z);
+        if (tap < 2) {
+          y = y + stp[e][tap * 64 + co];
+          XF[(tap * SD0 + s) * CS2 + pc] = y;
+        } else {
+          y = y + 0.f;
+          if (cx.valid(s)) stp[e][(tap - 2) * 64 + co] = y - sub;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- a0 = QUANTIZE(lrelu(x164)) ------------------------------------------------------------------
+  for (int idx = tid; idx < 2 * SD0 * 256; idx += NTD0) {
+    int c = idx & 255, rs = idx >> 8;
+    QA[rs * QS + c] = (int8_t)quantize_f(lrelu(XF[rs * CS2 + at16(c)]), P.q1.s, P.q1.z);
+  }
+  __syncthreads();
+  // ---- resblock 0 (int8 body, float skip): dilation 1, history of 2 rows (replaced) -----------------
+  {
+    const DwQ dq = P.dwq[0];
+    for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
+      int w4 = idx & 63, s = (idx >> 6) & 15, t = idx >> 10;
+      int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        int tau = t - (2 - j);
+        int w;
+        if (tau >= 0) w = *reinterpret_cast<const int*>(&QA[(tau * SD0 + s) * QS + w4 * 4]);
+        else w = *reinterpret_cast<const int*>(cx.sbase(s) + st::D_R0_0 + (2 + tau) * 256 + w4 * 4);
+        int ww = *reinterpret_cast<const int*>(&dq.w[j * 256 + w4 * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (sx8(w, e) - dq.zin) * sx8(ww, e);
+      }
+      int o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int c = w4 * 4 + e;
+        o[e] = clamp8(requant(acc[e] + dq.b[c], dq.M[c], dq.sh[c], mode) + dq.zout);
+      }
+      *reinterpret_cast<int*>(&QD[(t * SD0 + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
+      int w4 = idx & 63, s = (idx >> 6) & 15, t = idx >> 10;
+      if (cx.valid(s))
+        *reinterpret_cast<int*>(cx.sbase(s) + st::D_R0_0 + t * 256 + w4 * 4) =
+            *reinterpret_cast<const int*>(&QA[(t * SD0 + s) * QS + w4 * 4]);
+    }
+    {
+      i32x4 acc[2][2];
+      auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
+      gemm_i8<2, 2, 4>(QD, aoff, P.pwq[0].w + (wave * 2) * 4 * 64, acc);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int n = (wave * 2 + j) * 16 + (lane & 15);
+        int bias = P.pwq[0].b[n], M = P.pwq[0].M[n], sh = P.pwq[0].sh[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.pwq[0].zout);
+            QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lrelu_q(c8, P.lr[0]);
+          }
+      }
+    }
+    __syncthreads();
+    {
+      i32x4 acc[2][2];
+      const int g = wave >> 1;
+      auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 64 + q * 16; };
+      gemm_i8<2, 2, 1>(QP, aoff, P.cvq[0].w + (wave * 2) * 64, acc);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int n = (wave * 2 + j) * 16 + (lane & 15);
+        int bias = P.cvq[0].b[n], M = P.cvq[0].M[n], sh = P.cvq[0].sh[n];
+        int pc = at16(n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int row = i * 16 + q * 4 + e;
+            int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.cvq[0].zout);
+            float v = dequantize_f(c8, P.dq_r0.s, P.dq_r0.z) + XF[row * CS2 + pc];
+            QX[row * QS + n] = (int8_t)quantize_f(v, P.q3.s, P.q3.z);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  resblock_q256(QX, QA, QD, QP, cx, 3, st::D_R0_1, P.lr[1], P.lr[2], P.dwq[1], P.pwq[1], P.cvq[1], P.add[0], mode);
+  resblock_q256(QX, QA, QD, QP, cx, 9, st::D_R0_2, P.lr[3], P.lr[4], P.dwq[2], P.pwq[2], P.cvq[2], P.add[1], mode);
+  for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
+    int w4 = idx & 63, rs = idx >> 6;
+    int w = *reinterpret_cast<const int*>(&QX[rs * QS + w4 * 4]);
+    *reinterpret_cast<int*>(&QA[rs * QS + w4 * 4]) =
+        pack8(lrelu_q(sx8(w, 0), P.lr[5]), lrelu_q(sx8(w, 1), P.lr[5]), lrelu_q(sx8(w, 2), P.lr[5]),
+              lrelu_q(sx8(w, 3), P.lr[5]));
+  }
+  __syncthreads();
+  {  // 2 grouped int8 transposed convs k4/s2: rows t=0,1 -> 6 output rows (integer overlap-add), tail of 2
+    i32x4 acc[2][4];
+    const int g = wave >> 2, ct = wave & 3;
+    const TconvQ U = P.up1[g];
+    auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 128 + c * 64 + q * 16; };
+    gemm_i8<2, 4, 2>(QA, aoff, U.w + (ct * 4) * 2 * 64, acc);
+    const int co = ct * 16 + (lane & 15);
+    const int bias = U.bias[co];
+    const float sub = P.up1_sub[g][co];
+    const int pc = at16(g * 64 + co);
+    int zf[4];
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) zf[tap] = U.zfold[tap * 64 + co];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int s = q * 4 + e;
+      float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP1 + g * 512);
+      int o[6];
+      o[0] = acc[0][0][e] + zf[0];
+      o[1] = acc[0][1][e] + zf[1];
+      o[2] = (acc[0][2][e] + zf[2]) + (acc[1][0][e] + zf[0]);
+      o[3] = (acc[0][3][e] + zf[3]) + (acc[1][1][e] + zf[1]);
+      o[4] = acc[1][2][e] + zf[2];
+      o[5] = acc[1][3][e] + zf[3];
+      float y[6];
+#pragma unroll
+      for (int tau = 0; tau < 6; ++tau) {
+        int c8 = clamp8(requant(o[tau] + bias, U.M, U.sh, mode) + U.zout);
+        y[tau] = dequantize_f(c8, P.up1_dq[g].s, P.up1_dq[g].z);
+      }
+      y[0] = y[0] + stp[co];
+      y[1] = y[1] + stp[64 + co];
+#pragma unroll
+      for (int tau = 2; tau < 6; ++tau) y[tau] = y[tau] + 0.f;
+      if (cx.valid(s)) {
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = y[tau];
+        stp[co] = y[4] - sub;
+        stp[64 + co] = y[5] - sub;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// stage 1
+// =============================================================================================
+namespace {
+constexpr int SD1 = 16;
+constexpr int CS1 = 136;
+constexpr int NTD1 = 512;
+}  // namespace
+
+size_t dec_s1_lds_bytes() { return (size_t)(7 * SD1 * CS1 + 4 * SD1 * CS1) * 4 + 2 * SD1 * 4; }
+int dec_s1_streams_per_wg() { return SD1; }
+
+__global__ __launch_bounds__(NTD1) void dec_s1_kernel(DecS1P P, const float* __restrict__ in0,
+                                                       const int32_t* __restrict__ ids, int B,
+                                                       uint8_t* __restrict__ state, float* __restrict__ out1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XB = smem;                     // [7][16][136]: row 0 zeros, rows 1-4 X[t], rows 5-6 zeros
+  float* DB = XB + 7 * SD1 * CS1;       // [4][16][136]; later: old tconv tail [5][16][72]
+  int* sids = reinterpret_cast<int*>(DB + 4 * SD1 * CS1);
+  int* sphase = sids + SD1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * SD1;
+  if (tid < SD1) {
+    int id = ids[min(b0 + tid, B - 1)];
+    sids[tid] = id;
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
+  }
+  __syncthreads();
+  TileCtx cx{state, sids, sphase, B - b0};
+  for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
+    int p4 = idx & 31, s = (idx >> 5) & 15, t = idx >> 9;
+    int b = min(b0 + s, B - 1);
+    *reinterpret_cast<f32x4*>(&XB[((1 + t) * SD1 + s) * CS1 + p4 * 4]) =
+        *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
+  }
+  for (int idx = tid; idx < 3 * SD1 * 32; idx += NTD1) {
+    int p4 = idx & 31, s = (idx >> 5) & 15, j = idx >> 9;
+    int row = j == 0 ? 0 : 4 + j;
+    *reinterpret_cast<f32x4*>(&XB[(row * SD1 + s) * CS1 + p4 * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  resblocks128(XB + SD1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2);
+  for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
+    int p4 = idx & 31, rs = idx >> 5;
+    f32x4* x = reinterpret_cast<f32x4*>(&XB[(SD1 + rs) * CS1 + p4 * 4]);
+    *x = lrelu4(*x);
+  }
+  float* SB = DB;  // old carried tail [5][16][72]
+  for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {
+    int p4 = idx & 15, s = (idx >> 4) & 15, j = idx >> 8;
+    *reinterpret_cast<f32x4*>(&SB[(j * SD1 + s) * 72 + p4 * 4]) =
+        *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
+  }
+  __syncthreads();
+  {  // tconv k10/s5, polyphase: blocks b = 0..4 (+1 dummy), K = [x[b-1] | x[b]] = 256, N = 5 x 64
+    f32x4 acc[3][5];
+    const int wn = wave & 3, wm = wave >> 2;
+    auto aoff = [&](int i, int c) {
+      int b = 3 * wm + i;
+      int row = (c < 8 ? b - 1 : b) + 1;
+      return (row * SD1 + m) * CS1 + (c & 7) * 16 + q * 4;
+    };
+    gemm_f32<3, 5, 16>(XB, aoff, P.up.w + (wn * 5) * 16 * 64, acc);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int n = (wn * 5 + j) * 16 + (lane & 15);
+      const int jj = n >> 6, co = n & 63;
+      const float bias = P.up.b[co], sub = P.up_sub[co];
+      const int pc = at16(co);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int b = 3 * wm + i;
+        if (b > 4) continue;
+        const int tau = 5 * b + jj;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int s = q * 4 + e;
+          float y = acc[i][j][e] + bias;
+          y = y + (tau < 5 ? SB[(tau * SD1 + s) * 72 + co] : 0.f);
+          if (cx.valid(s)) {
+            if (tau < 20) out1[((size_t)(b0 + s) * 20 + tau) * 64 + pc] = y;
+            else reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[(tau - 20) * 64 + co] = y - sub;
+          }
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// stage 2
+// =============================================================================================
+namespace {
+constexpr int SD2 = 8;
+constexpr int CS0 = 72;
+constexpr int NTD2 = 512;
+}  // namespace
+
+size_t dec_s2_lds_bytes() { return (size_t)(27 * SD2 * CS0 + 20 * SD2 * CS0) * 4 + 64; }
+int dec_s2_streams_per_wg() { return SD2; }
+
+__global__ __launch_bounds__(NTD2) void dec_s2_kernel(DecS2P P, const float* __restrict__ in1,
+                                                       const int32_t* __restrict__ ids, int B,
+                                                       uint8_t* __restrict__ state, int16_t* __restrict__ pcm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* XB = smem;                     // [27][8][72]: rows 0-2 zeros, rows 3-22 X[t], rows 23-26 zeros
+  float* DB = XB + 27 * SD2 * CS0;      // [20][8][72]; later: old overlap tail [8][48]
+  int* sids = reinterpret_cast<int*>(DB + 20 * SD2 * CS0);
+  int* sphase = sids + SD2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * SD2;
+  if (tid < SD2) {
+    int id = ids[min(b0 + tid, B - 1)];
+    sids[tid] = id;
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
+  }
+  __syncthreads();
+  TileCtx cx{state, sids, sphase, B - b0};
+  for (int idx = tid; idx < 20 * SD2 * 16; idx += NTD2) {
+    int p4 = idx & 15, s = (idx >> 4) & 7, t = idx >> 7;
+    int b = min(b0 + s, B - 1);
+    *reinterpret_cast<f32x4*>(&XB[((3 + t) * SD2 + s) * CS0 + p4 * 4]) =
+        *reinterpret_cast<const f32x4*>(&in1[((size_t)b * 20 + t) * 64 + p4 * 4]);
+  }
+  for (int idx = tid; idx < 7 * SD2 * 16; idx += NTD2) {
+    int p4 = idx & 15, s = (idx >> 4) & 7, j = idx >> 7;
+    int row = j < 3 ? j : 20 + j;
+    *reinterpret_cast<f32x4*>(&XB[(row * SD2 + s) * CS0 + p4 * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  resblocks64(XB + 3 * SD2 * CS0, DB, cx, P.dw, P.pw, P.cv, st::D_R2_0, st::D_R2_1, st::D_R2_2);
+  for (int idx = tid; idx < 20 * SD2 * 16; idx += NTD2) {
+    int p4 = idx & 15, rs = idx >> 4;
+    f32x4* x = reinterpret_cast<f32x4*>(&XB[(3 * SD2 + rs) * CS0 + p4 * 4]);
+    *x = lrelu4(*x);
+  }
+  float* SB = DB;  // old overlap tail [8][48]
+  for (int idx = tid; idx < SD2 * 48; idx += NTD2) {
+    int s = idx / 48, i = idx - s * 48;
+    SB[idx] = reinterpret_cast<const float*>(cx.sbase(s) + st::D_UP3)[i];
+  }
+  __syncthreads();
+  if (wave < 6) {  // tconv k64/s16, polyphase: blocks b = 0..22 (+1 dummy), K = 4 x 64, N = 16 phases
+    f32x4 acc[2][1];
+    auto aoff = [&](int i, int c) {
+      int b = 2 * (2 * wave + i) + (m >> 3);
+      return ((b + (c >> 2)) * SD2 + (m & 7)) * CS0 + (c & 3) * 16 + q * 4;
+    };
+    gemm_f32<2, 1, 16>(XB, aoff, P.up.w, acc);
+    const int j = lane & 15;
+    const float bias = P.up.b[0];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int rr = q * 4 + e;
+        int b = 2 * (2 * wave + i) + (rr >> 3), s = rr & 7;
+        if (b > 22) continue;
+        int tau = 16 * b + j;
+        float y = acc[i][0][e] + bias;
+        y = y + (tau < 48 ? SB[s * 48 + tau] : 0.f);
+        if (!cx.valid(s)) continue;
+        if (tau < 320) {
+          // UnitToInt16Scalar (dsp_utils.h:54-88): scale, clip, C truncation
+          float v = y * 32768.f;
+          v = v < -32768.f ? -32768.f : v;
+          v = v > 32767.f ? 32767.f : v;
+          pcm[(size_t)(b0 + s) * 320 + tau] = (int16_t)v;
+        } else {
+          reinterpret_cast<float*>(cx.sbase(s) + st::D_UP3)[tau - 320] = y - P.up_sub;
+        }
+      }
+  }
+  if (tid < SD2 && cx.valid(tid)) {
+    int ph = sphase[tid] + 1;
+    *reinterpret_cast<int*>(cx.sbase(tid) + st::DEC_PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+  }
+}
+
+}  // namespace lyra

@@ -1,0 +1,67 @@
+// kernels.h -- kernel parameter blocks and launch-side declarations (internal to liblyra_hip.so).
+#pragma once
+#include "lyra_dev.h"
+#include "state_layout.h"
+
+namespace lyra {
+
+// ---- encoder ---------------------------------------------------------------------------------
+struct EncS0P { ConvF first; DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF down; };
+struct EncS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF down; };
+struct EncS2P {
+  DwF dw0; ConvF pw0;
+  QP q_r0, dq_r0, q_x1, out;
+  LreluQ lr[7];
+  ConvQ r0b;
+  DwQ dwq[2]; ConvQ pwq[2]; ConvQ cvq[2]; AddQ add[2];
+  ConvQ down2, bott;
+  int mode;
+};
+
+__global__ void enc_s0_kernel(EncS0P P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* out0);
+__global__ void enc_s1_kernel(EncS1P P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
+__global__ void enc_s2_kernel(EncS2P P, const float* in1, const int32_t* ids, int B, uint8_t* state, float* feats,
+                              float* codes_dbg);
+size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg();
+size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg();
+size_t enc_s2_lds_bytes(); int enc_s2_streams_per_wg();
+
+// ---- decoder ---------------------------------------------------------------------------------
+// int8 transpose conv k4/s2 as a GEMM [rows][K=128] x [K][N = 4 taps x 64]; N tiles ordered [co tile][tap].
+// zfold[tap*64+co] = -zin * sum_c w[co][tap][c] (the GEMM runs on raw codes); bias added once per output row.
+struct TconvQ { const i32x4* w; const int32_t* zfold; const int32_t* bias; int32_t M, sh, zout; };
+struct DecS0P {
+  ConvF head;                 // conv k3 g4 (fp32): 4 groups, K = 3 taps x 16, N = 128
+  QP q0;                      // QUANTIZE after the float LeakyReLU
+  TconvQ up0[4]; QP up0_dq[4]; const float* up0_sub[4];
+  QP q1;                      // QUANTIZE of lrelu(x164)
+  DwQ dwq[3]; ConvQ pwq[3]; ConvQ cvq[3];
+  LreluQ lr[6]; AddQ add[2];
+  QP dq_r0, q3;               // DEQUANTIZE of resblock-0 conv out; QUANTIZE of (conv + float skip)
+  TconvQ up1[2]; QP up1_dq[2]; const float* up1_sub[2];
+  int mode;
+};
+struct DecS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; const float* up_sub; };
+struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; };
+
+__global__ void dec_s0_kernel(DecS0P P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0);
+__global__ void dec_s1_kernel(DecS1P P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
+__global__ void dec_s2_kernel(DecS2P P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm);
+size_t dec_s0_lds_bytes(); int dec_s0_streams_per_wg();
+size_t dec_s1_lds_bytes(); int dec_s1_streams_per_wg();
+size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg();
+
+// ---- RVQ / packets / log-mel / state ---------------------------------------------------------------
+// cbt: codebooks transposed [46][64][16]; cb: natural [46][16][64]
+__global__ void rvq_encode_kernel(const float* cbt, const float* feats, int B, int num_stages, int32_t* indices,
+                                  uint8_t* packets);
+__global__ void rvq_decode_kernel(const float* cb, const int32_t* indices, const uint8_t* packets, int num_stages,
+                                  int B, float* feats);
+struct MelP { const double* hann; const double* tw_re; const double* tw_im; const int* band; const double* w;
+              int start, end; };
+__global__ void logmel_kernel(MelP P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* mel);
+size_t logmel_lds_bytes();
+struct ResetP { int8_t e_r2_1, e_r2_2, e_d2, e_bott, d_r0_0, d_r0_1, d_r0_2; };
+__global__ void reset_kernel(ResetP P, const int32_t* ids, int n, int all, uint8_t* state);
+
+}  // namespace lyra

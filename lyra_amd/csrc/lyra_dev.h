@@ -1,0 +1,166 @@
+// lyra_dev.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// Conventions (see DESIGN.md "Data layout"):
+//  * A workgroup owns a tile of S independent streams and runs a whole network stage with the
+//    activations in LDS as [row = (time, stream)][channel] matrices.
+//  * fp32 activations are stored in "AT16" channel order: inside every aligned block of 16
+//    channels the 4x4 index matrix is transposed (phys = (k&3)*4 + (k>>2)&3).  A lane of
+//    v_mfma_f32_16x16x4_f32 holds A[m = lane&15][k = lane>>4]; with AT16 one ds_read_b128 returns
+//    the lane's A operands for four consecutive MFMAs (k = q, 4+q, 8+q, 12+q ... i.e. kk*4+q), so the
+//    K loop runs in strictly ascending k -- bitwise the fmaf chain the oracle defines
+//    (oracle/lyra_oracle.c header) -- at one LDS read per four MFMAs.
+//  * fp32 rows are padded by 8 floats (stride C+8): conflict-free for that ds_read_b128 pattern.
+//  * int8 activations keep natural channel order, row stride C+32 bytes.
+//  * Weights are pre-packed on the host into per-lane MFMA B fragments (one 16-byte global load
+//    per lane per K chunk, fully coalesced).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define LYRA_LRELU_ALPHA 0.30000001192092896f
+
+namespace lyra {
+
+__host__ __device__ constexpr int at16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : x * LYRA_LRELU_ALPHA; }
+__device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
+  f32x4 r;
+  r[0] = lrelu(v[0]); r[1] = lrelu(v[1]); r[2] = lrelu(v[2]); r[3] = lrelu(v[3]);
+  return r;
+}
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
+  f32x4 r;
+  r[0] = __builtin_fmaf(a[0], b[0], c[0]); r[1] = __builtin_fmaf(a[1], b[1], c[1]);
+  r[2] = __builtin_fmaf(a[2], b[2], c[2]); r[3] = __builtin_fmaf(a[3], b[3], c[3]);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed point (TFLite common.h semantics; same formulas as oracle/lyra_oracle.c)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t srdhm(int32_t a, int32_t b) {
+  if (a == INT32_MIN && b == INT32_MIN) return INT32_MAX;
+  int64_t ab = (int64_t)a * (int64_t)b;
+  int64_t nudge = ab >= 0 ? (1ll << 30) : (1 - (1ll << 30));
+  return (int32_t)((ab + nudge) / (1ll << 31));
+}
+__device__ __forceinline__ int32_t rdivpot(int32_t x, int e) {
+  int32_t mask = (int32_t)((1ll << e) - 1);
+  int32_t rem = x & mask;
+  int32_t thr = (mask >> 1) + (x < 0 ? 1 : 0);
+  return (x >> e) + (rem > thr ? 1 : 0);
+}
+__device__ __forceinline__ int32_t mbqm_double(int32_t x, int32_t M, int shift) {
+  int left = shift > 0 ? shift : 0;
+  int right = shift > 0 ? 0 : -shift;
+  return rdivpot(srdhm((int32_t)((int64_t)x * (1ll << left)), M), right);
+}
+__device__ __forceinline__ int32_t mbqm_exact(int32_t x, int32_t M, int shift) {
+  int total = 31 - shift;
+  return (int32_t)(((int64_t)x * (int64_t)M + (1ll << (total - 1))) >> total);
+}
+// conv / depthwise / transpose-conv requantisation: mode 0 exact, 1 gemmlowp double rounding
+__device__ __forceinline__ int32_t requant(int32_t acc, int32_t M, int shift, int mode) {
+  return mode ? mbqm_double(acc, M, shift) : mbqm_exact(acc, M, shift);
+}
+__device__ __forceinline__ int32_t clamp8(int32_t v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
+
+// TFLite AffineQuantize: round-half-away(x / s) + z, clamped.  IEEE division (the build passes
+// -fhip-fp32-correctly-rounded-divide-sqrt) so this is bitwise the oracle's quantize_f.
+__device__ __forceinline__ int32_t quantize_f(float x, float s, int32_t z) {
+  float r = __builtin_roundf(x / s);
+  return clamp8((int32_t)r + z);
+}
+// float(double(s) * (q - z)) == s * float(q - z) in fp32 (24-bit x 9-bit product is exact before the one rounding)
+__device__ __forceinline__ float dequantize_f(int32_t q, float s, int32_t z) { return s * (float)(q - z); }
+
+struct LreluQ { int32_t zin, zout, mpos, spos, mneg, sneg; };
+struct AddQ { int32_t z1, z2, zo, m1, s1, m2, s2, mo, so; };
+
+__device__ __forceinline__ int32_t lrelu_q(int32_t x, const LreluQ& L) {
+  int32_t v = x - L.zin;
+  int32_t r = v >= 0 ? mbqm_double(v, L.mpos, L.spos) : mbqm_double(v, L.mneg, L.sneg);
+  return clamp8(r + L.zout);
+}
+__device__ __forceinline__ int32_t add_q(int32_t a, int32_t b, const AddQ& L) {
+  int32_t va = (a - L.z1) * (1 << 20);
+  int32_t vb = (b - L.z2) * (1 << 20);
+  int32_t sa = mbqm_double(va, L.m1, L.s1);
+  int32_t sb = mbqm_double(vb, L.m2, L.s2);
+  return clamp8(mbqm_double(sa + sb, L.mo, L.so) + L.zo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA tile GEMMs: A from LDS, B fragments from global (L2-resident weights), C in registers.
+//   a_off(i, c)  -> offset (floats / bytes) of this lane's 16-byte A fragment for the wave's i-th
+//                   M tile and K chunk c (lane-specific part included by the caller's lambda)
+//   bfrag        -> this wave's first N tile; tile j at bfrag + j * KC * 64
+// Accumulators are returned to the caller (epilogues often straddle a barrier).
+// ---------------------------------------------------------------------------------------------
+template <int MTW, int NTW, int KC, class AOff>
+__device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* __restrict__ bfrag,
+                                         f32x4 (&acc)[MTW][NTW]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int c = 0; c < KC; ++c) {
+    f32x4 b[NTW], a[MTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) b[j] = bfrag[(j * KC + c) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a[i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c));
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <int MTW, int NTW, int KC, class AOff>
+__device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32x4* __restrict__ bfrag,
+                                        i32x4 (&acc)[MTW][NTW]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (i32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    i32x4 b[NTW], a[MTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) b[j] = bfrag[(j * KC + c) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) a[i] = *reinterpret_cast<const i32x4*>(lds + a_off(i, c));
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// C/D layout of every 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+__device__ __forceinline__ int cd_col() { return threadIdx.x & 15; }
+__device__ __forceinline__ int cd_row(int reg) { return (((threadIdx.x & 63) >> 4) << 2) + reg; }
+
+// ---------------------------------------------------------------------------------------------
+// parameter blocks (device pointers into the context's weight arena)
+// ---------------------------------------------------------------------------------------------
+struct ConvF { const f32x4* w; const float* b; };          // b: logical channel order
+struct DwF { const float* w; const float* b; };            // [3][C], [C] in AT16 channel order
+struct ConvQ { const i32x4* w; const int32_t* b; const int32_t* M; const int32_t* sh; int32_t zout; };
+//   b already holds bias - zin * sum_k(w): the GEMM runs on raw int8 codes
+struct DwQ { const int8_t* w; const int32_t* b; const int32_t* M; const int32_t* sh; int32_t zin, zout; };
+struct QP { float s; int32_t z; };
+
+}  // namespace lyra

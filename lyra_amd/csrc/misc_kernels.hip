@@ -1,0 +1,177 @@
+// misc_kernels.hip -- residual vector quantizer, packet (un)packing, log-mel front end, state reset.
+#include "kernels.h"
+
+namespace lyra {
+
+// =============================================================================================
+// RVQ encode: replaces quantizer.tflite `encode` (555 ops) + the bit-string assembly of
+// ResidualVectorQuantizer::Quantize (lyra/residual_vector_quantizer.cc:77-110) + Packet<>::Pack
+// (lyra/packet.h:91-122).  16 lanes = the 16 codewords of a stage; each lane runs the 64-term
+// squared-distance sum in the oracle's order (separate multiply and add, d ascending), then a
+// 16-lane shuffle argmin with lowest-index tie break (ARG_MIN = first minimum).  The residual lives
+// in registers, replicated across the 16 lanes, and is updated with the graph's three fp32 ops
+// r - (r + (q - r)).  4 frames per wavefront, 16 per workgroup.
+// =============================================================================================
+__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ cbt,
+                                                          const float* __restrict__ feats, int B, int num_stages,
+                                                          int32_t* __restrict__ indices,
+                                                          uint8_t* __restrict__ packets) {
+  const int j = threadIdx.x & 15;
+  const int frame = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int f = min(frame, B - 1);
+  float r[64];
+#pragma unroll
+  for (int d4 = 0; d4 < 16; ++d4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + d4 * 4]);
+    r[d4 * 4 + 0] = v[0]; r[d4 * 4 + 1] = v[1]; r[d4 * 4 + 2] = v[2]; r[d4 * 4 + 3] = v[3];
+  }
+  const int nbytes = (num_stages + 1) >> 1;
+  int cur = 0;
+#pragma unroll 1
+  for (int k = 0; k < num_stages; ++k) {
+    const float* ct = cbt + (size_t)k * 64 * 16;
+    float sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+      float df = r[d] - ct[d * 16 + j];
+      float sq = df * df;
+      sum = sum + sq;
+    }
+    int best = j;
+    float bd = sum;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      float od = __shfl_xor(bd, off, 16);
+      int oi = __shfl_xor(best, off, 16);
+      if (od < bd || (od == bd && oi < best)) { bd = od; best = oi; }
+    }
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+      float qv = ct[d * 16 + best];
+      float t1 = qv - r[d];
+      float t2 = r[d] + t1;
+      r[d] = r[d] - t2;
+    }
+    if (j == 0 && frame < B) {
+      if (indices) indices[(size_t)frame * 46 + k] = best;
+      if (packets) {
+        if (k & 1) packets[(size_t)frame * nbytes + (k >> 1)] = (uint8_t)(cur | best);
+        else cur = best << 4;
+      }
+    }
+  }
+  if (j == 0 && frame < B) {
+    if (packets && (num_stages & 1)) packets[(size_t)frame * nbytes + (num_stages >> 1)] = (uint8_t)cur;
+    if (indices)
+      for (int k = num_stages; k < 46; ++k) indices[(size_t)frame * 46 + k] = -1;
+  }
+}
+
+// RVQ decode: quantizer.tflite `decode` (233 ops) + the index extraction of DecodeToLossyFeatures
+// (residual_vector_quantizer.cc:140-157).  ((v0 + v1) + v2) + ... strictly left to right, masked
+// stages contribute v * 0.0f exactly as the graph does.
+__global__ __launch_bounds__(256) void rvq_decode_kernel(const float* __restrict__ cb,
+                                                          const int32_t* __restrict__ indices,
+                                                          const uint8_t* __restrict__ packets, int num_stages, int B,
+                                                          float* __restrict__ feats) {
+  const int d = threadIdx.x & 63;
+  const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (frame >= B) return;
+  const int nbytes = (num_stages + 1) >> 1;
+  float acc = 0.f;
+#pragma unroll 2
+  for (int k = 0; k < 46; ++k) {
+    int id;
+    if (packets) id = k < num_stages ? ((packets[(size_t)frame * nbytes + (k >> 1)] >> ((k & 1) ? 0 : 4)) & 15) : -1;
+    else id = indices[(size_t)frame * 46 + k];
+    float mask = id != -1 ? 1.f : 0.f;
+    int i = id < 0 ? 0 : id;
+    float v = cb[((size_t)k * 16 + i) * 64 + d] * mask;
+    acc = k == 0 ? v : acc + v;
+  }
+  feats[(size_t)frame * 64 + d] = acc;
+}
+
+// =============================================================================================
+// log-mel: LogMelSpectrogramExtractorImpl::Extract (lyra/log_mel_spectrogram_extractor_impl.cc:96-126)
+// as instantiated by NoiseEstimator (16 kHz, hop 320, window 640, 160 bands).
+// One workgroup per stream-frame: fp64 radix-2 FFT-1024 in LDS (same butterfly order and twiddles as
+// the oracle), |X|, then one thread per mel band accumulating its bins in ascending order (== the
+// reference's scatter loop order per band), float log/floor.
+// =============================================================================================
+size_t logmel_lds_bytes() { return (size_t)(1024 * 2 + 520) * 8; }
+
+__global__ __launch_bounds__(256) void logmel_kernel(MelP P, const int16_t* __restrict__ pcm,
+                                                      const int32_t* __restrict__ ids, int B,
+                                                      uint8_t* __restrict__ state, float* __restrict__ mel) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* re = dsm;
+  double* im = dsm + 1024;
+  double* mag = dsm + 2048;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  int16_t* prev = reinterpret_cast<int16_t*>(state + (size_t)ids[b] * st::BYTES + st::M_PREV);
+  for (int i = tid; i < 1024; i += 256) {
+    double v = 0.0;
+    if (i < 320) v = (double)prev[i] * P.hann[i];
+    else if (i < 640) v = (double)pcm[(size_t)b * 320 + (i - 320)] * P.hann[i];
+    int rv = __brev((unsigned)i) >> 22;
+    re[rv] = v;
+    im[rv] = 0.0;
+  }
+  __syncthreads();
+  for (int i = tid; i < 320; i += 256) prev[i] = pcm[(size_t)b * 320 + i];
+#pragma unroll 1
+  for (int p = 1; p <= 10; ++p) {
+    const int len = 1 << p, half = len >> 1;
+    for (int bf = tid; bf < 512; bf += 256) {
+      int grp = bf >> (p - 1), k = bf & (half - 1);
+      int i0 = grp * len + k, i1 = i0 + half;
+      double wr = P.tw_re[half - 1 + k], wi = P.tw_im[half - 1 + k];
+      double ur = re[i0], ui = im[i0];
+      double xr = re[i1], xi = im[i1];
+      double vr = xr * wr - xi * wi;
+      double vi = xr * wi + xi * wr;
+      re[i0] = ur + vr; im[i0] = ui + vi;
+      re[i1] = ur - vr; im[i1] = ui - vi;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i <= 512; i += 256) mag[i] = __builtin_sqrt(re[i] * re[i] + im[i] * im[i]);
+  __syncthreads();
+  if (tid < 160) {
+    // bins whose lower band is tid-1 contribute (v - v*w); bins whose lower band is tid contribute v*w
+    double acc = 0.0;
+    for (int i = P.band[tid]; i < P.band[tid + 1]; ++i) { double v = mag[i]; double w = v * P.w[i]; acc += v - w; }
+    for (int i = P.band[tid + 1]; i < P.band[tid + 2]; ++i) { double v = mag[i]; acc += v * P.w[i]; }
+    float v = (float)acc;
+    v = v > 500.f ? v : 500.f;
+    mel[(size_t)b * 160 + tid] = __builtin_logf(v) / 10.f;
+  }
+}
+
+// =============================================================================================
+// state reset: zeros everywhere (the graphs' CALL_ONCE init subgraph assigns zero constants), int8
+// histories hold the zero point of their tensor (== quantize(0.0f)).
+// =============================================================================================
+__global__ __launch_bounds__(256) void reset_kernel(ResetP P, const int32_t* __restrict__ ids, int n, int all,
+                                                     uint8_t* __restrict__ state) {
+  const int sidx = blockIdx.x;
+  if (sidx >= n) return;
+  const int id = all ? sidx : ids[sidx];
+  uint8_t* base = state + (size_t)id * st::BYTES;
+  for (int o = threadIdx.x * 16; o < st::BYTES; o += 256 * 16) {
+    int v = 0;
+    if (o >= st::E_R2_1 && o < st::E_R2_2) v = P.e_r2_1;
+    else if (o >= st::E_R2_2 && o < st::E_D2) v = P.e_r2_2;
+    else if (o >= st::E_D2 && o < st::E_BOTT) v = P.e_d2;
+    else if (o >= st::E_BOTT && o < st::E_END) v = P.e_bott;
+    else if (o >= st::D_R0_0 && o < st::D_R0_1) v = P.d_r0_0;
+    else if (o >= st::D_R0_1 && o < st::D_R0_2) v = P.d_r0_1;
+    else if (o >= st::D_R0_2 && o < st::D_UP1) v = P.d_r0_2;
+    int w = (v & 255) * 0x01010101;
+    *reinterpret_cast<i32x4*>(base + o) = (i32x4){w, w, w, w};
+  }
+}
+
+}  // namespace lyra

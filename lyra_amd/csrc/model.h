@@ -1,0 +1,51 @@
+// model.h -- host side: weight container reader and the device-resident, MFMA-fragment-packed model.
+// Replaces TfLiteModelWrapper (lyra/tflite_model_wrapper.cc:36-121): instead of building an interpreter
+// over the flatbuffers, the coefficients are re-laid once at context creation for the hand-written kernels.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace lyra {
+
+struct PackEntry {
+  char name[56];
+  uint32_t dtype, ndim, shape[4];
+  uint64_t offset, nbytes;
+};
+
+class Pack {
+ public:
+  bool open(const std::string& path, std::string* err);
+  const PackEntry* find(const std::string& name) const;
+  template <class T>
+  const T* data(const std::string& name) const {
+    const PackEntry* e = find(name);
+    return e ? reinterpret_cast<const T*>(blob_.data() + e->offset) : nullptr;
+  }
+  bool ok() const { return missing_.empty(); }
+  const std::string& missing() const { return missing_; }
+
+ private:
+  std::vector<uint8_t> blob_;
+  mutable std::string missing_;
+};
+
+struct Model {
+  EncS0P enc0; EncS1P enc1; EncS2P enc2;
+  DecS0P dec0; DecS1P dec1; DecS2P dec2;
+  const float* cb = nullptr;   // [46][16][64]
+  const float* cbt = nullptr;  // [46][64][16]
+  MelP mel;
+  ResetP reset;
+  uint8_t* d_arena = nullptr;
+  size_t arena_bytes = 0;
+};
+
+// Builds the packed model on the current HIP device.  Returns false and sets *err on failure.
+bool build_model(const Pack& pk, int requant_mode, Model* out, std::string* err);
+void free_model(Model* m);
+
+}  // namespace lyra

@@ -1,0 +1,434 @@
+// model.hip -- read lyra_v1.lyrapack, re-lay the coefficients into MFMA B fragments, upload.
+#include "model.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace lyra {
+
+// ---------------------------------------------------------------------------------------------
+// container
+// ---------------------------------------------------------------------------------------------
+bool Pack::open(const std::string& path, std::string* err) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { *err = "cannot open " + path; return false; }
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  blob_.resize((size_t)sz);
+  size_t got = fread(blob_.data(), 1, (size_t)sz, f);
+  fclose(f);
+  if (got != (size_t)sz || sz < 16 || memcmp(blob_.data(), "LYRAPK01", 8) != 0) {
+    *err = path + " is not a LYRAPK01 container";
+    return false;
+  }
+  return true;
+}
+
+const PackEntry* Pack::find(const std::string& name) const {
+  uint32_t n;
+  memcpy(&n, blob_.data() + 8, 4);
+  const PackEntry* e = reinterpret_cast<const PackEntry*>(blob_.data() + 16);
+  for (uint32_t i = 0; i < n; ++i)
+    if (strncmp(e[i].name, name.c_str(), 56) == 0) return &e[i];
+  if (missing_.empty()) missing_ = name;
+  return nullptr;
+}
+
+namespace {
+
+struct QM { int32_t m; int32_t shift; };
+
+// TFLite QuantizeMultiplier(double)
+QM quantize_multiplier(double d) {
+  QM r{0, 0};
+  if (d == 0.0) return r;
+  int sh;
+  double q = std::frexp(d, &sh);
+  long long m = std::llround(q * (double)(1ll << 31));
+  if (m == (1ll << 31)) { m /= 2; ++sh; }
+  if (sh < -31) return r;
+  r.m = (int32_t)m;
+  r.shift = sh;
+  return r;
+}
+
+class Arena {
+ public:
+  template <class T>
+  size_t push(const std::vector<T>& v) {
+    size_t off = (buf_.size() + 255) / 256 * 256;
+    buf_.resize(off + v.size() * sizeof(T));
+    if (!v.empty()) memcpy(buf_.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+  const std::vector<uint8_t>& bytes() const { return buf_; }
+
+ private:
+  std::vector<uint8_t> buf_;
+};
+
+struct Builder {
+  const Pack& pk;
+  Arena arena;
+  std::vector<std::pair<void*, size_t>> fixups;  // (address of a device-pointer field, arena offset)
+
+  template <class P, class T>
+  void put(P* field, const std::vector<T>& v) {
+    size_t off = arena.push(v);
+    fixups.emplace_back((void*)field, off);
+  }
+  std::string key(const char* pre, const char* kind, int idx, const char* leaf) const {
+    return std::string(pre) + "." + kind + "." + std::to_string(idx) + "." + leaf;
+  }
+
+  // ---- fp32 conv [cout][k][cig] -> B fragments [cout/16][K/16][64 lanes][4] --------------------
+  void conv_f(const char* pre, int idx, ConvF* out) {
+    const PackEntry* e = pk.find(key(pre, "conv", idx, "w"));
+    const float* w = pk.data<float>(key(pre, "conv", idx, "w"));
+    const float* b = pk.data<float>(key(pre, "conv", idx, "b"));
+    if (!e || !w || !b) return;
+    int cout = e->shape[0], k = e->shape[1], cig = e->shape[2];
+    int K = k * cig, KC = K / 16, NT = cout / 16;
+    std::vector<float> frag((size_t)NT * KC * 64 * 4);
+    for (int nt = 0; nt < NT; ++nt)
+      for (int c = 0; c < KC; ++c)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int kk = 0; kk < 4; ++kk) {
+            int kidx = c * 16 + kk * 4 + (lane >> 4);
+            int n = nt * 16 + (lane & 15);
+            int tap = kidx / cig, ci = kidx % cig;
+            frag[(((size_t)nt * KC + c) * 64 + lane) * 4 + kk] = w[((size_t)n * k + tap) * cig + ci];
+          }
+    put(&out->w, frag);
+    put(&out->b, std::vector<float>(b, b + cout));
+  }
+
+  // ---- fp32 transposed conv [cout][k][cin], stride s -> polyphase B fragments ---------------------
+  //   K = (k/s)*cin with the OLDEST input block first, N = s*cout (n = phase*cout + co)
+  void tconv_f(const char* pre, int idx, ConvF* out, int* cout_out) {
+    const PackEntry* e = pk.find(key(pre, "tconv", idx, "w"));
+    const float* w = pk.data<float>(key(pre, "tconv", idx, "w"));
+    const float* b = pk.data<float>(key(pre, "tconv", idx, "b"));
+    const int32_t* opt = pk.data<int32_t>(key(pre, "tconv", idx, "opt"));
+    if (!e || !w || !b || !opt) return;
+    int cout = e->shape[0], k = e->shape[1], cin = e->shape[2], s = opt[0];
+    int taps = k / s, K = taps * cin, KC = K / 16, N = s * cout, NT = N / 16;
+    std::vector<float> frag((size_t)NT * KC * 64 * 4);
+    for (int nt = 0; nt < NT; ++nt)
+      for (int c = 0; c < KC; ++c)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int kk = 0; kk < 4; ++kk) {
+            int kidx = c * 16 + kk * 4 + (lane >> 4);
+            int n = nt * 16 + (lane & 15);
+            int tb = kidx / cin, ci = kidx % cin;
+            int i = taps - 1 - tb;
+            int jj = n / cout, co = n % cout;
+            frag[(((size_t)nt * KC + c) * 64 + lane) * 4 + kk] = w[((size_t)co * k + (jj + s * i)) * cin + ci];
+          }
+    put(&out->w, frag);
+    put(&out->b, std::vector<float>(b, b + cout));
+    if (cout_out) *cout_out = cout;
+  }
+
+  // ---- fp32 depthwise [k][C] -> AT16 channel order -------------------------------------------------
+  void dw_f(const char* pre, int idx, DwF* out) {
+    const PackEntry* e = pk.find(key(pre, "dw", idx, "w"));
+    const float* w = pk.data<float>(key(pre, "dw", idx, "w"));
+    const float* b = pk.data<float>(key(pre, "dw", idx, "b"));
+    if (!e || !w || !b) return;
+    int k = e->shape[0], C = e->shape[1];
+    std::vector<float> wp((size_t)k * C), bp(C);
+    for (int j = 0; j < k; ++j)
+      for (int c = 0; c < C; ++c) wp[(size_t)j * C + at16(c)] = w[(size_t)j * C + c];
+    for (int c = 0; c < C; ++c) bp[at16(c)] = b[c];
+    put(&out->w, wp);
+    put(&out->b, bp);
+  }
+
+  // ---- int8 conv [cout][k][cig] -> B fragments [cout/16][K/64][64 lanes][16 bytes] ----------------
+  void conv_q(const char* pre, int idx, ConvQ* out) {
+    const PackEntry* e = pk.find(key(pre, "conv", idx, "w"));
+    const int8_t* w = pk.data<int8_t>(key(pre, "conv", idx, "w"));
+    const int32_t* b = pk.data<int32_t>(key(pre, "conv", idx, "b"));
+    const float* q = pk.data<float>(key(pre, "conv", idx, "q"));
+    const float* ws = pk.data<float>(key(pre, "conv", idx, "wscale"));
+    if (!e || !w || !b || !q || !ws) return;
+    int cout = e->shape[0], k = e->shape[1], cig = e->shape[2];
+    int K = k * cig, KC = K / 64, NT = cout / 16;
+    int zin = (int)q[1];
+    std::vector<int8_t> frag((size_t)NT * KC * 64 * 16);
+    for (int nt = 0; nt < NT; ++nt)
+      for (int c = 0; c < KC; ++c)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 16; ++j) {
+            int kidx = c * 64 + (lane >> 4) * 16 + j;
+            int n = nt * 16 + (lane & 15);
+            frag[(((size_t)nt * KC + c) * 64 + lane) * 16 + j] = w[(size_t)n * K + kidx];
+          }
+    std::vector<int32_t> bf(cout), M(cout), sh(cout);
+    for (int n = 0; n < cout; ++n) {
+      long long sum = 0;
+      for (int kk = 0; kk < K; ++kk) sum += w[(size_t)n * K + kk];
+      bf[n] = (int32_t)(b[n] - (long long)zin * sum);
+      QM m = quantize_multiplier((double)q[0] * (double)ws[n] / (double)q[2]);
+      M[n] = m.m; sh[n] = m.shift;
+    }
+    put(&out->w, frag);
+    put(&out->b, bf);
+    put(&out->M, M);
+    put(&out->sh, sh);
+    out->zout = (int)q[3];
+  }
+
+  // ---- int8 depthwise [k][C] --------------------------------------------------------------------------
+  void dw_q(const char* pre, int idx, DwQ* out) {
+    const PackEntry* e = pk.find(key(pre, "dw", idx, "w"));
+    const int8_t* w = pk.data<int8_t>(key(pre, "dw", idx, "w"));
+    const int32_t* b = pk.data<int32_t>(key(pre, "dw", idx, "b"));
+    const float* q = pk.data<float>(key(pre, "dw", idx, "q"));
+    const float* ws = pk.data<float>(key(pre, "dw", idx, "wscale"));
+    if (!e || !w || !b || !q || !ws) return;
+    int k = e->shape[0], C = e->shape[1];
+    std::vector<int32_t> M(C), sh(C);
+    for (int c = 0; c < C; ++c) {
+      QM m = quantize_multiplier((double)q[0] * (double)ws[c] / (double)q[2]);
+      M[c] = m.m; sh[c] = m.shift;
+    }
+    put(&out->w, std::vector<int8_t>(w, w + (size_t)k * C));
+    put(&out->b, std::vector<int32_t>(b, b + C));
+    put(&out->M, M);
+    put(&out->sh, sh);
+    out->zin = (int)q[1];
+    out->zout = (int)q[3];
+  }
+
+  // ---- int8 transposed conv [64][4][128] -> GEMM fragments, N tiles ordered [co tile][tap] ----------------
+  void tconv_q(const char* pre, int idx, TconvQ* out, QP* dq, const float** sub, int sub_idx) {
+    const PackEntry* e = pk.find(key(pre, "tconv", idx, "w"));
+    const int8_t* w = pk.data<int8_t>(key(pre, "tconv", idx, "w"));
+    const int32_t* b = pk.data<int32_t>(key(pre, "tconv", idx, "b"));
+    const float* q = pk.data<float>(key(pre, "tconv", idx, "q"));
+    const float* ws = pk.data<float>(key(pre, "tconv", idx, "wscale"));
+    const float* sc = pk.data<float>(key(pre, "sub", sub_idx, "c"));
+    if (!e || !w || !b || !q || !ws || !sc) return;
+    int cout = e->shape[0], k = e->shape[1], cin = e->shape[2];  // 64, 4, 128
+    int KC = cin / 64, NT = (cout / 16) * k;
+    int zin = (int)q[1];
+    std::vector<int8_t> frag((size_t)NT * KC * 64 * 16);
+    for (int ct = 0; ct < cout / 16; ++ct)
+      for (int tap = 0; tap < k; ++tap)
+        for (int c = 0; c < KC; ++c)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+              int kidx = c * 64 + (lane >> 4) * 16 + j;
+              int co = ct * 16 + (lane & 15);
+              int nt = ct * k + tap;
+              frag[(((size_t)nt * KC + c) * 64 + lane) * 16 + j] = w[((size_t)co * k + tap) * cin + kidx];
+            }
+    std::vector<int32_t> zf((size_t)k * cout);
+    for (int tap = 0; tap < k; ++tap)
+      for (int co = 0; co < cout; ++co) {
+        long long sum = 0;
+        for (int c = 0; c < cin; ++c) sum += w[((size_t)co * k + tap) * cin + c];
+        zf[(size_t)tap * cout + co] = (int32_t)(-(long long)zin * sum);
+      }
+    QM m = quantize_multiplier((double)q[0] * (double)ws[0] / (double)q[2]);
+    put(&out->w, frag);
+    put(&out->zfold, zf);
+    put(&out->bias, std::vector<int32_t>(b, b + cout));
+    out->M = m.m; out->sh = m.shift; out->zout = (int)q[3];
+    dq->s = q[2]; dq->z = (int)q[3];
+    put(sub, std::vector<float>(sc, sc + cout));
+  }
+
+  void lrelu_q(const char* pre, int idx, LreluQ* out) {
+    const float* q = pk.data<float>(key(pre, "lrelu8", idx, "q"));
+    if (!q) return;
+    QM p = quantize_multiplier((double)q[0] / (double)q[2]);
+    QM n = quantize_multiplier((double)q[0] * (double)LYRA_LRELU_ALPHA / (double)q[2]);
+    out->zin = (int)q[1]; out->zout = (int)q[3];
+    out->mpos = p.m; out->spos = p.shift; out->mneg = n.m; out->sneg = n.shift;
+  }
+  void add_q(const char* pre, int idx, AddQ* out) {
+    const float* q = pk.data<float>(key(pre, "add8", idx, "q"));
+    if (!q) return;
+    double s1 = q[0], s2 = q[2], so = q[4];
+    double twice = 2.0 * (s1 > s2 ? s1 : s2);
+    QM m1 = quantize_multiplier(s1 / twice), m2 = quantize_multiplier(s2 / twice);
+    QM mo = quantize_multiplier(twice / ((double)(1 << 20) * so));
+    out->z1 = (int)q[1]; out->z2 = (int)q[3]; out->zo = (int)q[5];
+    out->m1 = m1.m; out->s1 = m1.shift; out->m2 = m2.m; out->s2 = m2.shift; out->mo = mo.m; out->so = mo.shift;
+  }
+  QP qp(const char* pre, const char* kind, int idx) {
+    const float* q = pk.data<float>(key(pre, kind, idx, "q"));
+    QP r{1.f, 0};
+    if (q) { r.s = q[0]; r.z = (int)q[1]; }
+    return r;
+  }
+};
+
+double hz_to_mel(double f) { return 1127.0 * std::log1p(f / 700.0); }
+
+}  // namespace
+
+bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
+  const int32_t* ver = pk.data<int32_t>("meta.version");
+  if (!ver || ver[0] != 3) { *err = "weight container version identifier is not 3 (lyra_config.h:145-166)"; return false; }
+  Builder B{pk};
+  // ---- encoder (op numbering: tools/pack_weights.py) ----------------------------------
+  B.conv_f("enc", 0, &M->enc0.first);
+  for (int r = 0; r < 3; ++r) {
+    B.dw_f("enc", r, &M->enc0.dw[r]);
+    B.conv_f("enc", 1 + 2 * r, &M->enc0.pw[r]);
+    B.conv_f("enc", 2 + 2 * r, &M->enc0.cv[r]);
+    B.dw_f("enc", 3 + r, &M->enc1.dw[r]);
+    B.conv_f("enc", 8 + 2 * r, &M->enc1.pw[r]);
+    B.conv_f("enc", 9 + 2 * r, &M->enc1.cv[r]);
+  }
+  B.conv_f("enc", 7, &M->enc0.down);
+  B.conv_f("enc", 14, &M->enc1.down);
+  EncS2P& E2 = M->enc2;
+  B.dw_f("enc", 6, &E2.dw0);
+  B.conv_f("enc", 15, &E2.pw0);
+  E2.q_r0 = B.qp("enc", "quant", 0);
+  E2.dq_r0 = B.qp("enc", "dequant", 0);
+  E2.q_x1 = B.qp("enc", "quant", 1);
+  E2.out = B.qp("enc", "dequant", 9);
+  for (int i = 0; i < 7; ++i) B.lrelu_q("enc", i, &E2.lr[i]);
+  B.conv_q("enc", 16, &E2.r0b);
+  for (int r = 0; r < 2; ++r) {
+    B.dw_q("enc", 7 + r, &E2.dwq[r]);
+    B.conv_q("enc", 17 + 2 * r, &E2.pwq[r]);
+    B.conv_q("enc", 18 + 2 * r, &E2.cvq[r]);
+    B.add_q("enc", r, &E2.add[r]);
+  }
+  B.conv_q("enc", 21, &E2.down2);
+  B.conv_q("enc", 22, &E2.bott);
+  E2.mode = requant_mode;
+  // ---- decoder -----------------------------------------------------------------------------
+  DecS0P& D0 = M->dec0;
+  B.conv_f("dec", 0, &D0.head);
+  D0.q0 = B.qp("dec", "quant", 0);
+  for (int g = 0; g < 4; ++g) B.tconv_q("dec", g, &D0.up0[g], &D0.up0_dq[g], &D0.up0_sub[g], g);
+  D0.q1 = B.qp("dec", "quant", 1);
+  for (int r = 0; r < 3; ++r) {
+    B.dw_q("dec", r, &D0.dwq[r]);
+    B.conv_q("dec", 1 + 2 * r, &D0.pwq[r]);
+    B.conv_q("dec", 2 + 2 * r, &D0.cvq[r]);
+  }
+  for (int i = 0; i < 6; ++i) B.lrelu_q("dec", i, &D0.lr[i]);
+  for (int i = 0; i < 2; ++i) B.add_q("dec", i, &D0.add[i]);
+  {
+    const float* q = pk.data<float>("dec.conv.2.q");  // output quantisation of resblock-0's grouped conv
+    if (q) { D0.dq_r0.s = q[2]; D0.dq_r0.z = (int)q[3]; }
+  }
+  D0.q3 = B.qp("dec", "quant", 3);
+  for (int g = 0; g < 2; ++g) B.tconv_q("dec", 4 + g, &D0.up1[g], &D0.up1_dq[g], &D0.up1_sub[g], 4 + g);
+  D0.mode = requant_mode;
+  for (int r = 0; r < 3; ++r) {
+    B.dw_f("dec", 3 + r, &M->dec1.dw[r]);
+    B.conv_f("dec", 7 + 2 * r, &M->dec1.pw[r]);
+    B.conv_f("dec", 8 + 2 * r, &M->dec1.cv[r]);
+    B.dw_f("dec", 6 + r, &M->dec2.dw[r]);
+    B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r]);
+    B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r]);
+  }
+  B.tconv_f("dec", 6, &M->dec1.up, nullptr);
+  {
+    const float* sc = pk.data<float>("dec.sub.6.c");
+    if (sc) B.put(&M->dec1.up_sub, std::vector<float>(sc, sc + 64));
+  }
+  B.tconv_f("dec", 7, &M->dec2.up, nullptr);
+  {
+    const float* sc = pk.data<float>("dec.sub.7.c");
+    if (sc) M->dec2.up_sub = sc[0];
+  }
+  // ---- RVQ codebooks -------------------------------------------------------------------------------------
+  {
+    const float* cb = pk.data<float>("rvq.codebooks");
+    if (cb) {
+      std::vector<float> nat(cb, cb + 46 * 16 * 64), tr((size_t)46 * 64 * 16);
+      for (int k = 0; k < 46; ++k)
+        for (int j = 0; j < 16; ++j)
+          for (int d = 0; d < 64; ++d) tr[((size_t)k * 64 + d) * 16 + j] = cb[((size_t)k * 16 + j) * 64 + d];
+      B.put(&M->cb, nat);
+      B.put(&M->cbt, tr);
+    }
+  }
+  // ---- log-mel tables: periodic Hann 640, radix-2 twiddles, 160-band two-tap mel -----------
+  {
+    const double PI = 3.14159265358979323846;
+    std::vector<double> hann(640), twr(1023), twi(1023), w(513, 0.0);
+    for (int i = 0; i < 640; ++i) hann[i] = 0.5 - 0.5 * std::cos(2.0 * PI * i / 640);
+    for (int len = 2; len <= 1024; len <<= 1) {
+      double ang = -2.0 * PI / len;
+      for (int k = 0; k < len / 2; ++k) {
+        twr[len / 2 - 1 + k] = std::cos(ang * k);
+        twi[len / 2 - 1 + k] = std::sin(ang * k);
+      }
+    }
+    const int NB = 160, BINS = 513;
+    double lo = 0.0, hi = 0.495 * 16000.0;
+    double mel_lo = hz_to_mel(lo), mel_hi = hz_to_mel(hi);
+    double spacing = (mel_hi - mel_lo) / (NB + 1);
+    std::vector<double> center(NB + 1);
+    for (int i = 0; i <= NB; ++i) center[i] = mel_lo + spacing * (i + 1);
+    double hz_per_bin = 0.5 * 16000.0 / (BINS - 1);
+    int start = (int)(1.5 + lo / hz_per_bin), end = (int)(hi / hz_per_bin);
+    std::vector<int> band(BINS, -2);
+    int channel = 0;
+    for (int i = start; i <= end; ++i) {
+      double melf = hz_to_mel(i * hz_per_bin);
+      while (channel < NB && center[channel] < melf) ++channel;
+      band[i] = channel - 1;
+      int ch = channel - 1;
+      w[i] = ch >= 0 ? (center[ch + 1] - melf) / (center[ch + 1] - center[ch])
+                     : (center[0] - melf) / (center[0] - mel_lo);
+    }
+    // first[v + 1] = first bin whose lower band is >= v, v = -1 .. 160 (bands are non-decreasing over [start,end])
+    std::vector<int> first(NB + 2);
+    for (int v = -1; v <= NB; ++v) {
+      int i = start;
+      while (i <= end && band[i] < v) ++i;
+      first[v + 1] = i;
+    }
+    B.put(&M->mel.hann, hann);
+    B.put(&M->mel.tw_re, twr);
+    B.put(&M->mel.tw_im, twi);
+    B.put(&M->mel.band, first);
+    B.put(&M->mel.w, w);
+    M->mel.start = start;
+    M->mel.end = end;
+  }
+  // ---- zero points of the int8 histories -----------------------------------------------------------------------
+  M->reset.e_r2_1 = (int8_t)E2.dwq[0].zin;
+  M->reset.e_r2_2 = (int8_t)E2.dwq[1].zin;
+  M->reset.e_d2 = (int8_t)E2.lr[5].zout;
+  M->reset.e_bott = (int8_t)E2.lr[6].zout;
+  M->reset.d_r0_0 = (int8_t)D0.dwq[0].zin;
+  M->reset.d_r0_1 = (int8_t)D0.dwq[1].zin;
+  M->reset.d_r0_2 = (int8_t)D0.dwq[2].zin;
+
+  if (!pk.ok()) { *err = "weight container lacks tensor " + pk.missing(); return false; }
+
+  const std::vector<uint8_t>& bytes = B.arena.bytes();
+  if (hipMalloc((void**)&M->d_arena, bytes.size()) != hipSuccess) { *err = "hipMalloc(weights) failed"; return false; }
+  if (hipMemcpy(M->d_arena, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    *err = "hipMemcpy(weights) failed";
+    return false;
+  }
+  M->arena_bytes = bytes.size();
+  for (auto& fx : B.fixups) *reinterpret_cast<const uint8_t**>(fx.first) = M->d_arena + fx.second;
+  return true;
+}
+
+void free_model(Model* m) {
+  if (m->d_arena) (void)hipFree(m->d_arena);
+  m->d_arena = nullptr;
+}
+
+}  // namespace lyra
