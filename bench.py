@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X-native Lyra encode+decode hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric, configs[2]): per GPU 4096 independent 16 kHz streams, each advancing one
+20 ms frame (320 samples) per step, encode at 9200 bps (184 bits = 46 RVQ stages) + decode.  A "step" =
+lyra_hip_encode_dev (PCM -> packets) followed by lyra_hip_decode_dev (packets -> PCM) over the whole batch,
+inputs already resident in HBM, state carried from step to step (frames of a stream are NOT independent).
+Streams are sharded across GPUs with no data-path collective (weak scaling: 4096 streams per GPU); the
+only collectives are the timing barrier and the max-over-ranks reduction.
+
+One JSON line on rank 0.  `roofline` is for the kernel with the largest share of the step, its duration
+measured live with HIP events recorded on the library's own stream around every launch of the timed region
+(lyra_hip_profile_*); `cpu_baseline` times the CPU oracle (a port, not the TFLite binary) on this box's host
+cores on a bounded sample of the same kind of input.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STREAMS_PER_GPU = 4096
+NUM_BITS = 184
+SEED = 0x4C797261  # "Lyra"
+
+# Algorithmic work per stream-frame of each kernel (DESIGN.md "Kernels"): fp32 MACs, int8 MACs, HBM bytes
+# (inputs + outputs + per-stream state read and written, at the reference's fp32 state representation).
+KERNEL_WORK = {
+    "enc_s0_kernel": dict(f32=912640, i8=0, bytes=640 + 2 * (48 + 26 * 64 + 5 * 64) * 4 + 4 * 128 * 4),
+    "enc_s1_kernel": dict(f32=430592, i8=0, bytes=4 * 128 * 4 + 2 * (26 * 128 + 2 * 128) * 4 + 2 * 256 * 4),
+    "enc_s2_kernel": dict(f32=132608, i8=519168, bytes=2 * 256 * 4 + 2 * (26 * 256 + 2 * 256 + 2 * 512) * 4 + 256),
+    "rvq_encode_kernel": dict(f32=0, i8=0, bytes=256 + 23, flops=3 * 16 * 64 * 46 + 3 * 64 * 46),
+    "rvq_decode_kernel": dict(f32=0, i8=0, bytes=23 + 256, flops=64 * 46),
+    "dec_s0_kernel": dict(f32=24576, i8=758272, bytes=256 + 2 * (2 * 64 + 8 * 64 + 26 * 256 + 4 * 64) * 4 + 4 * 128 * 4),
+    "dec_s1_kernel": dict(f32=627200, i8=0, bytes=4 * 128 * 4 + 2 * (26 * 128 + 5 * 64) * 4 + 20 * 64 * 4),
+    "dec_s2_kernel": dict(f32=584960, i8=0, bytes=20 * 64 * 4 + 2 * (26 * 64 + 48) * 4 + 640),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
+    ap.add_argument("--bits", type=int, default=NUM_BITS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="CPU-only: exercise the multi-rank plumbing (gloo) without touching a GPU")
+    return ap.parse_args()
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def reduce_job(local_seconds, local_units, world, backend_device):
+    """max-over-ranks time, sum-over-ranks units (the only collectives of the whole job)."""
+    if world == 1:
+        return local_seconds, local_units
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=backend_device)
+    u = torch.tensor([float(local_units)], dtype=torch.float64, device=backend_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(u.item())
+
+
+def shard_ids(total_streams, rank, world):
+    """Contiguous block of stream ids per rank.  State never leaves its GPU."""
+    per = total_streams // world
+    return rank * per, per
+
+
+def selftest_dist(args):
+    import torch
+    import torch.distributed as dist
+    rank, world, _ = dist_env()
+    if world > 1:
+        dist.init_process_group("gloo", init_method="env://")
+        dist.barrier()
+    lo, per = shard_ids(args.streams * world, rank, world)
+    secs, units = reduce_job(0.5 + 0.25 * rank, per * args.steps, world, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"selftest": "dist", "world": world, "seconds": secs, "units": units,
+                          "first_id": lo, "per_rank": per}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(bits):
+    """Oracle (CPU port of the same arithmetic) on the host cores, bounded to ~12 s."""
+    from oracle import lyra_oracle
+    lyra_oracle.build()
+    o = lyra_oracle.Oracle(mode="exact")
+    cores = os.cpu_count() or 1
+    rng = np.random.Generator(np.random.PCG64(SEED))
+    streams = cores * 2
+
+    def run(steps):
+        pcm = rng.integers(-32768, 32768, size=(steps, streams, 320)).astype(np.int16)
+        r = lyra_oracle.run_batch(o, pcm, bits // 4, do_decode=True, threads=cores)
+        return streams * steps / r["seconds"], r
+    rate, _ = run(8)
+    steps = int(max(16, min(4000, 12.0 * rate / streams)))
+    rate, r = run(steps)
+    split = r["stage_seconds"] / (streams * steps) * 1e3
+    return {"value": round(rate, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{streams} streams x {steps} frames, uniform full-scale int16 PCM, {bits} bits, "
+                      f"oracle/lyra_oracle.c one stream per thread",
+            "ms_per_frame_per_core": {"extract": round(float(split[0]), 4), "quantize": round(float(split[1]), 4),
+                                      "dequantize": round(float(split[2]), 4), "generate": round(float(split[3]), 4)}}
+
+
+def main():
+    args = parse()
+    if args.selftest_dist:
+        return selftest_dist(args)
+    import torch
+    import lyra_amd
+    rank, world, local = dist_env()
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback); use --selftest-dist for the plumbing test")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    B, K, W, bits = args.streams, args.steps, args.warmup, args.bits
+    first_id, _ = shard_ids(B * world, rank, world)
+    ctx = lyra_amd.LyraHip(device=local, max_streams=B, requant="exact")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + first_id)
+    # UnitToInt16Scalar(U(-1,1)) i.i.d. (lyra_benchmark_lib.cc:233-239): full-scale uniform int16
+    pcm_in = torch.randint(-32768, 32768, (W + K, B, 320), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
+    ids = torch.arange(B, device=dev, dtype=torch.int32)  # local stream slots of this rank's shard
+    packets = torch.empty((B, lyra_amd.packet_size(bits)), device=dev, dtype=torch.uint8)
+    pcm_out = torch.empty((B, 320), device=dev, dtype=torch.int16)
+    torch.cuda.synchronize()
+
+    def step(i):
+        ctx.encode_dev(ids, pcm_in[i], bits, packets)
+        ctx.decode_dev(ids, packets, bits, pcm_out)
+
+    for i in range(W):
+        step(i)
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_read()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+    barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    secs, frames = reduce_job(t1 - t0, B * K, world, dev)
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    value = frames / secs
+    kern = {}
+    for name, (ms, n) in prof.items():
+        if n == 0 or name not in KERNEL_WORK:
+            continue
+        w = KERNEL_WORK[name]
+        dur = ms / n * 1e-3
+        kern[name] = {"avg_us": round(dur * 1e6, 2), "launches": n,
+                      "f32_tflops": round(2 * w["f32"] * B / dur / 1e12, 3),
+                      "i8_tops": round(2 * w["i8"] * B / dur / 1e12, 3),
+                      "alg_gbs": round(w["bytes"] * B / dur / 1e9, 1)}
+    dom = max(kern, key=lambda k: kern[k]["avg_us"])
+    w = KERNEL_WORK[dom]
+    dur = kern[dom]["avg_us"] * 1e-6
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from rocprofv3 --pmc passes (offline)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if w["f32"] > 0:
+        ach = 2 * w["f32"] * B / dur / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_flops_per_launch": 2 * w["f32"] * B, "algorithmic_bytes_per_launch": w["bytes"] * B,
+                "avg_launch_us": kern[dom]["avg_us"]}
+    else:
+        ach = w["bytes"] * B / dur / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": w["bytes"] * B, "avg_launch_us": kern[dom]["avg_us"]}
+    out = {
+        "metric": "20ms 16kHz frames/sec encode+decode (whole node) at batch 4096; xRT/stream",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(secs / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32+i8 (fp32 and int8 layers exactly as the reference graphs)",
+        "data": "synthetic",
+        "config": {"workload": f"batch={B} streams/GPU x 1 frame(20 ms, 320 samples)/step, {bits} bits "
+                               f"({bits // 4}-stage RVQ, {bits * 50} bps), encode+decode, state carried across steps",
+                   "streams_per_gpu": B, "total_streams": B * world, "num_bits": bits,
+                   "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
+                   "requant_mode": "exact"},
+        "xrt_per_stream": round(value / 50.0 / (B * world), 3),
+        "xrt_aggregate": round(value / 50.0, 1),
+        "path_f32_tflops": round(value * 5.425152e6 / 1e12 / world, 3),
+        "path_frac_of_f32_mfma_peak": round(value * 5.425152e6 / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
+        "roofline": roof,
+        "kernels": kern,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(bits)
+        except Exception as e:  # the baseline leg must never take the GPU number down with it
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,14 @@ int lyra_hip_synchronize(lyra_hip_ctx* ctx);
 size_t lyra_hip_state_bytes_per_stream(void);
 int lyra_hip_max_streams(const lyra_hip_ctx* ctx);
 
+/* Measurement hook (bench.py): when enabled, every kernel launch is bracketed by HIP events recorded on the
+ * context's stream; profile_read() synchronises, returns per-kernel total milliseconds and launch counts
+ * since the previous read (arrays of lyra_hip_profile_kernel_count() entries) and clears them. */
+int lyra_hip_profile_enable(lyra_hip_ctx* ctx, int on);
+int lyra_hip_profile_kernel_count(void);
+const char* lyra_hip_profile_kernel_name(int i);
+int lyra_hip_profile_read(lyra_hip_ctx* ctx, double* total_ms, long* launches);
+
 /* Test hook: copies stage-boundary activations of the LAST extract/generate call (device scratch) to host.
  * which: 0 enc stage0 out [B][4][128], 1 enc stage1 out [B][2][256], 2 enc int8 codes [B][64] (as f32),
  *        3 dec head out [B][4][128], 4 dec stage1 out [B][20][64].  Channel order is the library's

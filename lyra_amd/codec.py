@@ -84,6 +84,10 @@ def _load():
     L.lyra_hip_synchronize.argtypes = [vp]
     L.lyra_hip_state_bytes_per_stream.restype = C.c_size_t
     L.lyra_hip_max_streams.argtypes = [vp]
+    L.lyra_hip_profile_enable.argtypes = [vp, ci]
+    L.lyra_hip_profile_kernel_name.restype = cp
+    L.lyra_hip_profile_kernel_name.argtypes = [ci]
+    L.lyra_hip_profile_read.argtypes = [vp, vp, vp]
     L.lyra_hip_debug_read.restype = C.c_long
     L.lyra_hip_debug_read.argtypes = [vp, ci, vp, C.c_long]
     _lib = L
@@ -214,6 +218,17 @@ class LyraHip:
         out = np.empty((B, HOP), np.int16)
         self._chk(self.L.lyra_hip_decode(self.h, ids.ctypes.data, B, packets.ctypes.data, num_bits, out.ctypes.data))
         return out
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.lyra_hip_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        """{kernel name: (total_ms, launches)} since the last read (HIP events on the context's stream)."""
+        n = self.L.lyra_hip_profile_kernel_count()
+        ms = (C.c_double * n)()
+        cnt = (C.c_long * n)()
+        self._chk(self.L.lyra_hip_profile_read(self.h, ms, cnt))
+        return {self.L.lyra_hip_profile_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
 
     def debug_read(self, which, n):
         out = np.empty(n, np.float32)

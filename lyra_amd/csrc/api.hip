@@ -42,6 +42,11 @@ struct lyra_hip_ctx {
   int16_t* d_pcm_out = nullptr;
   float* d_mel = nullptr;    // [cap][160]
   int last_B_enc = 0, last_B_dec = 0;
+  // optional per-kernel timing with HIP events on this context's stream (bench.py roofline leg)
+  bool profiling = false;
+  struct Span { int kid; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> event_pool;
   std::string err;
 };
 
@@ -125,51 +130,81 @@ int check_ids_host(lyra_hip_ctx* c, const int32_t* ids, int B) {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+enum { K_ENC_S0, K_ENC_S1, K_ENC_S2, K_RVQ_ENC, K_RVQ_DEC, K_DEC_S0, K_DEC_S1, K_DEC_S2, K_LOGMEL, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"enc_s0_kernel", "enc_s1_kernel", "enc_s2_kernel", "rvq_encode_kernel",
+                                           "rvq_decode_kernel", "dec_s0_kernel", "dec_s1_kernel", "dec_s2_kernel",
+                                           "logmel_kernel"};
+
+hipEvent_t take_event(lyra_hip_ctx* c) {
+  if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  lyra_hip_ctx* c; int kid; hipEvent_t a = nullptr;
+  ProfScope(lyra_hip_ctx* c_, int kid_) : c(c_), kid(kid_) {
+    if (c->profiling) { a = take_event(c); (void)hipEventRecord(a, c->stream); }
+  }
+  ~ProfScope() {
+    if (a) { hipEvent_t b = take_event(c); (void)hipEventRecord(b, c->stream); c->spans.push_back({kid, a, b}); }
+  }
+};
+
 // ---- launches (all on c->stream) ---------------------------------------------------------------------
 int launch_extract(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
   const Model& M = c->model;
+  { ProfScope ps(c, K_ENC_S0);
   hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(512), enc_s0_lds_bytes(), c->stream,
-                     M.enc0, d_pcm, d_ids, B, c->d_state, c->d_e0);
+                     M.enc0, d_pcm, d_ids, B, c->d_state, c->d_e0); }
+  { ProfScope ps(c, K_ENC_S1);
   hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(512), enc_s1_lds_bytes(), c->stream,
-                     M.enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1);
+                     M.enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1); }
+  { ProfScope ps(c, K_ENC_S2);
   hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), c->stream,
-                     M.enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes);
+                     M.enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
   return 0;
 }
 
 int launch_rvq_encode(lyra_hip_ctx* c, int B, const float* d_feat, int num_stages, int32_t* d_idx, uint8_t* d_pkt) {
+  { ProfScope ps(c, K_RVQ_ENC);
   hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->stream, c->model.cbt, d_feat, B,
-                     num_stages, d_idx, d_pkt);
+                     num_stages, d_idx, d_pkt); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
 int launch_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* d_idx, const uint8_t* d_pkt, int num_stages,
                       float* d_feat) {
+  { ProfScope ps(c, K_RVQ_DEC);
   hipLaunchKernelGGL(rvq_decode_kernel, dim3(cdiv(B, 4)), dim3(256), 0, c->stream, c->model.cb, d_idx, d_pkt,
-                     num_stages, B, d_feat);
+                     num_stages, B, d_feat); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
 int launch_generate(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
   const Model& M = c->model;
+  { ProfScope ps(c, K_DEC_S0);
   hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), c->stream,
-                     M.dec0, d_feat, d_ids, B, c->d_state, c->d_d0);
+                     M.dec0, d_feat, d_ids, B, c->d_state, c->d_d0); }
+  { ProfScope ps(c, K_DEC_S1);
   hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(512), dec_s1_lds_bytes(), c->stream,
-                     M.dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1);
+                     M.dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1); }
+  { ProfScope ps(c, K_DEC_S2);
   hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(512), dec_s2_lds_bytes(), c->stream,
-                     M.dec2, c->d_d1, d_ids, B, c->d_state, d_pcm);
+                     M.dec2, c->d_d1, d_ids, B, c->d_state, d_pcm); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
   return 0;
 }
 
 int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
+  { ProfScope ps(c, K_LOGMEL);
   hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->stream, c->model.mel, d_pcm, d_ids, B,
-                     c->d_state, d_mel);
+                     c->d_state, d_mel); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -234,6 +269,8 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_scratch(c);
+  for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->d_state) (void)hipFree(c->d_state);
   free_model(&c->model);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -433,6 +470,29 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
   if ((rc = launch_generate(c, c->d_ids, B, c->d_lossy, c->d_pcm_out))) return rc;
   HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int lyra_hip_profile_enable(lyra_hip_ctx* c, int on) {
+  if (!c) return LYRA_HIP_EINVAL;
+  c->profiling = on != 0;
+  return 0;
+}
+int lyra_hip_profile_kernel_count(void) { return K_COUNT; }
+const char* lyra_hip_profile_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? kKernelNames[i] : ""; }
+int lyra_hip_profile_read(lyra_hip_ctx* c, double* total_ms, long* launches) {
+  if (!c || !total_ms || !launches) return LYRA_HIP_EINVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < K_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+  for (auto& sp : c->spans) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, sp.a, sp.b));
+    total_ms[sp.kid] += ms;
+    launches[sp.kid] += 1;
+    c->event_pool.push_back(sp.a);
+    c->event_pool.push_back(sp.b);
+  }
+  c->spans.clear();
   return 0;
 }
 

@@ -1,0 +1,124 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/lyra_hip.h declares, refuses to run without a GPU (no CPU fallback), and the host logic of the
+Python plugin mirror follows the reference's validation rules.  No compute calls here."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import lyra_amd
+    lyra_amd.build_library()
+    return ctypes.CDLL(lyra_amd.library_path())
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "lyra_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(lyra_hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/lyra_hip.h but not exported"
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import lyra_amd
+    h = ctypes.c_void_p()
+    lib.lyra_hip_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_void_p)]
+    rc = lib.lyra_hip_create(lyra_amd.default_model_dir().encode(), 0, 16, 0, ctypes.byref(h))
+    assert rc == -2 and not h.value  # LYRA_HIP_ENODEV
+    lib.lyra_hip_last_error.restype = ctypes.c_char_p
+    assert b"no CPU path" in lib.lyra_hip_last_error(None)
+    with pytest.raises(lyra_amd.LyraHipError):
+        lyra_amd.LyraHip()
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lyra_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f)).read()
+                # (comments may cite the oracle; code must not include, import, link or dlopen it)
+                for pat in (r'#include\s*[<"][^>"]*oracle', r"^\s*(from|import)\s+oracle", r"liblyra_oracle",
+                            r"dlopen", r"-l\s*lyra_oracle"):
+                    assert not re.search(pat, src, flags=re.M), (f, pat)
+    out = subprocess.run(["ldd", os.path.join(ROOT, "lyra_amd", "liblyra_hip.so")], capture_output=True, text=True)
+    assert "oracle" not in out.stdout
+
+
+def test_state_layout_constant(lib):
+    lib.lyra_hip_state_bytes_per_stream.restype = ctypes.c_size_t
+    n = lib.lyra_hip_state_bytes_per_stream()
+    assert n % 256 == 0 and 60000 < n < 70000
+
+
+def test_pack_container_roundtrip(tmp_path):
+    """The weight container the library loads is what tools/pack_weights.py writes (format check)."""
+    import struct
+    path = os.path.join(ROOT, "lyra_amd", "assets", "lyra_v1.lyrapack")
+    blob = open(path, "rb").read()
+    assert blob[:8] == b"LYRAPK01"
+    n = struct.unpack_from("<I", blob, 8)[0]
+    names = {}
+    for i in range(n):
+        name, dtype, ndim, s0, s1, s2, s3, off, nb = struct.unpack_from("<56sII4IQQ", blob, 16 + 96 * i)
+        names[name.rstrip(b"\0").decode()] = (dtype, (s0, s1, s2, s3)[:ndim], off, nb)
+        assert off % 64 == 0 and off + nb <= len(blob)
+    assert names["rvq.codebooks"][1] == (46, 16, 64)
+    assert names["enc.conv.0.w"][1] == (64, 64, 1) and names["dec.tconv.7.w"][1] == (1, 64, 64)
+    ver = np.frombuffer(blob, np.int32, 1, names["meta.version"][2])[0]
+    assert ver == 3  # lyra_config.binarypb identifier == kVersionMinor (lyra_config.h:145-166)
+
+
+def test_python_plugin_validation_rules():
+    """Argument validation that never reaches the device (residual_vector_quantizer.cc:79-89,116-126;
+    generative_model_interface.h:50-101)."""
+    import lyra_amd
+
+    class Boom:
+        def __getattr__(self, k):
+            raise AssertionError("device path must not be reached")
+    q = lyra_amd.ResidualVectorQuantizer(Boom())
+    assert q.Quantize(np.zeros(64), 185) is None
+    assert q.Quantize(np.zeros(64), 62) is None
+    assert q.DecodeToLossyFeatures("0" * 185) is None
+    assert q.DecodeToLossyFeatures("01" * 31) is None
+    g = lyra_amd.LyraGanModel(Boom())
+    assert g.GenerateSamples(-1) is None
+    assert g.GenerateSamples(0).size == 0
+    assert g.GenerateSamples(5) is None
+    assert g.AddFeatures(np.zeros(63)) is False
+    assert g.num_samples_available() == 0
+    assert g.AddFeatures(np.zeros(64)) and g.num_samples_available() == 320
+    e = lyra_amd.SoundStreamEncoder(Boom())
+    assert e.Extract(np.zeros(319, np.int16)) is None
+    assert lyra_amd.packet_size(64) == 8 and lyra_amd.packet_size(120) == 15 and lyra_amd.packet_size(184) == 23
+    assert lyra_amd.bitrate_to_num_bits(3200) == 64 and lyra_amd.bitrate_to_num_bits(9200) == 184
+
+
+def test_bench_multi_rank_plumbing_gloo():
+    """world_size 2 on CPU (gloo): stream sharding, barrier, max-over-ranks time, summed units."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--selftest-dist", "--gpus", "2",
+           "--steps", "7", "--streams", "4096"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["world"] == 2 and r["units"] == 2 * 4096 * 7 and abs(r["seconds"] - 0.75) < 1e-9
+    assert r["per_rank"] == 4096 and r["first_id"] == 0
