@@ -104,12 +104,24 @@ def selftest_dist(args):
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(bits):
     """Oracle (CPU port of the same arithmetic) on the host cores, bounded to ~12 s."""
     from oracle import lyra_oracle
     lyra_oracle.build()
     o = lyra_oracle.Oracle(mode="exact")
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     rng = np.random.Generator(np.random.PCG64(SEED))
     streams = cores * 2
 

@@ -156,13 +156,13 @@ int launch_extract(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* 
   const Model& M = c->model;
   { ProfScope ps(c, K_ENC_S0);
   hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(512), enc_s0_lds_bytes(), c->stream,
-                     M.enc0, d_pcm, d_ids, B, c->d_state, c->d_e0); }
+                     M.d_enc0, d_pcm, d_ids, B, c->d_state, c->d_e0); }
   { ProfScope ps(c, K_ENC_S1);
   hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(512), enc_s1_lds_bytes(), c->stream,
-                     M.enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1); }
+                     M.d_enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1); }
   { ProfScope ps(c, K_ENC_S2);
   hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), c->stream,
-                     M.enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes); }
+                     M.d_enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
   return 0;
@@ -170,7 +170,7 @@ int launch_extract(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* 
 
 int launch_rvq_encode(lyra_hip_ctx* c, int B, const float* d_feat, int num_stages, int32_t* d_idx, uint8_t* d_pkt) {
   { ProfScope ps(c, K_RVQ_ENC);
-  hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->stream, c->model.cbt, d_feat, B,
+  hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->stream, c->model.cb, d_feat, B,
                      num_stages, d_idx, d_pkt); }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -189,13 +189,13 @@ int launch_generate(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d
   const Model& M = c->model;
   { ProfScope ps(c, K_DEC_S0);
   hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), c->stream,
-                     M.dec0, d_feat, d_ids, B, c->d_state, c->d_d0); }
+                     M.d_dec0, d_feat, d_ids, B, c->d_state, c->d_d0); }
   { ProfScope ps(c, K_DEC_S1);
   hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(512), dec_s1_lds_bytes(), c->stream,
-                     M.dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1); }
+                     M.d_dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1); }
   { ProfScope ps(c, K_DEC_S2);
   hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(512), dec_s2_lds_bytes(), c->stream,
-                     M.dec2, c->d_d1, d_ids, B, c->d_state, d_pcm); }
+                     M.d_dec2, c->d_d1, d_ids, B, c->d_state, d_pcm); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
   return 0;
@@ -203,7 +203,7 @@ int launch_generate(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d
 
 int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
   { ProfScope ps(c, K_LOGMEL);
-  hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->stream, c->model.mel, d_pcm, d_ids, B,
+  hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->stream, c->model.d_mel, d_pcm, d_ids, B,
                      c->d_state, d_mel); }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -296,7 +296,7 @@ int lyra_hip_reset_streams(lyra_hip_ctx* c, const int32_t* ids, int n) {
   if (!c) return LYRA_HIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
   if (!ids) {
-    hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->stream, c->model.reset,
+    hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->stream, c->model.d_reset,
                        (const int32_t*)nullptr, c->max_streams, 1, c->d_state);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -306,7 +306,7 @@ int lyra_hip_reset_streams(lyra_hip_ctx* c, const int32_t* ids, int n) {
   if ((rc = check_ids_host(c, ids, n))) return rc;
   if ((rc = ensure_scratch(c, n))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->stream, c->model.reset, (const int32_t*)c->d_ids, n, 0,
+  hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->stream, c->model.d_reset, (const int32_t*)c->d_ids, n, 0,
                      c->d_state);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -16,31 +16,36 @@
 namespace lyra {
 
 // =============================================================================================
-// stage 0
+// stage 0 -- like encoder stage 2 a long chain of small dependent phases: small tile (S = 8 streams,
+// ~47 KB LDS), three workgroups per CU.  Rows of [2][S] matrices are t*S + s (one 16-row MFMA tile).
 // =============================================================================================
 namespace {
-constexpr int SD0 = 16;
+constexpr int SD0 = 8;
 constexpr int FS = 72;      // feature row stride (64 + 8) floats
 constexpr int CS2 = 264;    // 256 + 8 floats
 constexpr int QS = 288;     // int8 row stride, C = 256
 constexpr int QS5 = 544;    // int8 row stride, C = 512
 constexpr int NTD0 = 512;
-constexpr int FB_FLOATS = 3 * SD0 * FS;
+constexpr int MTD0 = (2 * SD0) / 16;
+constexpr int FB_FLOATS = 3 * 16 * FS;      // sized for a full 16-row M tile (rows >= S are padding)
 constexpr int XF_FLOATS = 2 * SD0 * CS2;
-constexpr int QB_BYTES = 2 * SD0 * QS;
+constexpr int H8_BYTES = 16 * QS5;
+constexpr int QB_BYTES = 2 * 16 * QS;       // 2 M tiles of 16 rows: the up1 GEMM reads [t][16 rows]
+static_assert(SD0 == 8 || SD0 == 16, "tile sizes the index math below supports");
 }  // namespace
 
-size_t dec_s0_lds_bytes() { return (size_t)(FB_FLOATS + XF_FLOATS) * 4 + SD0 * QS5 + 4 * QB_BYTES + 2 * SD0 * 4; }
+size_t dec_s0_lds_bytes() { return (size_t)(FB_FLOATS + XF_FLOATS) * 4 + H8_BYTES + 4 * QB_BYTES + 2 * SD0 * 4; }
 int dec_s0_streams_per_wg() { return SD0; }
 
-__global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __restrict__ feats,
+__global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                        const int32_t* __restrict__ ids, int B,
                                                        uint8_t* __restrict__ state, float* __restrict__ out0) {
+  const DecS0P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* FB = smem;                                   // [3][16][72]: two history rows + new features
-  float* XF = FB + FB_FLOATS;                         // [2][16][264]: x164 (float skip of resblock 0)
+  float* FB = smem;                                   // [3][16][72]: two history rows + new features (rows s < S used)
+  float* XF = FB + FB_FLOATS;                         // [2][S][264]: x164 (float skip of resblock 0)
   int8_t* H8 = reinterpret_cast<int8_t*>(XF + XF_FLOATS);  // [16][544]
-  int8_t* QX = H8 + SD0 * QS5;
+  int8_t* QX = H8 + H8_BYTES;
   int8_t* QA = QX + QB_BYTES;
   int8_t* QD = QA + QB_BYTES;
   int8_t* QP = QD + QB_BYTES;
@@ -58,16 +63,16 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
 
-  // ---- feature window [f-2, f-1, f] (history ring R=2, T=1) ----------------------------------------
+  // ---- feature window [f-2, f-1, f] (history ring R=2, T=1); GEMM rows = streams, 16-row tile ----------
   for (int idx = tid; idx < SD0 * 64; idx += NTD0) {
     int c = idx & 63, s = idx >> 6;
     int b = min(b0 + s, B - 1);
-    FB[(2 * SD0 + s) * FS + at16(c)] = feats[(size_t)b * 64 + c];
+    FB[(2 * 16 + s) * FS + at16(c)] = feats[(size_t)b * 64 + c];
   }
   for (int idx = tid; idx < 2 * SD0 * 16; idx += NTD0) {
-    int p4 = idx & 15, s = (idx >> 4) & 15, j = idx >> 8;
+    int p4 = idx & 15, s = (idx >> 4) & (SD0 - 1), j = (idx >> 4) / SD0;
     int slot = (sphase[s] + j) & 1;
-    *reinterpret_cast<f32x4*>(&FB[(j * SD0 + s) * FS + p4 * 4]) =
+    *reinterpret_cast<f32x4*>(&FB[(j * 16 + s) * FS + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4);
   }
   __syncthreads();
@@ -76,12 +81,12 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
     int slot = sphase[s] & 1;
     if (cx.valid(s))
       *reinterpret_cast<f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4) =
-          *reinterpret_cast<const f32x4*>(&FB[(2 * SD0 + s) * FS + p4 * 4]);
+          *reinterpret_cast<const f32x4*>(&FB[(2 * 16 + s) * FS + p4 * 4]);
   }
   {  // conv k3 g4: per group [16 rows] x K=48 x N=128; LeakyReLU; QUANTIZE -> H8
     f32x4 acc[1][4];
     const int g = wave >> 1;
-    auto aoff = [&](int i, int c) { return (c * SD0 + m) * FS + g * 16 + q * 4; };
+    auto aoff = [&](int i, int c) { return (c * 16 + m) * FS + g * 16 + q * 4; };
     gemm_f32<1, 4, 3>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, acc);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -99,9 +104,6 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
     const TconvQ U = P.up0[g];
     auto aoff = [&](int i, int c) { return m * QS5 + g * 128 + c * 64 + q * 16; };
     gemm_i8<1, 8, 2>(H8, aoff, U.w + ((wave & 1) * 8) * 2 * 64, acc);
-    float* stp[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) stp[e] = reinterpret_cast<float*>(cx.sbase(q * 4 + e) + st::D_UP0 + g * 512);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ct = (wave & 1) * 2 + (j >> 2), tap = j & 3;
@@ -112,14 +114,16 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int s = q * 4 + e;
+        if (s >= SD0) continue;
+        float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP0 + g * 512);
         int c8 = clamp8(requant(acc[0][j][e] + zf + bias, U.M, U.sh, mode) + U.zout);
         float y = dequantize_f(c8, P.up0_dq[g].s, P.up0_dq[g].z);
         if (tap < 2) {
-          y = y + stp[e][tap * 64 + co];
+          y = y + stp[tap * 64 + co];
           XF[(tap * SD0 + s) * CS2 + pc] = y;
         } else {
           y = y + 0.f;
-          if (cx.valid(s)) stp[e][(tap - 2) * 64 + co] = y - sub;
+          if (cx.valid(s)) stp[(tap - 2) * 64 + co] = y - sub;
         }
       }
     }
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
   {
     const DwQ dq = P.dwq[0];
     for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
-      int w4 = idx & 63, s = (idx >> 6) & 15, t = idx >> 10;
+      int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
       int acc[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -157,21 +161,21 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
     }
     __syncthreads();
     for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
-      int w4 = idx & 63, s = (idx >> 6) & 15, t = idx >> 10;
+      int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
       if (cx.valid(s))
         *reinterpret_cast<int*>(cx.sbase(s) + st::D_R0_0 + t * 256 + w4 * 4) =
             *reinterpret_cast<const int*>(&QA[(t * SD0 + s) * QS + w4 * 4]);
     }
     {
-      i32x4 acc[2][2];
+      i32x4 acc[MTD0][2];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
-      gemm_i8<2, 2, 4>(QD, aoff, P.pwq[0].w + (wave * 2) * 4 * 64, acc);
+      gemm_i8<MTD0, 2, 4>(QD, aoff, P.pwq[0].w + (wave * 2) * 4 * 64, acc);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int n = (wave * 2 + j) * 16 + (lane & 15);
         int bias = P.pwq[0].b[n], M = P.pwq[0].M[n], sh = P.pwq[0].sh[n];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MTD0; ++i)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.pwq[0].zout);
@@ -181,17 +185,17 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
     }
     __syncthreads();
     {
-      i32x4 acc[2][2];
+      i32x4 acc[MTD0][2];
       const int g = wave >> 1;
       auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 64 + q * 16; };
-      gemm_i8<2, 2, 1>(QP, aoff, P.cvq[0].w + (wave * 2) * 64, acc);
+      gemm_i8<MTD0, 2, 1>(QP, aoff, P.cvq[0].w + (wave * 2) * 64, acc);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int n = (wave * 2 + j) * 16 + (lane & 15);
         int bias = P.cvq[0].b[n], M = P.cvq[0].M[n], sh = P.cvq[0].sh[n];
         int pc = at16(n);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MTD0; ++i)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             int row = i * 16 + q * 4 + e;
@@ -203,12 +207,13 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
     }
     __syncthreads();
   }
-  resblock_q256(QX, QA, QD, QP, cx, 3, st::D_R0_1, P.lr[1], P.lr[2], P.dwq[1], P.pwq[1], P.cvq[1], P.add[0], mode);
-  resblock_q256(QX, QA, QD, QP, cx, 9, st::D_R0_2, P.lr[3], P.lr[4], P.dwq[2], P.pwq[2], P.cvq[2], P.add[1], mode);
+  resblock_q256<SD0>(QX, QA, QD, QP, cx, 3, st::D_R0_1, P.lr[1], P.lr[2], P.dwq[1], P.pwq[1], P.cvq[1], P.add[0], mode);
+  resblock_q256<SD0>(QX, QA, QD, QP, cx, 9, st::D_R0_2, P.lr[3], P.lr[4], P.dwq[2], P.pwq[2], P.cvq[2], P.add[1], mode);
+  // a = int8 LeakyReLU(X3), laid out for the up1 GEMM as [t][16 rows][QS] (rows s >= S are padding)
   for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
-    int w4 = idx & 63, rs = idx >> 6;
-    int w = *reinterpret_cast<const int*>(&QX[rs * QS + w4 * 4]);
-    *reinterpret_cast<int*>(&QA[rs * QS + w4 * 4]) =
+    int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
+    int w = *reinterpret_cast<const int*>(&QX[(t * SD0 + s) * QS + w4 * 4]);
+    *reinterpret_cast<int*>(&QA[(t * 16 + s) * QS + w4 * 4]) =
         pack8(lrelu_q(sx8(w, 0), P.lr[5]), lrelu_q(sx8(w, 1), P.lr[5]), lrelu_q(sx8(w, 2), P.lr[5]),
               lrelu_q(sx8(w, 3), P.lr[5]));
   }
@@ -229,6 +234,7 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(DecS0P P, const float* __r
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = q * 4 + e;
+      if (s >= SD0) continue;
       float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP1 + g * 512);
       int o[6];
       o[0] = acc[0][0][e] + zf[0];
@@ -269,9 +275,10 @@ constexpr int NTD1 = 512;
 size_t dec_s1_lds_bytes() { return (size_t)(7 * SD1 * CS1 + 4 * SD1 * CS1) * 4 + 2 * SD1 * 4; }
 int dec_s1_streams_per_wg() { return SD1; }
 
-__global__ __launch_bounds__(NTD1) void dec_s1_kernel(DecS1P P, const float* __restrict__ in0,
+__global__ __launch_bounds__(NTD1) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
                                                        const int32_t* __restrict__ ids, int B,
                                                        uint8_t* __restrict__ state, float* __restrict__ out1) {
+  const DecS1P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [7][16][136]: row 0 zeros, rows 1-4 X[t], rows 5-6 zeros
   float* DB = XB + 7 * SD1 * CS1;       // [4][16][136]; later: old tconv tail [5][16][72]
@@ -359,9 +366,10 @@ constexpr int NTD2 = 512;
 size_t dec_s2_lds_bytes() { return (size_t)(27 * SD2 * CS0 + 20 * SD2 * CS0) * 4 + 64; }
 int dec_s2_streams_per_wg() { return SD2; }
 
-__global__ __launch_bounds__(NTD2) void dec_s2_kernel(DecS2P P, const float* __restrict__ in1,
+__global__ __launch_bounds__(NTD2) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                        const int32_t* __restrict__ ids, int B,
                                                        uint8_t* __restrict__ state, int16_t* __restrict__ pcm) {
+  const DecS2P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [27][8][72]: rows 0-2 zeros, rows 3-22 X[t], rows 23-26 zeros
   float* DB = XB + 27 * SD2 * CS0;      // [20][8][72]; later: old overlap tail [8][48]

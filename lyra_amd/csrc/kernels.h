@@ -18,9 +18,9 @@ struct EncS2P {
   int mode;
 };
 
-__global__ void enc_s0_kernel(EncS0P P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* out0);
-__global__ void enc_s1_kernel(EncS1P P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
-__global__ void enc_s2_kernel(EncS2P P, const float* in1, const int32_t* ids, int B, uint8_t* state, float* feats,
+__global__ void enc_s0_kernel(const EncS0P* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* out0);
+__global__ void enc_s1_kernel(const EncS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
+__global__ void enc_s2_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, float* feats,
                               float* codes_dbg);
 size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg();
 size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg();
@@ -44,24 +44,24 @@ struct DecS0P {
 struct DecS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; const float* up_sub; };
 struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; };
 
-__global__ void dec_s0_kernel(DecS0P P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0);
-__global__ void dec_s1_kernel(DecS1P P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
-__global__ void dec_s2_kernel(DecS2P P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm);
+__global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0);
+__global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
+__global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm);
 size_t dec_s0_lds_bytes(); int dec_s0_streams_per_wg();
 size_t dec_s1_lds_bytes(); int dec_s1_streams_per_wg();
 size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg();
 
 // ---- RVQ / packets / log-mel / state ---------------------------------------------------------------
-// cbt: codebooks transposed [46][64][16]; cb: natural [46][16][64]
-__global__ void rvq_encode_kernel(const float* cbt, const float* feats, int B, int num_stages, int32_t* indices,
+// cb: codebooks, natural layout [46][16][64]
+__global__ void rvq_encode_kernel(const float* cb, const float* feats, int B, int num_stages, int32_t* indices,
                                   uint8_t* packets);
 __global__ void rvq_decode_kernel(const float* cb, const int32_t* indices, const uint8_t* packets, int num_stages,
                                   int B, float* feats);
 struct MelP { const double* hann; const double* tw_re; const double* tw_im; const int* band; const double* w;
               int start, end; };
-__global__ void logmel_kernel(MelP P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* mel);
+__global__ void logmel_kernel(const MelP* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* mel);
 size_t logmel_lds_bytes();
 struct ResetP { int8_t e_r2_1, e_r2_2, e_d2, e_bott, d_r0_0, d_r0_1, d_r0_2; };
-__global__ void reset_kernel(ResetP P, const int32_t* ids, int n, int all, uint8_t* state);
+__global__ void reset_kernel(const ResetP* P, const int32_t* ids, int n, int all, uint8_t* state);
 
 }  // namespace lyra

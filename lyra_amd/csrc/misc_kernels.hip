@@ -10,15 +10,22 @@ namespace lyra {
 // squared-distance sum in the oracle's order (separate multiply and add, d ascending), then a
 // 16-lane shuffle argmin with lowest-index tie break (ARG_MIN = first minimum).  The residual lives
 // in registers, replicated across the 16 lanes, and is updated with the graph's three fp32 ops
-// r - (r + (q - r)).  4 frames per wavefront, 16 per workgroup.
+// r - (r + (q - r)).  4 frames per wavefront, 16 per workgroup.  The 4 KB codebook of the current
+// stage sits in LDS (rows padded to 68 floats: conflict-free ds_read_b128 across the 16 code lanes),
+// double-buffered: the next stage's rows are fetched from L2 while this stage computes.
 // =============================================================================================
-__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ cbt,
+__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ cb,
                                                           const float* __restrict__ feats, int B, int num_stages,
                                                           int32_t* __restrict__ indices,
                                                           uint8_t* __restrict__ packets) {
-  const int j = threadIdx.x & 15;
-  const int frame = blockIdx.x * 16 + (threadIdx.x >> 4);
+  __shared__ __attribute__((aligned(16))) float cbs[2][16 * 68];
+  const int tid = threadIdx.x;
+  const int j = tid & 15;
+  const int frame = blockIdx.x * 16 + (tid >> 4);
   const int f = min(frame, B - 1);
+  const int ldrow = tid >> 4, ldc4 = tid & 15;  // this thread's float4 of a stage's [16][64] codebook
+  *reinterpret_cast<f32x4*>(&cbs[0][ldrow * 68 + ldc4 * 4]) =
+      *reinterpret_cast<const f32x4*>(&cb[(size_t)ldrow * 64 + ldc4 * 4]);
   float r[64];
 #pragma unroll
   for (int d4 = 0; d4 < 16; ++d4) {
@@ -29,13 +36,21 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
   int cur = 0;
 #pragma unroll 1
   for (int k = 0; k < num_stages; ++k) {
-    const float* ct = cbt + (size_t)k * 64 * 16;
+    __syncthreads();  // stage k rows visible; everyone is done with the buffer stage k+1 will land in
+    f32x4 nxt = {0.f, 0.f, 0.f, 0.f};
+    if (k + 1 < num_stages)
+      nxt = *reinterpret_cast<const f32x4*>(&cb[((size_t)(k + 1) * 16 + ldrow) * 64 + ldc4 * 4]);
+    const float* c = cbs[k & 1];
     float sum = 0.f;
 #pragma unroll
-    for (int d = 0; d < 64; ++d) {
-      float df = r[d] - ct[d * 16 + j];
-      float sq = df * df;
-      sum = sum + sq;
+    for (int d4 = 0; d4 < 16; ++d4) {
+      f32x4 cv = *reinterpret_cast<const f32x4*>(&c[j * 68 + d4 * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float df = r[d4 * 4 + e] - cv[e];
+        float sq = df * df;
+        sum = sum + sq;
+      }
     }
     int best = j;
     float bd = sum;
@@ -46,12 +61,16 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
       if (od < bd || (od == bd && oi < best)) { bd = od; best = oi; }
     }
 #pragma unroll
-    for (int d = 0; d < 64; ++d) {
-      float qv = ct[d * 16 + best];
-      float t1 = qv - r[d];
-      float t2 = r[d] + t1;
-      r[d] = r[d] - t2;
+    for (int d4 = 0; d4 < 16; ++d4) {
+      f32x4 qv = *reinterpret_cast<const f32x4*>(&c[best * 68 + d4 * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t1 = qv[e] - r[d4 * 4 + e];
+        float t2 = r[d4 * 4 + e] + t1;
+        r[d4 * 4 + e] = r[d4 * 4 + e] - t2;
+      }
     }
+    if (k + 1 < num_stages) *reinterpret_cast<f32x4*>(&cbs[(k + 1) & 1][ldrow * 68 + ldc4 * 4]) = nxt;
     if (j == 0 && frame < B) {
       if (indices) indices[(size_t)frame * 46 + k] = best;
       if (packets) {
@@ -101,9 +120,10 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const float* __restrict
 // =============================================================================================
 size_t logmel_lds_bytes() { return (size_t)(1024 * 2 + 520) * 8; }
 
-__global__ __launch_bounds__(256) void logmel_kernel(MelP P, const int16_t* __restrict__ pcm,
+__global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, float* __restrict__ mel) {
+  const MelP& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* re = dsm;
   double* im = dsm + 1024;
@@ -154,8 +174,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(MelP P, const int16_t* __re
 // state reset: zeros everywhere (the graphs' CALL_ONCE init subgraph assigns zero constants), int8
 // histories hold the zero point of their tensor (== quantize(0.0f)).
 // =============================================================================================
-__global__ __launch_bounds__(256) void reset_kernel(ResetP P, const int32_t* __restrict__ ids, int n, int all,
+__global__ __launch_bounds__(256) void reset_kernel(const ResetP* __restrict__ Pp, const int32_t* __restrict__ ids, int n, int all,
                                                      uint8_t* __restrict__ state) {
+  const ResetP& P = *Pp;
   const int sidx = blockIdx.x;
   if (sidx >= n) return;
   const int id = all ? sidx : ids[sidx];

@@ -40,6 +40,11 @@ struct Model {
   const float* cbt = nullptr;  // [46][64][16]
   MelP mel;
   ResetP reset;
+  // device-resident copies of the parameter blocks above (what the kernels actually read)
+  EncS0P* d_enc0 = nullptr; EncS1P* d_enc1 = nullptr; EncS2P* d_enc2 = nullptr;
+  DecS0P* d_dec0 = nullptr; DecS1P* d_dec1 = nullptr; DecS2P* d_dec2 = nullptr;
+  MelP* d_mel = nullptr; ResetP* d_reset = nullptr;
+  uint8_t* d_params = nullptr;
   uint8_t* d_arena = nullptr;
   size_t arena_bytes = 0;
 };

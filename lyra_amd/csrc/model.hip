@@ -423,11 +423,30 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   }
   M->arena_bytes = bytes.size();
   for (auto& fx : B.fixups) *reinterpret_cast<const uint8_t**>(fx.first) = M->d_arena + fx.second;
+  // parameter blocks -> device memory (kernels read them through a pointer: scalar loads from L2, never from a
+  // host-resident kernarg segment)
+  {
+    std::vector<uint8_t> pb;
+    auto add = [&](const void* p, size_t n) { size_t off = (pb.size() + 255) / 256 * 256; pb.resize(off + n); memcpy(pb.data() + off, p, n); return off; };
+    size_t o0 = add(&M->enc0, sizeof M->enc0), o1 = add(&M->enc1, sizeof M->enc1), o2 = add(&M->enc2, sizeof M->enc2);
+    size_t o3 = add(&M->dec0, sizeof M->dec0), o4 = add(&M->dec1, sizeof M->dec1), o5 = add(&M->dec2, sizeof M->dec2);
+    size_t o6 = add(&M->mel, sizeof M->mel), o7 = add(&M->reset, sizeof M->reset);
+    if (hipMalloc((void**)&M->d_params, pb.size()) != hipSuccess ||
+        hipMemcpy(M->d_params, pb.data(), pb.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      *err = "uploading parameter blocks failed";
+      return false;
+    }
+    M->d_enc0 = (EncS0P*)(M->d_params + o0); M->d_enc1 = (EncS1P*)(M->d_params + o1); M->d_enc2 = (EncS2P*)(M->d_params + o2);
+    M->d_dec0 = (DecS0P*)(M->d_params + o3); M->d_dec1 = (DecS1P*)(M->d_params + o4); M->d_dec2 = (DecS2P*)(M->d_params + o5);
+    M->d_mel = (MelP*)(M->d_params + o6); M->d_reset = (ResetP*)(M->d_params + o7);
+  }
   return true;
 }
 
 void free_model(Model* m) {
   if (m->d_arena) (void)hipFree(m->d_arena);
+  if (m->d_params) (void)hipFree(m->d_params);
+  m->d_params = nullptr;
   m->d_arena = nullptr;
 }
 

@@ -167,16 +167,18 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
 }
 
 // ---- int8 residual block at 256 channels x 2 rows, 16 streams per workgroup, 512 threads -----------
-// QX residual stream, QA/QD/QP scratch, all [2][16][288] int8.  Ring history of R2 = 2*d rows, T = 2.
+// QX residual stream, QA/QD/QP scratch, all [2][S][288] int8.  Ring history of R2 = 2*d rows, T = 2.
 __device__ __forceinline__ int sx8(int w, int i) { return (int)(int8_t)(w >> (8 * i)); }
 __device__ __forceinline__ int pack8(int a, int b, int c, int d) {
   return (a & 255) | ((b & 255) << 8) | ((c & 255) << 16) | ((d & 255) << 24);
 }
 
+template <int S>
 __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD, int8_t* QP, const TileCtx& cx,
                                               int d, int off, const LreluQ& la, const LreluQ& lm, const DwQ& dq,
                                               const ConvQ& pw, const ConvQ& cv, const AddQ& add, int mode) {
-  constexpr int S = 16, QS = 288, NT = 512;
+  // rows = (t, s) -> t * S + s, T = 2; S = 16: two M tiles, S = 8: one.
+  constexpr int QS = 288, NT = 512, MT = (2 * S) / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int R2 = 2 * d;
@@ -188,7 +190,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * S * 64; idx += NT) {
-    int w4 = idx & 63, s = (idx >> 6) & 15, t = idx >> 10;
+    int w4 = idx & 63, s = (idx >> 6) & (S - 1), t = (idx >> 6) / S;
     int base = (cx.sphase[s] * 2) % R2;
     int acc[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -216,7 +218,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * S * 64; idx += NT) {
-    int w4 = idx & 63, s = (idx >> 6) & 15, t = idx >> 10;
+    int w4 = idx & 63, s = (idx >> 6) & (S - 1), t = (idx >> 6) / S;
     int row = (cx.sphase[s] * 2) % R2 + t;
     row = row >= R2 ? row - R2 : row;
     if (cx.valid(s))
@@ -224,15 +226,15 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
           *reinterpret_cast<const int*>(&QA[(t * S + s) * QS + w4 * 4]);
   }
   {
-    i32x4 acc[2][2];
+    i32x4 acc[MT][2];
     auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
-    gemm_i8<2, 2, 4>(QD, aoff, pw.w + (wave * 2) * 4 * 64, acc);
+    gemm_i8<MT, 2, 4>(QD, aoff, pw.w + (wave * 2) * 4 * 64, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
       int bias = pw.b[n], M = pw.M[n], sh = pw.sh[n];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + pw.zout);
@@ -242,16 +244,16 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
   }
   __syncthreads();
   {
-    i32x4 acc[2][2];
+    i32x4 acc[MT][2];
     const int g = wave >> 1;
     auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 64 + q * 16; };
-    gemm_i8<2, 2, 1>(QP, aoff, cv.w + (wave * 2) * 64, acc);
+    gemm_i8<MT, 2, 1>(QP, aoff, cv.w + (wave * 2) * 64, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
       int bias = cv.b[n], M = cv.M[n], sh = cv.sh[n];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int row = i * 16 + q * 4 + e;
