@@ -125,10 +125,11 @@ int lyra_hip_synchronize(lyra_hip_ctx* ctx);
 size_t lyra_hip_state_bytes_per_stream(void);
 int lyra_hip_max_streams(const lyra_hip_ctx* ctx);
 
-/* Measurement hook (bench.py): when enabled, every kernel launch is bracketed by HIP events recorded on the
- * context's stream; profile_read() synchronises, returns per-kernel total milliseconds and launch counts
- * since the previous read (arrays of lyra_hip_profile_kernel_count() entries) and clears them. */
-int lyra_hip_profile_enable(lyra_hip_ctx* ctx, int on);
+/* Measurement hook (bench.py): launches of every kernel whose bit is set in `kernel_mask` (bit i = kernel i of
+ * lyra_hip_profile_kernel_name) are bracketed by HIP events recorded on the context's stream; 0 disables.
+ * profile_read() synchronises, returns per-kernel total milliseconds and launch counts since the previous read
+ * (arrays of lyra_hip_profile_kernel_count() entries) and clears them. */
+int lyra_hip_profile_enable(lyra_hip_ctx* ctx, unsigned kernel_mask);
 int lyra_hip_profile_kernel_count(void);
 const char* lyra_hip_profile_kernel_name(int i);
 int lyra_hip_profile_read(lyra_hip_ctx* ctx, double* total_ms, long* launches);

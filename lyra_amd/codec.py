@@ -34,7 +34,8 @@ def packet_size(num_bits):
 
 
 def library_path():
-    return os.path.join(HERE, "liblyra_hip.so")
+    # LYRA_HIP_LIB: developer override used to A/B kernel variants on the GPU box
+    return os.environ.get("LYRA_HIP_LIB") or os.path.join(HERE, "liblyra_hip.so")
 
 
 def default_model_dir():
@@ -84,7 +85,7 @@ def _load():
     L.lyra_hip_synchronize.argtypes = [vp]
     L.lyra_hip_state_bytes_per_stream.restype = C.c_size_t
     L.lyra_hip_max_streams.argtypes = [vp]
-    L.lyra_hip_profile_enable.argtypes = [vp, ci]
+    L.lyra_hip_profile_enable.argtypes = [vp, C.c_uint]
     L.lyra_hip_profile_kernel_name.restype = cp
     L.lyra_hip_profile_kernel_name.argtypes = [ci]
     L.lyra_hip_profile_read.argtypes = [vp, vp, vp]
@@ -219,8 +220,17 @@ class LyraHip:
         self._chk(self.L.lyra_hip_decode(self.h, ids.ctypes.data, B, packets.ctypes.data, num_bits, out.ctypes.data))
         return out
 
-    def profile_enable(self, on=True):
-        self._chk(self.L.lyra_hip_profile_enable(self.h, int(on)))
+    def profile_kernel_names(self):
+        n = self.L.lyra_hip_profile_kernel_count()
+        return [self.L.lyra_hip_profile_kernel_name(i).decode() for i in range(n)]
+
+    def profile_enable(self, on=True, only=None):
+        """Bracket kernel launches with HIP events: all kernels, or only the named one."""
+        mask = 0
+        if on:
+            names = self.profile_kernel_names()
+            mask = (1 << names.index(only)) if only else (1 << len(names)) - 1
+        self._chk(self.L.lyra_hip_profile_enable(self.h, mask))
 
     def profile_read(self):
         """{kernel name: (total_ms, launches)} since the last read (HIP events on the context's stream)."""

@@ -43,7 +43,7 @@ struct lyra_hip_ctx {
   float* d_mel = nullptr;    // [cap][160]
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on this context's stream (bench.py roofline leg)
-  bool profiling = false;
+  unsigned profiling = 0;  // bit i set: bracket launches of kernel i with HIP events
   struct Span { int kid; hipEvent_t a, b; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> event_pool;
@@ -144,7 +144,7 @@ hipEvent_t take_event(lyra_hip_ctx* c) {
 struct ProfScope {
   lyra_hip_ctx* c; int kid; hipEvent_t a = nullptr;
   ProfScope(lyra_hip_ctx* c_, int kid_) : c(c_), kid(kid_) {
-    if (c->profiling) { a = take_event(c); (void)hipEventRecord(a, c->stream); }
+    if (c->profiling & (1u << kid)) { a = take_event(c); (void)hipEventRecord(a, c->stream); }
   }
   ~ProfScope() {
     if (a) { hipEvent_t b = take_event(c); (void)hipEventRecord(b, c->stream); c->spans.push_back({kid, a, b}); }
@@ -155,10 +155,10 @@ struct ProfScope {
 int launch_extract(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
   const Model& M = c->model;
   { ProfScope ps(c, K_ENC_S0);
-  hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(512), enc_s0_lds_bytes(), c->stream,
+  hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), c->stream,
                      M.d_enc0, d_pcm, d_ids, B, c->d_state, c->d_e0); }
   { ProfScope ps(c, K_ENC_S1);
-  hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(512), enc_s1_lds_bytes(), c->stream,
+  hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(256), enc_s1_lds_bytes(), c->stream,
                      M.d_enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1); }
   { ProfScope ps(c, K_ENC_S2);
   hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), c->stream,
@@ -191,10 +191,10 @@ int launch_generate(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d
   hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), c->stream,
                      M.d_dec0, d_feat, d_ids, B, c->d_state, c->d_d0); }
   { ProfScope ps(c, K_DEC_S1);
-  hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(512), dec_s1_lds_bytes(), c->stream,
+  hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(256), dec_s1_lds_bytes(), c->stream,
                      M.d_dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1); }
   { ProfScope ps(c, K_DEC_S2);
-  hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(512), dec_s2_lds_bytes(), c->stream,
+  hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), c->stream,
                      M.d_dec2, c->d_d1, d_ids, B, c->d_state, d_pcm); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
@@ -473,9 +473,9 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
   return 0;
 }
 
-int lyra_hip_profile_enable(lyra_hip_ctx* c, int on) {
+int lyra_hip_profile_enable(lyra_hip_ctx* c, unsigned kernel_mask) {
   if (!c) return LYRA_HIP_EINVAL;
-  c->profiling = on != 0;
+  c->profiling = kernel_mask;
   return 0;
 }
 int lyra_hip_profile_kernel_count(void) { return K_COUNT; }

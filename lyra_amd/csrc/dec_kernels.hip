@@ -2,16 +2,16 @@
 // RunModel, lyra/lyra_gan_model.cc:53-64, incl. the float->int16 conversion of dsp_utils.h:54-88) as three
 // stream-tiled gfx950 kernels.
 //
-//   dec_s0  S=16  features -> conv k3 g4 (fp32) -> int8: 4x tconv k4/s2, 3 resblocks @256ch x 2 rows,
-//                 2x tconv k4/s2 -> [4][128] fp32
-//   dec_s1  S=16  3 fp32 resblocks @128ch x 4 rows -> tconv k10/s5 -> [20][64]
-//   dec_s2  S=8   3 fp32 resblocks @64ch x 20 rows -> tconv k64/s16 -> 320 samples -> int16 PCM
+//   dec_s0  8 streams/WG  features -> conv k3 g4 (fp32) -> int8: 4x tconv k4/s2, 3 resblocks @256ch x 2 rows,
+//                         2x tconv k4/s2 -> [4][128] fp32
+//   dec_s1  8 streams/WG  3 fp32 resblocks @128ch x 4 rows -> tconv k10/s5 -> [20][64]
+//   dec_s2  4 streams/WG  3 fp32 resblocks @64ch x 20 rows -> tconv k64/s16 -> 320 samples -> int16 PCM
 //
 // Transposed convs run in polyphase form: output block b (s rows) = [x[b-taps+1] .. x[b]] (K = taps*Cin,
 // oldest input first) times W[K][s*Cout] -- per output element exactly the oracle's chain (input position
 // ascending, channel ascending).  The tail rows that belong to the next frame are carried in the state with
 // the bias removed, as the graph does.
-#include "resblocks.h"
+#include "resblock_q.h"
 
 namespace lyra {
 
@@ -267,21 +267,22 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
 // stage 1
 // =============================================================================================
 namespace {
-constexpr int SD1 = 16;
+constexpr int SD1 = 8;
 constexpr int CS1 = 136;
-constexpr int NTD1 = 512;
+constexpr int NTD1 = 256;
+constexpr int MTD1 = (6 * SD1) / 16;   // M tiles of the [6 blocks][S] polyphase GEMM (block 5 is padding)
 }  // namespace
 
 size_t dec_s1_lds_bytes() { return (size_t)(7 * SD1 * CS1 + 4 * SD1 * CS1) * 4 + 2 * SD1 * 4; }
 int dec_s1_streams_per_wg() { return SD1; }
 
-__global__ __launch_bounds__(NTD1) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
-                                                       const int32_t* __restrict__ ids, int B,
-                                                       uint8_t* __restrict__ state, float* __restrict__ out1) {
+__global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
+                                                          const int32_t* __restrict__ ids, int B,
+                                                          uint8_t* __restrict__ state, float* __restrict__ out1) {
   const DecS1P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XB = smem;                     // [7][16][136]: row 0 zeros, rows 1-4 X[t], rows 5-6 zeros
-  float* DB = XB + 7 * SD1 * CS1;       // [4][16][136]; later: old tconv tail [5][16][72]
+  float* XB = smem;                     // [7][S][136]: row 0 zeros, rows 1-4 X[t], rows 5-6 zeros
+  float* DB = XB + 7 * SD1 * CS1;       // [4][S][136]; later: old tconv tail [5][S][72]
   int* sids = reinterpret_cast<int*>(DB + 4 * SD1 * CS1);
   int* sphase = sids + SD1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -295,53 +296,51 @@ __global__ __launch_bounds__(NTD1) void dec_s1_kernel(const DecS1P* __restrict__
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
-    int p4 = idx & 31, s = (idx >> 5) & 15, t = idx >> 9;
+    int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
     int b = min(b0 + s, B - 1);
     *reinterpret_cast<f32x4*>(&XB[((1 + t) * SD1 + s) * CS1 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
   }
   for (int idx = tid; idx < 3 * SD1 * 32; idx += NTD1) {
-    int p4 = idx & 31, s = (idx >> 5) & 15, j = idx >> 9;
+    int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), j = (idx >> 5) / SD1;
     int row = j == 0 ? 0 : 4 + j;
     *reinterpret_cast<f32x4*>(&XB[(row * SD1 + s) * CS1 + p4 * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
-  resblocks128(XB + SD1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2);
+  resblocks128<SD1, NTD1>(XB + SD1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2);
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, rs = idx >> 5;
     f32x4* x = reinterpret_cast<f32x4*>(&XB[(SD1 + rs) * CS1 + p4 * 4]);
     *x = lrelu4(*x);
   }
-  float* SB = DB;  // old carried tail [5][16][72]
+  float* SB = DB;  // old carried tail [5][S][72]
   for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {
-    int p4 = idx & 15, s = (idx >> 4) & 15, j = idx >> 8;
+    int p4 = idx & 15, s = (idx >> 4) & (SD1 - 1), j = (idx >> 4) / SD1;
     *reinterpret_cast<f32x4*>(&SB[(j * SD1 + s) * 72 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
   }
   __syncthreads();
-  {  // tconv k10/s5, polyphase: blocks b = 0..4 (+1 dummy), K = [x[b-1] | x[b]] = 256, N = 5 x 64
-    f32x4 acc[3][5];
-    const int wn = wave & 3, wm = wave >> 2;
+  {  // tconv k10/s5, polyphase: blocks b = 0..4 (+1 of padding), rows (b, s); K = [x[b-1] | x[b]] = 256; N = 5 x 64
+    f32x4 acc[MTD1][5];
     auto aoff = [&](int i, int c) {
-      int b = 3 * wm + i;
+      int R = i * 16 + m, b = R / SD1, s = R & (SD1 - 1);
       int row = (c < 8 ? b - 1 : b) + 1;
-      return (row * SD1 + m) * CS1 + (c & 7) * 16 + q * 4;
+      return (row * SD1 + s) * CS1 + (c & 7) * 16 + q * 4;
     };
-    gemm_f32<3, 5, 16>(XB, aoff, P.up.w + (wn * 5) * 16 * 64, acc);
+    gemm_f32<MTD1, 5, 16>(XB, aoff, P.up.w + (wave * 5) * 16 * 64, acc);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const int n = (wn * 5 + j) * 16 + (lane & 15);
+      const int n = (wave * 5 + j) * 16 + (lane & 15);
       const int jj = n >> 6, co = n & 63;
-      const float bias = P.up.b[co], sub = P.up_sub[co];
+      const float bias = as_global(P.up.b)[co], sub = as_global(P.up_sub)[co];
       const int pc = at16(co);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int b = 3 * wm + i;
-        if (b > 4) continue;
-        const int tau = 5 * b + jj;
+      for (int i = 0; i < MTD1; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          int s = q * 4 + e;
+          const int R = i * 16 + q * 4 + e, b = R / SD1, s = R & (SD1 - 1);
+          if (b > 4) continue;
+          const int tau = 5 * b + jj;
           float y = acc[i][j][e] + bias;
           y = y + (tau < 5 ? SB[(tau * SD1 + s) * 72 + co] : 0.f);
           if (cx.valid(s)) {
@@ -349,7 +348,6 @@ __global__ __launch_bounds__(NTD1) void dec_s1_kernel(const DecS1P* __restrict__
             else reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[(tau - 20) * 64 + co] = y - sub;
           }
         }
-      }
     }
   }
 }
@@ -358,22 +356,22 @@ __global__ __launch_bounds__(NTD1) void dec_s1_kernel(const DecS1P* __restrict__
 // stage 2
 // =============================================================================================
 namespace {
-constexpr int SD2 = 8;
+constexpr int SD2 = 4;
 constexpr int CS0 = 72;
-constexpr int NTD2 = 512;
+constexpr int NTD2 = 256;
 }  // namespace
 
-size_t dec_s2_lds_bytes() { return (size_t)(27 * SD2 * CS0 + 20 * SD2 * CS0) * 4 + 64; }
+size_t dec_s2_lds_bytes() { return (size_t)(27 * SD2 * CS0 + SD2 * 48) * 4 + 64; }
 int dec_s2_streams_per_wg() { return SD2; }
 
-__global__ __launch_bounds__(NTD2) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
-                                                       const int32_t* __restrict__ ids, int B,
-                                                       uint8_t* __restrict__ state, int16_t* __restrict__ pcm) {
+__global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
+                                                          const int32_t* __restrict__ ids, int B,
+                                                          uint8_t* __restrict__ state, int16_t* __restrict__ pcm) {
   const DecS2P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XB = smem;                     // [27][8][72]: rows 0-2 zeros, rows 3-22 X[t], rows 23-26 zeros
-  float* DB = XB + 27 * SD2 * CS0;      // [20][8][72]; later: old overlap tail [8][48]
-  int* sids = reinterpret_cast<int*>(DB + 20 * SD2 * CS0);
+  float* XB = smem;                     // [27][S][72]: rows 0-2 zeros, rows 3-22 activations, rows 23-26 zeros
+  float* SB = XB + 27 * SD2 * CS0;      // old overlap tail [S][48]
+  int* sids = reinterpret_cast<int*>(SB + SD2 * 48);
   int* sphase = sids + SD2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
@@ -385,47 +383,51 @@ __global__ __launch_bounds__(NTD2) void dec_s2_kernel(const DecS2P* __restrict__
   }
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
-  for (int idx = tid; idx < 20 * SD2 * 16; idx += NTD2) {
-    int p4 = idx & 15, s = (idx >> 4) & 7, t = idx >> 7;
-    int b = min(b0 + s, B - 1);
-    *reinterpret_cast<f32x4*>(&XB[((3 + t) * SD2 + s) * CS0 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(&in1[((size_t)b * 20 + t) * 64 + p4 * 4]);
-  }
+  const int wn = wave & 3, wm = wave >> 2;
+  const int pcol = at16(wn * 16 + (lane & 15));
+  f32x4 xr[5][1];  // residual stream in registers (MFMA C layout)
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / SD2, s = R & (SD2 - 1);
+      int b = min(b0 + s, B - 1);
+      xr[i][0][e] = in1[((size_t)b * 20 + t) * 64 + pcol];
+    }
   for (int idx = tid; idx < 7 * SD2 * 16; idx += NTD2) {
-    int p4 = idx & 15, s = (idx >> 4) & 7, j = idx >> 7;
+    int p4 = idx & 15, s = (idx >> 4) & (SD2 - 1), j = (idx >> 4) / SD2;
     int row = j < 3 ? j : 20 + j;
     *reinterpret_cast<f32x4*>(&XB[(row * SD2 + s) * CS0 + p4 * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  __syncthreads();
-  resblocks64(XB + 3 * SD2 * CS0, DB, cx, P.dw, P.pw, P.cv, st::D_R2_0, st::D_R2_1, st::D_R2_2);
-  for (int idx = tid; idx < 20 * SD2 * 16; idx += NTD2) {
-    int p4 = idx & 15, rs = idx >> 4;
-    f32x4* x = reinterpret_cast<f32x4*>(&XB[(3 * SD2 + rs) * CS0 + p4 * 4]);
-    *x = lrelu4(*x);
-  }
-  float* SB = DB;  // old overlap tail [8][48]
   for (int idx = tid; idx < SD2 * 48; idx += NTD2) {
     int s = idx / 48, i = idx - s * 48;
     SB[idx] = reinterpret_cast<const float*>(cx.sbase(s) + st::D_UP3)[i];
   }
+  resblocks64r<SD2, NTD2>(xr, XB + 3 * SD2 * CS0, cx, P.dw, P.pw, P.cv, st::D_R2_0, st::D_R2_1, st::D_R2_2);
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
   __syncthreads();
-  if (wave < 6) {  // tconv k64/s16, polyphase: blocks b = 0..22 (+1 dummy), K = 4 x 64, N = 16 phases
+  // tconv k64/s16, polyphase: blocks b = 0..22 (+1 of padding), rows (b, s); K = 4 x 64 (oldest input first);
+  // N = 16 phases.  24*S rows = 6 M tiles: waves 0..2 take two each.
+  if (wave < 3) {
     f32x4 acc[2][1];
     auto aoff = [&](int i, int c) {
-      int b = 2 * (2 * wave + i) + (m >> 3);
-      return ((b + (c >> 2)) * SD2 + (m & 7)) * CS0 + (c & 3) * 16 + q * 4;
+      int R = (2 * wave + i) * 16 + m, b = R / SD2, s = R & (SD2 - 1);
+      return ((b + (c >> 2)) * SD2 + s) * CS0 + (c & 3) * 16 + q * 4;
     };
     gemm_f32<2, 1, 16>(XB, aoff, P.up.w, acc);
     const int j = lane & 15;
-    const float bias = P.up.b[0];
+    const float bias = as_global(P.up.b)[0];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int rr = q * 4 + e;
-        int b = 2 * (2 * wave + i) + (rr >> 3), s = rr & 7;
+        const int R = (2 * wave + i) * 16 + q * 4 + e, b = R / SD2, s = R & (SD2 - 1);
         if (b > 22) continue;
-        int tau = 16 * b + j;
+        const int tau = 16 * b + j;
         float y = acc[i][0][e] + bias;
         y = y + (tau < 48 ? SB[s * 48 + tau] : 0.f);
         if (!cx.valid(s)) continue;

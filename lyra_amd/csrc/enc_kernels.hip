@@ -1,16 +1,21 @@
-// enc_kernels.hip -- SoundStream encoder (replaces soundstream_encoder.tflite as run by
-// SoundStreamEncoder::Extract, lyra/soundstream_encoder.cc:53-64) as three stream-tiled gfx950 kernels.
+// enc_kernels.hip -- SoundStream encoder stages 0 and 1 (replaces soundstream_encoder.tflite ops 15-93 as run
+// by SoundStreamEncoder::Extract, lyra/soundstream_encoder.cc:53-64).  Stage 2 is in enc_s2_kernel.hip.
 //
-//   enc_s0  S=8  streams/WG  PCM -> first conv k64/s16 -> 3 resblocks @64ch x 20 rows -> conv k10/s5   (fp32)
-//   enc_s1  S=16 streams/WG  3 resblocks @128ch x 4 rows (2nd conv g=2) -> conv k4/s2 g=2               (fp32)
-//   enc_s2  S=8  streams/WG  (enc_s2_kernel.hip) resblock @256 (fp32 dw+pw, then int8), 2 int8 resblocks,
-//                            int8 k4/s2 g4, int8 k3 g4 bottleneck -> 64 int8 codes -> features
+//   enc_s0  4 streams/WG  PCM -> first conv k64/s16 -> 3 resblocks @64ch x 20 rows -> conv k10/s5   (fp32)
+//   enc_s1  8 streams/WG  3 resblocks @128ch x 4 rows (2nd conv g=2) -> conv k4/s2 g=2               (fp32)
 //
-// Every fp32 dot product runs on v_mfma_f32_16x16x4_f32 in ascending-k order (== the oracle's fmaf chain),
-// int8 ones on v_mfma_i32_16x16x64_i8; everything between two GEMMs (LeakyReLU, depthwise dilated conv,
-// residual add, (de)quantisation, state update) is fused around them in LDS/registers.  Per stream and
-// step the only HBM traffic is: PCM in, state read/write, two small inter-stage activations, features out.
+// Every fp32 dot product runs on v_mfma_f32_16x16x4_f32 in ascending-k order (== the oracle's fmaf chain);
+// everything between two GEMMs (LeakyReLU, depthwise dilated conv, residual add, history update) is fused
+// around them in LDS/registers.  Tiles are small (256 threads, ~50 KB LDS) so three workgroups share a CU:
+// the MFMA phases of one overlap the VALU/LDS/HBM phases of the others.  Per stream and step the only HBM
+// traffic is PCM in, history read/write and one small inter-stage activation.
 #include "resblocks.h"
+
+#ifdef LYRA_TIMING
+extern "C" int lyra_hip_debug_timing(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_tdbg), sizeof(long long) * 128);
+}
+#endif
 
 namespace lyra {
 
@@ -18,130 +23,152 @@ namespace lyra {
 // stage 0
 // =============================================================================================
 namespace {
-constexpr int S0 = 8;      // streams per workgroup
+constexpr int S0 = 4;      // streams per workgroup
 constexpr int CS0 = 72;    // LDS row stride (64 + 8) floats
 constexpr int PBS = 376;   // PCM staging row stride (368 + 8) floats
-constexpr int NT0 = 512;   // threads
+constexpr int NT0 = 256;   // threads
+constexpr int NW0 = NT0 / 64;
 }  // namespace
 
-size_t enc_s0_lds_bytes() { return (size_t)(25 * S0 * CS0 + 20 * S0 * CS0) * 4 + 64; }
+size_t enc_s0_lds_bytes() { return (size_t)(25 * S0 * CS0) * 4 + 64; }
 int enc_s0_streams_per_wg() { return S0; }
 
-__global__ __launch_bounds__(NT0) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
-                                                      const int32_t* __restrict__ ids, int B,
-                                                      uint8_t* __restrict__ state, float* __restrict__ out0) {
+__global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
+                                                         const int32_t* __restrict__ ids, int B,
+                                                         uint8_t* __restrict__ state, float* __restrict__ out0) {
   const EncS0P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XB = smem;                     // [25][S0][CS0]: rows 0-4 strided-conv history, rows 5-24 X[t]
-  float* DB = XB + 25 * S0 * CS0;       // [20][S0][CS0]: depthwise out / pointwise out; first: PCM staging
-  int* sids = reinterpret_cast<int*>(DB + 20 * S0 * CS0);
+  float* XB = smem;                     // [25][S0][CS0]: rows 0-4 strided-conv history, rows 5-24 the one
+                                        // activation matrix of the residual blocks; first: PCM staging
+  int* sids = reinterpret_cast<int*>(XB + 25 * S0 * CS0);
+  static_assert(S0 * PBS <= 25 * S0 * CS0, "PCM staging fits");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * S0;
+  LYRA_TSTAMP(0);
   if (tid < S0) sids[tid] = ids[min(b0 + tid, B - 1)];
   __syncthreads();
   auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B; };
 
   // ---- A. window = [48 history samples | 320 new samples] / 32768, AT16 order ----------------
-  float* PB = DB;
-  for (int idx = tid; idx < S0 * 368; idx += NT0) {
-    int s = idx / 368, i = idx - s * 368;
-    float v;
-    if (i < 48) {
-      v = reinterpret_cast<const float*>(sbase(s) + st::E_FIRST)[i];
+  float* PB = XB;
+  for (int idx = tid; idx < S0 * 46; idx += NT0) {   // 46 = 6 history + 40 PCM pieces of 8 samples
+    int s = idx / 46, v = idx - s * 46;
+    float x[8];
+    if (v < 6) {
+      const f32x4* h = reinterpret_cast<const f32x4*>(sbase(s) + st::E_FIRST) + v * 2;
+      f32x4 a = h[0], b = h[1];
+      x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
     } else {
       int b = min(b0 + s, B - 1);
-      v = (float)pcm[(size_t)b * 320 + (i - 48)] * (1.0f / 32768.0f);  // Int16ToUnitScalar, dsp_utils.h:106-108
+      i32x4 w = *reinterpret_cast<const i32x4*>(pcm + (size_t)b * 320 + (v - 6) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // Int16ToUnitScalar, dsp_utils.h:106-108
+        x[2 * e] = (float)(int16_t)(w[e] & 0xffff) * (1.0f / 32768.0f);
+        x[2 * e + 1] = (float)(int16_t)(w[e] >> 16) * (1.0f / 32768.0f);
+      }
     }
-    PB[s * PBS + at16(i)] = v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) PB[s * PBS + at16(v * 8 + e)] = x[e];
   }
   __syncthreads();
   for (int idx = tid; idx < S0 * 48; idx += NT0) {
     int s = idx / 48, i = idx - s * 48;
     if (valid(s)) reinterpret_cast<float*>(sbase(s) + st::E_FIRST)[i] = PB[s * PBS + at16(320 + i)];
   }
+  LYRA_TSTAMP(1);
 
-  const int wn = wave & 3, wm = wave >> 2;  // GEMM wave grid for N=64: 4 N tiles x 2 halves of the 10 M tiles
+  const int wn = wave & 3, wm = wave >> 2;  // GEMM wave grid for N = 64: N tile x M group of 5 tiles
   const int ncol = wn * 16 + (lane & 15);   // logical output channel of this lane's C column
   const int pcol = at16(ncol);
 
-  // ---- B. first conv k64/s16: [20x8 rows] x K=64 x N=64 ---------------------------------------
+  // ---- B. first conv k64/s16: [20*S rows] x K=64 x N=64 ---------------------------------------
+  f32x4 xr[5][1];  // the residual stream X, resident in registers (MFMA C layout) through the three blocks
   {
-    f32x4 acc[5][1];
     auto aoff = [&](int i, int c) {
-      int t = 2 * (wm * 5 + i) + (m >> 3);
-      return (m & 7) * PBS + (t + c) * 16 + q * 4;
+      int R = (wm * 5 + i) * 16 + m;
+      return (R & (S0 - 1)) * PBS + (R / S0 + c) * 16 + q * 4;
     };
-    gemm_f32<5, 1, 4>(PB, aoff, P.first.w + wn * 4 * 64, acc);
-    float bias = P.first.b[ncol];
+    gemm_f32<5, 1, 4>(PB, aoff, P.first.w + wn * 4 * 64, xr);
+    float bias = as_global(P.first.b)[ncol];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) XB[(40 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = acc[i][0][e] + bias;
+      for (int e = 0; e < 4; ++e) xr[i][0][e] = xr[i][0][e] + bias;
   }
-  __syncthreads();
+  __syncthreads();  // PCM staging area is free again
+  LYRA_TSTAMP(2);
 
   // ---- C. three residual blocks, dilation 1 / 3 / 9 --------------------------------------------
   TileCtx cx{state, sids, nullptr, B - b0};
-  resblocks64(XB + 5 * S0 * CS0, DB, cx, P.dw, P.pw, P.cv, st::E_R0_0, st::E_R0_1, st::E_R0_2);
+  resblocks64r<S0, NT0>(xr, XB + 5 * S0 * CS0, cx, P.dw, P.pw, P.cv, st::E_R0_0, st::E_R0_1, st::E_R0_2);
+  LYRA_TSTAMP(3);
 
-  // ---- D. a = lrelu(X); prepend the 5 history rows of the strided conv ---------------------------
-  for (int idx = tid; idx < 20 * S0 * 16; idx += NT0) {
-    int p4 = idx & 15, rs = idx >> 4;
-    f32x4* x = reinterpret_cast<f32x4*>(&XB[(40 + rs) * CS0 + p4 * 4]);
-    *x = lrelu4(*x);
-  }
+  // ---- D. a = lrelu(X) -> rows 5..24; prepend the 5 history rows of the strided conv ------------------
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      XB[(5 * S0 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
   for (int idx = tid; idx < 5 * S0 * 16; idx += NT0) {
-    int p4 = idx & 15, s = (idx >> 4) & 7, j = idx >> 7;
+    int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
     *reinterpret_cast<f32x4*>(&XB[(j * S0 + s) * CS0 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D0 + (j * 64 + p4 * 4) * 4);
   }
   __syncthreads();
   for (int idx = tid; idx < 5 * S0 * 16; idx += NT0) {
-    int p4 = idx & 15, s = (idx >> 4) & 7, j = idx >> 7;
+    int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
     if (valid(s))
       *reinterpret_cast<f32x4*>(sbase(s) + st::E_D0 + (j * 64 + p4 * 4) * 4) =
           *reinterpret_cast<const f32x4*>(&XB[((20 + j) * S0 + s) * CS0 + p4 * 4]);
   }
+  LYRA_TSTAMP(4);
 
-  // ---- E. conv k10/s5: [4x8 rows] x K=640 x N=128 -----------------------------------------------
+  // ---- E. conv k10/s5: [4*S rows] x K=640 x N=128 -----------------------------------------------
   {
-    f32x4 acc[2][1];
+    constexpr int MTW = (4 * S0) / 16, NTW = 8 / NW0;
+    f32x4 acc[MTW][NTW];
     auto aoff = [&](int i, int c) {
       int tap = c >> 2, c16 = c & 3;
-      int tau = 2 * i + (m >> 3);
-      return ((5 * tau + tap) * S0 + (m & 7)) * CS0 + c16 * 16 + q * 4;
+      int R = i * 16 + m;
+      return ((5 * (R / S0) + tap) * S0 + (R & (S0 - 1))) * CS0 + c16 * 16 + q * 4;
     };
-    gemm_f32<2, 1, 40>(XB, aoff, P.down.w + wave * 40 * 64, acc);
-    int n = wave * 16 + (lane & 15);
-    float bias = P.down.b[n];
-    int pc = at16(n);
+    gemm_f32<MTW, NTW, 40>(XB, aoff, P.down.w + (wave * NTW) * 40 * 64, acc);
+    LYRA_TSTAMP(5);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NTW; ++j) {
+      int n = (wave * NTW + j) * 16 + (lane & 15);
+      float bias = as_global(P.down.b)[n];
+      int pc = at16(n);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int rr = q * 4 + e, tau = 2 * i + (rr >> 3), s = rr & 7;
-        if (valid(s)) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = acc[i][0][e] + bias;
-      }
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int R = i * 16 + q * 4 + e, tau = R / S0, s = R & (S0 - 1);
+          if (valid(s)) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = acc[i][j][e] + bias;
+        }
+    }
   }
+  LYRA_TSTAMP(6);
 }
 
 // =============================================================================================
 // stage 1
 // =============================================================================================
 namespace {
-constexpr int S1 = 16;
+constexpr int S1 = 8;
 constexpr int CS1 = 136;   // 128 + 8
-constexpr int NT1 = 512;
+constexpr int NT1 = 256;
+constexpr int NW1 = NT1 / 64;
 }  // namespace
 
 size_t enc_s1_lds_bytes() { return (size_t)(6 * S1 * CS1 + 4 * S1 * CS1) * 4 + 2 * S1 * 4; }
 int enc_s1_streams_per_wg() { return S1; }
 
-__global__ __launch_bounds__(NT1) void enc_s1_kernel(const EncS1P* __restrict__ Pp, const float* __restrict__ in0,
-                                                      const int32_t* __restrict__ ids, int B,
-                                                      uint8_t* __restrict__ state, float* __restrict__ out1) {
+__global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict__ Pp, const float* __restrict__ in0,
+                                                         const int32_t* __restrict__ ids, int B,
+                                                         uint8_t* __restrict__ state, float* __restrict__ out1) {
   const EncS1P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                    // [6][S1][CS1]: rows 0-1 strided-conv history, rows 2-5 X[t]
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(NT1) void enc_s1_kernel(const EncS1P* __restrict__ 
   auto valid = [&](int s) -> bool { return b0 + s < B; };
 
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
-    int p4 = idx & 31, s = (idx >> 5) & 15, t = idx >> 9;
+    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
     int b = min(b0 + s, B - 1);
     *reinterpret_cast<f32x4*>(&XB[((2 + t) * S1 + s) * CS1 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
@@ -169,7 +196,7 @@ __global__ __launch_bounds__(NT1) void enc_s1_kernel(const EncS1P* __restrict__ 
   __syncthreads();
 
   TileCtx cx{state, sids, sphase, B - b0};
-  resblocks128(XB + 2 * S1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::E_R1_0, st::E_R1_1, st::E_R1_2);
+  resblocks128<S1, NT1>(XB + 2 * S1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::E_R1_0, st::E_R1_1, st::E_R1_2);
 
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, rs = idx >> 5;
@@ -177,37 +204,39 @@ __global__ __launch_bounds__(NT1) void enc_s1_kernel(const EncS1P* __restrict__ 
     *x = lrelu4(*x);
   }
   for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {
-    int p4 = idx & 31, s = (idx >> 5) & 15, j = idx >> 9;
+    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), j = (idx >> 5) / S1;
     *reinterpret_cast<f32x4*>(&XB[(j * S1 + s) * CS1 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D1 + (j * 128 + p4 * 4) * 4);
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {
-    int p4 = idx & 31, s = (idx >> 5) & 15, j = idx >> 9;
+    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), j = (idx >> 5) / S1;
     if (valid(s))
       *reinterpret_cast<f32x4*>(sbase(s) + st::E_D1 + (j * 128 + p4 * 4) * 4) =
           *reinterpret_cast<const f32x4*>(&XB[((4 + j) * S1 + s) * CS1 + p4 * 4]);
   }
 
-  {  // conv k4/s2, 2 groups: per group [2x16 rows] x K=256 x N=128
-    f32x4 acc[2][2];
-    const int g = wave >> 2, nt0 = g * 8 + (wave & 3) * 2;
+  {  // conv k4/s2, 2 groups: per group [2*S rows] x K=256 x N=128; a wave's N tiles lie in one group
+    constexpr int MTW = (2 * S1) / 16, NTW = 16 / NW1;
+    f32x4 acc[MTW][NTW];
+    const int nt0 = wave * NTW, g = nt0 >> 3;
     auto aoff = [&](int i, int c) {
       int tap = c >> 2, c16 = c & 3;
-      return ((2 * i + tap) * S1 + m) * CS1 + g * 64 + c16 * 16 + q * 4;
+      int R = i * 16 + m;
+      return ((2 * (R / S1) + tap) * S1 + (R & (S1 - 1))) * CS1 + g * 64 + c16 * 16 + q * 4;
     };
-    gemm_f32<2, 2, 16>(XB, aoff, P.down.w + nt0 * 16 * 64, acc);
+    gemm_f32<MTW, NTW, 16>(XB, aoff, P.down.w + nt0 * 16 * 64, acc);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NTW; ++j) {
       int n = (nt0 + j) * 16 + (lane & 15);
-      float bias = P.down.b[n];
+      float bias = as_global(P.down.b)[n];
       int pc = at16(n);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          int s = q * 4 + e;
-          if (valid(s)) out1[((size_t)(b0 + s) * 2 + i) * 256 + pc] = acc[i][j][e] + bias;
+          int R = i * 16 + q * 4 + e, tau = R / S1, s = R & (S1 - 1);
+          if (valid(s)) out1[((size_t)(b0 + s) * 2 + tau) * 256 + pc] = acc[i][j][e] + bias;
         }
     }
   }

@@ -6,7 +6,7 @@
 // the tile is kept small (S = 8 streams, ~53 KB LDS) so that three workgroups share a CU and cover each
 // other's global-memory latencies.  Rows are (t, s) -> t*S + s; with S = 8 the two time steps fill exactly
 // one 16-row MFMA tile.
-#include "resblocks.h"
+#include "resblock_q.h"
 
 namespace lyra {
 

@@ -22,6 +22,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define LYRA_LRELU_ALPHA 0.30000001192092896f
 
+#ifdef LYRA_TIMING
+static __device__ long long g_lyra_tdbg[128];
+#define LYRA_TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lyra_tdbg[i] = clock64(); } while (0)
+#else
+#define LYRA_TSTAMP(i) do { } while (0)
+#endif
+
 namespace lyra {
 
 __host__ __device__ constexpr int at16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
@@ -101,35 +108,72 @@ __device__ __forceinline__ int32_t add_q(int32_t a, int32_t b, const AddQ& L) {
 //   bfrag        -> this wave's first N tile; tile j at bfrag + j * KC * 64
 // Accumulators are returned to the caller (epilogues often straddle a barrier).
 // ---------------------------------------------------------------------------------------------
-template <int MTW, int NTW, int KC, class AOff>
-__device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* __restrict__ bfrag,
+// The weight pointers come out of a parameter block in memory, so the compiler only knows them as generic
+// (flat) pointers; say they are global so the loads are global_load (vmcnt only, no LDS aperture check).
+#define LYRA_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const T LYRA_GLOBAL* as_global(const T* p) {
+  return (const T LYRA_GLOBAL*)p;
+}
+
+// Software-pipelined: the B fragments (L2, ~500+ cycles) and A fragments (LDS) of chunk c+PF are requested
+// before the MFMAs of chunk c issue; the K loop is fully unrolled so the PF+1 register stages are static and
+// the compiler emits counted s_waitcnt (the prefetches stay in flight across the MFMA block).
+#ifndef LYRA_PF_SCALE
+#define LYRA_PF_SCALE 1
+#endif
+template <int MTW, int NTW, int KC,
+          int PF = LYRA_PF_SCALE * (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+__device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                          f32x4 (&acc)[MTW][NTW]) {
   const int lane = threadIdx.x & 63;
+  const f32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic) + lane;
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+  f32x4 bq[PF + 1][NTW], aq[PF + 1][MTW];
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < KC) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) bq[p][j] = bfrag[(j * KC + p) * 64];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) aq[p][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, p));
+    }
+#pragma unroll
   for (int c = 0; c < KC; ++c) {
-    f32x4 b[NTW], a[MTW];
+    if (c + PF < KC) {
+      const int sl = (c + PF) % (PF + 1);
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) b[j] = bfrag[(j * KC + c) * 64 + lane];
+      for (int j = 0; j < NTW; ++j) bq[sl][j] = bfrag[(j * KC + c + PF) * 64];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) a[i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c));
+      for (int i = 0; i < MTW; ++i) aq[sl][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c + PF));
+    }
+    const int cur = c % (PF + 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+#ifdef LYRA_ABL_NOMFMA
+          asm volatile("" ::"v"(aq[cur][i][kk]), "v"(bq[cur][j][kk]));
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], acc[i][j], 0, 0, 0);
+#endif
   }
 }
 
 template <int MTW, int NTW, int KC, class AOff>
-__device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32x4* __restrict__ bfrag,
+__device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32x4* bfrag_generic,
                                         i32x4 (&acc)[MTW][NTW]) {
   const int lane = threadIdx.x & 63;
+#ifdef LYRA_I8_FLAT
+  const i32x4* bfrag = bfrag_generic;
+#else
+  const i32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic);
+#endif
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll

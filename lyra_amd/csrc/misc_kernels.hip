@@ -54,12 +54,17 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
     }
     int best = j;
     float bd = sum;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-      float od = __shfl_xor(bd, off, 16);
-      int oi = __shfl_xor(best, off, 16);
-      if (od < bd || (od == bd && oi < best)) { bd = od; best = oi; }
-    }
+    // all-reduce over the 16 code lanes with DPP row rotations (row_ror:8/4/2/1): register-only, no LDS crossbar.
+    // (distance, index) is totally ordered, so every lane ends with the same winner.
+#define LYRA_ROR_STEP(N)                                                                                  \
+  {                                                                                                       \
+    float od = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bd),      \
+                                                                       0x120 + (N), 0xf, 0xf, false));    \
+    int oi = __builtin_amdgcn_update_dpp(0, best, 0x120 + (N), 0xf, 0xf, false);                          \
+    if (od < bd || (od == bd && oi < best)) { bd = od; best = oi; }                                       \
+  }
+    LYRA_ROR_STEP(8) LYRA_ROR_STEP(4) LYRA_ROR_STEP(2) LYRA_ROR_STEP(1)
+#undef LYRA_ROR_STEP
 #pragma unroll
     for (int d4 = 0; d4 < 16; ++d4) {
       f32x4 qv = *reinterpret_cast<const f32x4*>(&c[best * 68 + d4 * 4]);

@@ -1,0 +1,29 @@
+// lyra_hip_components.h -- HIP-backed implementations of the reference's plugin interfaces and the factory
+// functions that replace lyra/lyra_components.cc:42-55.  Each object is ONE stream of the shared GPU context
+// (batch = 1 through the batched C ABI); for throughput use the batched C ABI / BatchCodec directly.
+#ifndef LYRA_AMD_HOST_LYRA_HIP_COMPONENTS_H_
+#define LYRA_AMD_HOST_LYRA_HIP_COMPONENTS_H_
+#include <memory>
+
+#include "include/ghc/filesystem.hpp"
+#include "plugin_interfaces.h"
+
+namespace chromemedia {
+namespace codec {
+
+// Same names / argument meaning as lyra/lyra_components.h:32-39.  `model_path` is a directory holding
+// lyra_v1.lyrapack (tools/pack_weights.py output of the reference's model_coeffs).  nullptr on failure.
+std::unique_ptr<VectorQuantizerInterface> CreateQuantizer(const ghc::filesystem::path& model_path);
+std::unique_ptr<GenerativeModelInterface> CreateGenerativeModel(int num_output_features,
+                                                                const ghc::filesystem::path& model_path);
+std::unique_ptr<FeatureExtractorInterface> CreateFeatureExtractor(const ghc::filesystem::path& model_path);
+// The NoiseEstimator front end (lyra/noise_estimator.cc:157-160): 16 kHz / hop 320 / window 640 / 160 mel bins.
+std::unique_ptr<FeatureExtractorInterface> CreateLogMelExtractor(const ghc::filesystem::path& model_path);
+
+// Process-wide settings of the shared context (call before the first Create*).
+void SetHipDevice(int device);
+void SetMaxStreams(int max_streams);  // how many plugin objects may be alive at once (default 1024)
+
+}  // namespace codec
+}  // namespace chromemedia
+#endif
