@@ -165,13 +165,23 @@ def main():
     # UnitToInt16Scalar(U(-1,1)) i.i.d. (lyra_benchmark_lib.cc:233-239): full-scale uniform int16
     pcm_in = torch.randint(-32768, 32768, (W + K, B, 320), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
     ids = torch.arange(B, device=dev, dtype=torch.int32)  # local stream slots of this rank's shard
-    packets = torch.empty((B, lyra_amd.packet_size(bits)), device=dev, dtype=torch.uint8)
-    pcm_out = torch.empty((B, 320), device=dev, dtype=torch.int16)
+    # two packet / PCM buffers, alternated: the library runs decode of step i (decode-side stream) concurrently with
+    # encode of step i+1 (encode-side stream); a packet buffer is rewritten only two steps later, after a
+    # stream-ordered decode has consumed it (include/lyra_hip.h "Streams").
+    packets = [torch.empty((B, lyra_amd.packet_size(bits)), device=dev, dtype=torch.uint8) for _ in range(2)]
+    pcm_out = [torch.empty((B, 320), device=dev, dtype=torch.int16) for _ in range(2)]
     torch.cuda.synchronize()
 
+    s_enc = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+    s_dec = torch.cuda.ExternalStream(ctx.stream_handle_decode(), device=dev)
+    dec_done = [torch.cuda.Event(), torch.cuda.Event()]
+
     def step(i):
-        ctx.encode_dev(ids, pcm_in[i], bits, packets)
-        ctx.decode_dev(ids, packets, bits, pcm_out)
+        if i >= 2:
+            s_enc.wait_event(dec_done[i & 1])   # encode(i) rewrites the buffer decode(i-2) read
+        ctx.encode_dev(ids, pcm_in[i], bits, packets[i & 1])
+        ctx.decode_dev(ids, packets[i & 1], bits, pcm_out[i & 1])
+        dec_done[i & 1].record(s_dec)
 
     # warm-up: every kernel bracketed by HIP events -> per-kernel share and the dominant kernel
     ctx.profile_enable(True)

@@ -23,8 +23,18 @@
  * fails.
  *
  * Pointer flavours: functions without suffix take HOST pointers (they copy
- * H2D/D2H on the context's stream and synchronise); `_dev` variants take DEVICE
- * pointers, enqueue on the context's stream and do not synchronise.
+ * H2D/D2H and synchronise); `_dev` variants take DEVICE pointers, enqueue and
+ * do not synchronise.
+ *
+ * Streams: a context runs two HIP streams -- the ENCODE side (extract,
+ * rvq_encode, encode) and the DECODE side (rvq_decode, generate, decode,
+ * logmel); encoder and decoder state are disjoint.  A decode-side call is
+ * ordered (on the GPU) after every earlier encode-side call, so
+ * encode_dev -> decode_dev on the produced packets needs no caller sync.
+ * Encode-side calls are NOT ordered after earlier decode-side calls: encode of
+ * frame i+1 overlaps decode of frame i.  With `_dev` variants, do not let an
+ * encode-side call overwrite a buffer that a pending decode-side call still
+ * reads (alternate two buffers, or lyra_hip_synchronize()).
  */
 #ifndef LYRA_HIP_H_
 #define LYRA_HIP_H_
@@ -117,8 +127,10 @@ int lyra_hip_encode_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, c
 int lyra_hip_decode_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const uint8_t* d_packets,
                         int num_bits, int16_t* d_pcm);
 
-/* The context's HIP stream (hipStream_t as void*), for event timing / ordering by the caller. */
+/* The context's HIP streams (hipStream_t as void*), for event timing / ordering by the caller:
+ * encode side and decode side.  lyra_hip_synchronize() waits for both. */
 void* lyra_hip_stream(lyra_hip_ctx* ctx);
+void* lyra_hip_stream_decode(lyra_hip_ctx* ctx);
 int lyra_hip_synchronize(lyra_hip_ctx* ctx);
 
 /* Per-stream state footprint in HBM (bytes) and the context's stream capacity. */

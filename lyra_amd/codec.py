@@ -82,6 +82,8 @@ def _load():
         getattr(L, f"lyra_hip_decode{suf}").argtypes = [vp, vp, ci, vp, ci, vp]
     L.lyra_hip_stream.restype = vp
     L.lyra_hip_stream.argtypes = [vp]
+    L.lyra_hip_stream_decode.restype = vp
+    L.lyra_hip_stream_decode.argtypes = [vp]
     L.lyra_hip_synchronize.argtypes = [vp]
     L.lyra_hip_state_bytes_per_stream.restype = C.c_size_t
     L.lyra_hip_max_streams.argtypes = [vp]
@@ -139,7 +141,12 @@ class LyraHip:
             raise LyraHipError(f"lyra_hip error {rc}: {self.last_error()}")
 
     def stream_handle(self):
+        """hipStream_t (int) of the encode side."""
         return self.L.lyra_hip_stream(self.h)
+
+    def stream_handle_decode(self):
+        """hipStream_t (int) of the decode side."""
+        return self.L.lyra_hip_stream_decode(self.h)
 
     def synchronize(self):
         self._chk(self.L.lyra_hip_synchronize(self.h))

@@ -1,5 +1,11 @@
 // api.hip -- the C ABI of include/lyra_hip.h: context, scratch, launches.  No CPU fallback anywhere:
 // every entry point either runs the gfx950 kernels or fails with an error code.
+//
+// Two HIP streams per context: the ENCODE side (extract, rvq_encode, encode) and the DECODE side (rvq_decode,
+// generate, decode, logmel).  Encoder and decoder state are disjoint, so decode of step i can overlap encode of
+// step i+1; every stage kernel is a chain of short dependent phases, and two chains in flight fill each other's
+// bubbles.  Ordering: a decode-side call waits (on the GPU) for every earlier encode-side call; encode-side calls do
+// not wait for decode-side calls.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -23,12 +29,15 @@ struct lyra_hip_ctx {
   int device = 0;
   int max_streams = 0;
   int mode = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t se = nullptr;  // encode side
+  hipStream_t sd = nullptr;  // decode side
+  hipEvent_t ev_enc = nullptr;
   Model model;
   uint8_t* d_state = nullptr;
   // scratch, sized for `cap` frames
   int cap = 0;
-  int32_t* d_ids = nullptr;
+  int32_t* d_ids = nullptr;      // encode-side staging of host ids
+  int32_t* d_ids_dec = nullptr;  // decode-side staging of host ids
   int16_t* d_pcm_in = nullptr;
   float* d_e0 = nullptr;     // [cap][4][128]
   float* d_e1 = nullptr;     // [cap][2][256]
@@ -42,8 +51,8 @@ struct lyra_hip_ctx {
   int16_t* d_pcm_out = nullptr;
   float* d_mel = nullptr;    // [cap][160]
   int last_B_enc = 0, last_B_dec = 0;
-  // optional per-kernel timing with HIP events on this context's stream (bench.py roofline leg)
-  unsigned profiling = 0;  // bit i set: bracket launches of kernel i with HIP events
+  // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
+  unsigned profiling = 0;  // bit i set: bracket launches of kernel i
   struct Span { int kid; hipEvent_t a, b; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> event_pool;
@@ -72,23 +81,31 @@ int fail(lyra_hip_ctx* c, int code, const char* fmt, ...) {
 template <class T>
 hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
 
+int sync_all(lyra_hip_ctx* c) {
+  HIPCHK(c, hipStreamSynchronize(c->se));
+  HIPCHK(c, hipStreamSynchronize(c->sd));
+  return 0;
+}
+
 void free_scratch(lyra_hip_ctx* c) {
-  void* ps[] = {c->d_ids, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_codes, c->d_idx, c->d_pkt,
+  void* ps[] = {c->d_ids, c->d_ids_dec, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_codes, c->d_idx, c->d_pkt,
                 c->d_lossy, c->d_d0, c->d_d1, c->d_pcm_out, c->d_mel};
   for (void* p : ps)
     if (p) (void)hipFree(p);
-  c->d_ids = nullptr; c->d_pcm_in = nullptr; c->d_e0 = nullptr; c->d_e1 = nullptr; c->d_feat = nullptr;
-  c->d_codes = nullptr; c->d_idx = nullptr; c->d_pkt = nullptr; c->d_lossy = nullptr; c->d_d0 = nullptr;
-  c->d_d1 = nullptr; c->d_pcm_out = nullptr; c->d_mel = nullptr;
+  c->d_ids = nullptr; c->d_ids_dec = nullptr; c->d_pcm_in = nullptr; c->d_e0 = nullptr; c->d_e1 = nullptr;
+  c->d_feat = nullptr; c->d_codes = nullptr; c->d_idx = nullptr; c->d_pkt = nullptr; c->d_lossy = nullptr;
+  c->d_d0 = nullptr; c->d_d1 = nullptr; c->d_pcm_out = nullptr; c->d_mel = nullptr;
   c->cap = 0;
 }
 
 int ensure_scratch(lyra_hip_ctx* c, int B) {
   if (B <= c->cap) return 0;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = sync_all(c);
+  if (rc) return rc;
   free_scratch(c);
   size_t n = (size_t)B;
   HIPCHK(c, dalloc(&c->d_ids, n));
+  HIPCHK(c, dalloc(&c->d_ids_dec, n));
   HIPCHK(c, dalloc(&c->d_pcm_in, n * 320));
   HIPCHK(c, dalloc(&c->d_e0, n * 4 * 128));
   HIPCHK(c, dalloc(&c->d_e1, n * 2 * 256));
@@ -142,69 +159,72 @@ hipEvent_t take_event(lyra_hip_ctx* c) {
   return e;
 }
 struct ProfScope {
-  lyra_hip_ctx* c; int kid; hipEvent_t a = nullptr;
-  ProfScope(lyra_hip_ctx* c_, int kid_) : c(c_), kid(kid_) {
-    if (c->profiling & (1u << kid)) { a = take_event(c); (void)hipEventRecord(a, c->stream); }
+  lyra_hip_ctx* c; int kid; hipStream_t s; hipEvent_t a = nullptr;
+  ProfScope(lyra_hip_ctx* c_, int kid_, hipStream_t s_) : c(c_), kid(kid_), s(s_) {
+    if (c->profiling & (1u << kid)) { a = take_event(c); (void)hipEventRecord(a, s); }
   }
   ~ProfScope() {
-    if (a) { hipEvent_t b = take_event(c); (void)hipEventRecord(b, c->stream); c->spans.push_back({kid, a, b}); }
+    if (a) { hipEvent_t b = take_event(c); (void)hipEventRecord(b, s); c->spans.push_back({kid, a, b}); }
   }
 };
 
-// ---- launches (all on c->stream) ---------------------------------------------------------------------
+// ---- launches -----------------------------------------------------------------------------------------
+void enc_side_done(lyra_hip_ctx* c) { (void)hipEventRecord(c->ev_enc, c->se); }
+void dec_side_begin(lyra_hip_ctx* c) { (void)hipStreamWaitEvent(c->sd, c->ev_enc, 0); }
+
 int launch_extract(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
   const Model& M = c->model;
-  { ProfScope ps(c, K_ENC_S0);
-  hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), c->stream,
-                     M.d_enc0, d_pcm, d_ids, B, c->d_state, c->d_e0); }
-  { ProfScope ps(c, K_ENC_S1);
-  hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(256), enc_s1_lds_bytes(), c->stream,
-                     M.d_enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1); }
-  { ProfScope ps(c, K_ENC_S2);
-  hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), c->stream,
-                     M.d_enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes); }
+  { ProfScope ps(c, K_ENC_S0, c->se);
+    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), c->se,
+                       M.d_enc0, d_pcm, d_ids, B, c->d_state, c->d_e0); }
+  { ProfScope ps(c, K_ENC_S1, c->se);
+    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(256), enc_s1_lds_bytes(), c->se,
+                       M.d_enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1); }
+  { ProfScope ps(c, K_ENC_S2, c->se);
+    hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), c->se,
+                       M.d_enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
   return 0;
 }
 
 int launch_rvq_encode(lyra_hip_ctx* c, int B, const float* d_feat, int num_stages, int32_t* d_idx, uint8_t* d_pkt) {
-  { ProfScope ps(c, K_RVQ_ENC);
-  hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->stream, c->model.cb, d_feat, B,
-                     num_stages, d_idx, d_pkt); }
+  { ProfScope ps(c, K_RVQ_ENC, c->se);
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->se, c->model.cb, d_feat, B, num_stages,
+                       d_idx, d_pkt); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
 int launch_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* d_idx, const uint8_t* d_pkt, int num_stages,
                       float* d_feat) {
-  { ProfScope ps(c, K_RVQ_DEC);
-  hipLaunchKernelGGL(rvq_decode_kernel, dim3(cdiv(B, 4)), dim3(256), 0, c->stream, c->model.cb, d_idx, d_pkt,
-                     num_stages, B, d_feat); }
+  { ProfScope ps(c, K_RVQ_DEC, c->sd);
+    hipLaunchKernelGGL(rvq_decode_kernel, dim3(cdiv(B, 4)), dim3(256), 0, c->sd, c->model.cb, d_idx, d_pkt,
+                       num_stages, B, d_feat); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
 int launch_generate(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
   const Model& M = c->model;
-  { ProfScope ps(c, K_DEC_S0);
-  hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), c->stream,
-                     M.d_dec0, d_feat, d_ids, B, c->d_state, c->d_d0); }
-  { ProfScope ps(c, K_DEC_S1);
-  hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(256), dec_s1_lds_bytes(), c->stream,
-                     M.d_dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1); }
-  { ProfScope ps(c, K_DEC_S2);
-  hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), c->stream,
-                     M.d_dec2, c->d_d1, d_ids, B, c->d_state, d_pcm); }
+  { ProfScope ps(c, K_DEC_S0, c->sd);
+    hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), c->sd,
+                       M.d_dec0, d_feat, d_ids, B, c->d_state, c->d_d0); }
+  { ProfScope ps(c, K_DEC_S1, c->sd);
+    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(256), dec_s1_lds_bytes(), c->sd,
+                       M.d_dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1); }
+  { ProfScope ps(c, K_DEC_S2, c->sd);
+    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), c->sd,
+                       M.d_dec2, c->d_d1, d_ids, B, c->d_state, d_pcm); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
   return 0;
 }
 
 int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
-  { ProfScope ps(c, K_LOGMEL);
-  hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->stream, c->model.d_mel, d_pcm, d_ids, B,
-                     c->d_state, d_mel); }
+  { ProfScope ps(c, K_LOGMEL, c->sd);
+    hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd, c->model.d_mel, d_pcm, d_ids, B,
+                       c->d_state, d_mel); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -249,7 +269,10 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
     lyra_hip_destroy(c);
     return fail(nullptr, code, "%s", msg.c_str());
   };
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
+  if (hipStreamCreateWithFlags(&c->se, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->sd, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_enc, hipEventDisableTiming) != hipSuccess)
+    return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
@@ -257,9 +280,10 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
+  enc_side_done(c);
   *out = c;
   int rc = lyra_hip_reset_streams(c, nullptr, 0);
-  if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = LYRA_HIP_EHIP;
+  if (rc == 0) rc = sync_all(c);
   if (rc != 0) { *out = nullptr; return bail(rc, "initial state reset failed"); }
   return 0;
 }
@@ -267,13 +291,16 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
 void lyra_hip_destroy(lyra_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->se) (void)hipStreamSynchronize(c->se);
+  if (c->sd) (void)hipStreamSynchronize(c->sd);
   free_scratch(c);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
   if (c->d_state) (void)hipFree(c->d_state);
   free_model(&c->model);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->se) (void)hipStreamDestroy(c->se);
+  if (c->sd) (void)hipStreamDestroy(c->sd);
   delete c;
 }
 
@@ -283,11 +310,11 @@ const char* lyra_hip_last_error(const lyra_hip_ctx* c) {
   return g_create_error.c_str();
 }
 
-void* lyra_hip_stream(lyra_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* lyra_hip_stream(lyra_hip_ctx* c) { return c ? (void*)c->se : nullptr; }
+void* lyra_hip_stream_decode(lyra_hip_ctx* c) { return c ? (void*)c->sd : nullptr; }
 int lyra_hip_synchronize(lyra_hip_ctx* c) {
   if (!c) return LYRA_HIP_EINVAL;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return sync_all(c);
 }
 size_t lyra_hip_state_bytes_per_stream(void) { return (size_t)st::BYTES; }
 int lyra_hip_max_streams(const lyra_hip_ctx* c) { return c ? c->max_streams : 0; }
@@ -295,22 +322,24 @@ int lyra_hip_max_streams(const lyra_hip_ctx* c) { return c ? c->max_streams : 0;
 int lyra_hip_reset_streams(lyra_hip_ctx* c, const int32_t* ids, int n) {
   if (!c) return LYRA_HIP_EINVAL;
   HIPCHK(c, hipSetDevice(c->device));
+  int rc = sync_all(c);  // the reset touches encoder and decoder state: nothing may be in flight
+  if (rc) return rc;
   if (!ids) {
-    hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->stream, c->model.d_reset,
+    hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->se, c->model.d_reset,
                        (const int32_t*)nullptr, c->max_streams, 1, c->d_state);
     HIPCHK(c, hipGetLastError());
-    return 0;
+    enc_side_done(c);
+    return sync_all(c);
   }
-  int rc = check_batch(c, n);
-  if (rc) return rc;
+  if ((rc = check_batch(c, n))) return rc;
   if ((rc = check_ids_host(c, ids, n))) return rc;
   if ((rc = ensure_scratch(c, n))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->stream, c->model.d_reset, (const int32_t*)c->d_ids, n, 0,
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->se));
+  hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->se, c->model.d_reset, (const int32_t*)c->d_ids, n, 0,
                      c->d_state);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  enc_side_done(c);
+  return sync_all(c);
 }
 
 // ---- device-pointer variants ------------------------------------------------------------------------------
@@ -319,7 +348,9 @@ int lyra_hip_extract_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
-  return launch_extract(c, d_ids, B, d_pcm, d_feat);
+  rc = launch_extract(c, d_ids, B, d_pcm, d_feat);
+  enc_side_done(c);
+  return rc;
 }
 
 int lyra_hip_rvq_encode_dev(lyra_hip_ctx* c, int B, const float* d_feat, int num_bits, int32_t* d_idx) {
@@ -327,12 +358,15 @@ int lyra_hip_rvq_encode_dev(lyra_hip_ctx* c, int B, const float* d_feat, int num
   int rc = check_bits(c, num_bits);
   if (rc) return rc;
   if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
-  return launch_rvq_encode(c, B, d_feat, num_bits / 4, d_idx, nullptr);
+  rc = launch_rvq_encode(c, B, d_feat, num_bits / 4, d_idx, nullptr);
+  enc_side_done(c);
+  return rc;
 }
 
 int lyra_hip_rvq_decode_dev(lyra_hip_ctx* c, int B, const int32_t* d_idx, float* d_feat) {
   if (!c) return LYRA_HIP_EINVAL;
   if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
+  dec_side_begin(c);
   return launch_rvq_decode(c, B, d_idx, nullptr, 46, d_feat);
 }
 
@@ -341,6 +375,7 @@ int lyra_hip_generate_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const fl
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
+  dec_side_begin(c);
   return launch_generate(c, d_ids, B, d_feat, d_pcm);
 }
 
@@ -348,6 +383,7 @@ int lyra_hip_logmel_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
   int rc = check_batch(c, B);
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  dec_side_begin(c);
   return launch_logmel(c, d_ids, B, d_pcm, d_mel);
 }
 
@@ -359,7 +395,9 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
   if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
   if ((rc = launch_extract(c, d_ids, B, d_pcm, c->d_feat))) return rc;
-  return launch_rvq_encode(c, B, c->d_feat, num_bits / 4, nullptr, d_packets);
+  rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, nullptr, d_packets);
+  enc_side_done(c);
+  return rc;
 }
 
 int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint8_t* d_packets, int num_bits,
@@ -369,11 +407,12 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
   if ((rc = check_bits(c, num_bits))) return rc;
   if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
+  dec_side_begin(c);
   if ((rc = launch_rvq_decode(c, B, nullptr, d_packets, num_bits / 4, c->d_lossy))) return rc;
   return launch_generate(c, d_ids, B, c->d_lossy, d_pcm);
 }
 
-// ---- host-pointer variants ---------------------------------------------------------------------------------
+// ---- host-pointer variants (synchronous) --------------------------------------------------------------------
 #define PROLOGUE(c, B)                      \
   int rc = check_batch(c, B);               \
   if (rc) return rc;                        \
@@ -384,11 +423,12 @@ int lyra_hip_extract(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* 
   PROLOGUE(c, B);
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se));
   if ((rc = launch_extract(c, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
-  HIPCHK(c, hipMemcpyAsync(features, c->d_feat, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(features, c->d_feat, (size_t)B * 256, hipMemcpyDeviceToHost, c->se));
+  enc_side_done(c);
+  HIPCHK(c, hipStreamSynchronize(c->se));
   return 0;
 }
 
@@ -399,10 +439,11 @@ int lyra_hip_rvq_encode(lyra_hip_ctx* c, int B, const float* features, int num_b
   if (B <= 0 || !features || !indices) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
   HIPCHK(c, hipSetDevice(c->device));
   if ((rc = ensure_scratch(c, B))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_feat, features, (size_t)B * 256, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_feat, features, (size_t)B * 256, hipMemcpyHostToDevice, c->se));
   if ((rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, c->d_idx, nullptr))) return rc;
-  HIPCHK(c, hipMemcpyAsync(indices, c->d_idx, (size_t)B * 46 * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(indices, c->d_idx, (size_t)B * 46 * 4, hipMemcpyDeviceToHost, c->se));
+  enc_side_done(c);
+  HIPCHK(c, hipStreamSynchronize(c->se));
   return 0;
 }
 
@@ -412,10 +453,11 @@ int lyra_hip_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* indices, float* f
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = ensure_scratch(c, B))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_idx, indices, (size_t)B * 46 * 4, hipMemcpyHostToDevice, c->stream));
+  dec_side_begin(c);
+  HIPCHK(c, hipMemcpyAsync(c->d_idx, indices, (size_t)B * 46 * 4, hipMemcpyHostToDevice, c->sd));
   if ((rc = launch_rvq_decode(c, B, c->d_idx, nullptr, 46, c->d_lossy))) return rc;
-  HIPCHK(c, hipMemcpyAsync(features, c->d_lossy, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(features, c->d_lossy, (size_t)B * 256, hipMemcpyDeviceToHost, c->sd));
+  HIPCHK(c, hipStreamSynchronize(c->sd));
   return 0;
 }
 
@@ -423,11 +465,12 @@ int lyra_hip_generate(lyra_hip_ctx* c, const int32_t* ids, int B, const float* f
   PROLOGUE(c, B);
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_lossy, features, (size_t)B * 256, hipMemcpyHostToDevice, c->stream));
-  if ((rc = launch_generate(c, c->d_ids, B, c->d_lossy, c->d_pcm_out))) return rc;
-  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  dec_side_begin(c);
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd));
+  HIPCHK(c, hipMemcpyAsync(c->d_lossy, features, (size_t)B * 256, hipMemcpyHostToDevice, c->sd));
+  if ((rc = launch_generate(c, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->sd));
+  HIPCHK(c, hipStreamSynchronize(c->sd));
   return 0;
 }
 
@@ -435,11 +478,12 @@ int lyra_hip_logmel(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* p
   PROLOGUE(c, B);
   if (!pcm || !mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->stream));
-  if ((rc = launch_logmel(c, c->d_ids, B, c->d_pcm_in, c->d_mel))) return rc;
-  HIPCHK(c, hipMemcpyAsync(mel, c->d_mel, (size_t)B * 160 * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  dec_side_begin(c);
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_out, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->sd));
+  if ((rc = launch_logmel(c, c->d_ids_dec, B, c->d_pcm_out, c->d_mel))) return rc;
+  HIPCHK(c, hipMemcpyAsync(mel, c->d_mel, (size_t)B * 160 * 4, hipMemcpyDeviceToHost, c->sd));
+  HIPCHK(c, hipStreamSynchronize(c->sd));
   return 0;
 }
 
@@ -449,12 +493,13 @@ int lyra_hip_encode(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* p
   if (!pcm || !packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
   const int nbytes = (num_bits + 7) / 8;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se));
   if ((rc = launch_extract(c, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
   if ((rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, nullptr, c->d_pkt))) return rc;
-  HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->se));
+  enc_side_done(c);
+  HIPCHK(c, hipStreamSynchronize(c->se));
   return 0;
 }
 
@@ -464,12 +509,15 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
   if (!pcm || !packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
   const int nbytes = (num_bits + 7) / 8;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pkt, packets, (size_t)B * nbytes, hipMemcpyHostToDevice, c->stream));
-  if ((rc = launch_rvq_decode(c, B, nullptr, c->d_pkt, num_bits / 4, c->d_lossy))) return rc;
-  if ((rc = launch_generate(c, c->d_ids, B, c->d_lossy, c->d_pcm_out))) return rc;
-  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  dec_side_begin(c);
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd));
+  // decode-side packet staging reuses the idx scratch (the encode side owns d_pkt)
+  uint8_t* d_pk = reinterpret_cast<uint8_t*>(c->d_idx);
+  HIPCHK(c, hipMemcpyAsync(d_pk, packets, (size_t)B * nbytes, hipMemcpyHostToDevice, c->sd));
+  if ((rc = launch_rvq_decode(c, B, nullptr, d_pk, num_bits / 4, c->d_lossy))) return rc;
+  if ((rc = launch_generate(c, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->sd));
+  HIPCHK(c, hipStreamSynchronize(c->sd));
   return 0;
 }
 
@@ -482,7 +530,8 @@ int lyra_hip_profile_kernel_count(void) { return K_COUNT; }
 const char* lyra_hip_profile_kernel_name(int i) { return (i >= 0 && i < K_COUNT) ? kKernelNames[i] : ""; }
 int lyra_hip_profile_read(lyra_hip_ctx* c, double* total_ms, long* launches) {
   if (!c || !total_ms || !launches) return LYRA_HIP_EINVAL;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = sync_all(c);
+  if (rc) return rc;
   for (int i = 0; i < K_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
   for (auto& sp : c->spans) {
     float ms = 0.f;
@@ -509,7 +558,8 @@ long lyra_hip_debug_read(lyra_hip_ctx* c, int which, float* host_out, long capac
     default: return fail(c, LYRA_HIP_EINVAL, "unknown debug buffer %d", which);
   }
   if (n > capacity) return fail(c, LYRA_HIP_EINVAL, "debug buffer needs %ld floats", n);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = sync_all(c);
+  if (rc) return rc;
   HIPCHK(c, hipMemcpy(host_out, src, (size_t)n * 4, hipMemcpyDeviceToHost));
   return n;
 }

@@ -139,8 +139,14 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
           const int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / S, s = R & (S - 1);
           const float* hist = reinterpret_cast<const float*>(cx.sbase(s) + off);
           const int t0 = t - 2 * d, t1 = t - d;
+#ifdef LYRA_ABL_NOHIST
+          float v0 = A[((t0 >= 0 ? t0 : 0) * S + s) * CS + pcol];
+          float v1 = A[((t1 >= 0 ? t1 : 0) * S + s) * CS + pcol];
+          (void)hist;
+#else
           float v0 = t0 >= 0 ? A[(t0 * S + s) * CS + pcol] : hist[(R2 + t0) * 64 + pcol];
           float v1 = t1 >= 0 ? A[(t1 * S + s) * CS + pcol] : hist[(R2 + t1) * 64 + pcol];
+#endif
           float v2 = A[R * CS + pcol];
           float acc = __builtin_fmaf(v0, w0, 0.f);
           acc = __builtin_fmaf(v1, w1, acc);
