@@ -29,9 +29,13 @@ struct lyra_hip_ctx {
   int device = 0;
   int max_streams = 0;
   int mode = 0;
-  hipStream_t se = nullptr;  // encode side
-  hipStream_t sd = nullptr;  // decode side
-  hipEvent_t ev_enc = nullptr;
+  static constexpr int KMAX = 8;
+  int nsub = 1;                    // sub-batches a `_dev` call is split into (independent stream pairs)
+  hipStream_t se[KMAX] = {};       // encode side
+  hipStream_t sd[KMAX] = {};       // decode side
+  hipEvent_t ev_enc[KMAX] = {};    // end of the latest encode-side work on se[k]
+  hipEvent_t ev_dec[2][KMAX] = {}; // end of the two latest decode-side calls on sd[k]
+  long n_dec_calls = 0;
   Model model;
   uint8_t* d_state = nullptr;
   // scratch, sized for `cap` frames
@@ -82,8 +86,10 @@ template <class T>
 hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
 
 int sync_all(lyra_hip_ctx* c) {
-  HIPCHK(c, hipStreamSynchronize(c->se));
-  HIPCHK(c, hipStreamSynchronize(c->sd));
+  for (int k = 0; k < lyra_hip_ctx::KMAX; ++k) {
+    if (c->se[k]) HIPCHK(c, hipStreamSynchronize(c->se[k]));
+    if (c->sd[k]) HIPCHK(c, hipStreamSynchronize(c->sd[k]));
+  }
   return 0;
 }
 
@@ -169,61 +175,97 @@ struct ProfScope {
 };
 
 // ---- launches -----------------------------------------------------------------------------------------
-void enc_side_done(lyra_hip_ctx* c) { (void)hipEventRecord(c->ev_enc, c->se); }
-void dec_side_begin(lyra_hip_ctx* c) { (void)hipStreamWaitEvent(c->sd, c->ev_enc, 0); }
+// Ordering between the two sides (see include/lyra_hip.h "Streams"):
+//  * decode-side work on chunk k waits for all encode-side work enqueued so far;
+//  * encode-side work on chunk k waits for every decode-side call except the most recent one, so a caller that
+//    alternates two buffers never has a buffer rewritten while a pending decode still reads it.
+void enc_side_begin(lyra_hip_ctx* c, int k) {
+  if (c->n_dec_calls >= 2) (void)hipStreamWaitEvent(c->se[k], c->ev_dec[c->n_dec_calls & 1][k], 0);
+}
+void enc_side_done(lyra_hip_ctx* c, int k) { (void)hipEventRecord(c->ev_enc[k], c->se[k]); }
+void dec_side_begin(lyra_hip_ctx* c, int k) {
+  for (int j = 0; j < c->nsub; ++j) (void)hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0);
+}
+void dec_side_done(lyra_hip_ctx* c, int k, int nk = 0) {
+  const int slot = (int)(c->n_dec_calls & 1);
+  if (nk == 1) {  // an unsplit call stands for every chunk
+    for (int j = 0; j < c->nsub; ++j) (void)hipEventRecord(c->ev_dec[slot][j], c->sd[0]);
+  } else {
+    (void)hipEventRecord(c->ev_dec[slot][k], c->sd[k]);
+  }
+}
 
-int launch_extract(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
+// chunk k of a batch of B frames: [lo, lo + n), multiples of 16 streams so tiles stay whole
+void chunk_of(const lyra_hip_ctx* c, int B, int k, int* lo, int* n) {
+  int per = (B / c->nsub + 15) / 16 * 16;
+  int a = per * k, b = (k == c->nsub - 1) ? B : per * (k + 1);
+  if (a > B) a = B;
+  if (b > B) b = B;
+  *lo = a;
+  *n = b - a;
+}
+int chunks_for(const lyra_hip_ctx* c, int B) { return (c->nsub > 1 && B >= 64 * c->nsub) ? c->nsub : 1; }
+
+int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
   const Model& M = c->model;
-  { ProfScope ps(c, K_ENC_S0, c->se);
-    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), c->se,
-                       M.d_enc0, d_pcm, d_ids, B, c->d_state, c->d_e0); }
-  { ProfScope ps(c, K_ENC_S1, c->se);
-    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(256), enc_s1_lds_bytes(), c->se,
-                       M.d_enc1, c->d_e0, d_ids, B, c->d_state, c->d_e1); }
-  { ProfScope ps(c, K_ENC_S2, c->se);
-    hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), c->se,
-                       M.d_enc2, c->d_e1, d_ids, B, c->d_state, d_feat, c->d_codes); }
+  hipStream_t st_ = c->se[k];
+  float* e0 = c->d_e0 + (size_t)lo * 512;
+  float* e1 = c->d_e1 + (size_t)lo * 512;
+  float* codes = c->d_codes + (size_t)lo * 64;
+  { ProfScope ps(c, K_ENC_S0, st_);
+    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), st_,
+                       M.d_enc0, d_pcm, d_ids, B, c->d_state, e0); }
+  { ProfScope ps(c, K_ENC_S1, st_);
+    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(256), enc_s1_lds_bytes(), st_,
+                       M.d_enc1, e0, d_ids, B, c->d_state, e1); }
+  { ProfScope ps(c, K_ENC_S2, st_);
+    hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), st_,
+                       M.d_enc2, e1, d_ids, B, c->d_state, d_feat, codes); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
   return 0;
 }
 
-int launch_rvq_encode(lyra_hip_ctx* c, int B, const float* d_feat, int num_stages, int32_t* d_idx, uint8_t* d_pkt) {
-  { ProfScope ps(c, K_RVQ_ENC, c->se);
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->se, c->model.cb, d_feat, B, num_stages,
-                       d_idx, d_pkt); }
+int launch_rvq_encode(lyra_hip_ctx* c, int k, int B, const float* d_feat, int num_stages, int32_t* d_idx,
+                      uint8_t* d_pkt) {
+  { ProfScope ps(c, K_RVQ_ENC, c->se[k]);
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->se[k], c->model.cb, d_feat, B,
+                       num_stages, d_idx, d_pkt); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
-int launch_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* d_idx, const uint8_t* d_pkt, int num_stages,
+int launch_rvq_decode(lyra_hip_ctx* c, int k, int B, const int32_t* d_idx, const uint8_t* d_pkt, int num_stages,
                       float* d_feat) {
-  { ProfScope ps(c, K_RVQ_DEC, c->sd);
-    hipLaunchKernelGGL(rvq_decode_kernel, dim3(cdiv(B, 4)), dim3(256), 0, c->sd, c->model.cb, d_idx, d_pkt,
+  { ProfScope ps(c, K_RVQ_DEC, c->sd[k]);
+    hipLaunchKernelGGL(rvq_decode_kernel, dim3(cdiv(B, 4)), dim3(256), 0, c->sd[k], c->model.cb, d_idx, d_pkt,
                        num_stages, B, d_feat); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
-int launch_generate(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
+int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
   const Model& M = c->model;
-  { ProfScope ps(c, K_DEC_S0, c->sd);
-    hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), c->sd,
-                       M.d_dec0, d_feat, d_ids, B, c->d_state, c->d_d0); }
-  { ProfScope ps(c, K_DEC_S1, c->sd);
-    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(256), dec_s1_lds_bytes(), c->sd,
-                       M.d_dec1, c->d_d0, d_ids, B, c->d_state, c->d_d1); }
-  { ProfScope ps(c, K_DEC_S2, c->sd);
-    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), c->sd,
-                       M.d_dec2, c->d_d1, d_ids, B, c->d_state, d_pcm); }
+  hipStream_t st_ = c->sd[k];
+  float* d0 = c->d_d0 + (size_t)lo * 512;
+  float* d1 = c->d_d1 + (size_t)lo * 1280;
+  { ProfScope ps(c, K_DEC_S0, st_);
+    hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), st_,
+                       M.d_dec0, d_feat, d_ids, B, c->d_state, d0); }
+  { ProfScope ps(c, K_DEC_S1, st_);
+    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(256), dec_s1_lds_bytes(), st_,
+                       M.d_dec1, d0, d_ids, B, c->d_state, d1); }
+  { ProfScope ps(c, K_DEC_S2, st_);
+    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), st_,
+                       M.d_dec2, d1, d_ids, B, c->d_state, d_pcm); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
   return 0;
 }
 
 int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
-  { ProfScope ps(c, K_LOGMEL, c->sd);
-    hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd, c->model.d_mel, d_pcm, d_ids, B,
+  { ProfScope ps(c, K_LOGMEL, c->sd[0]);
+    hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, d_pcm, d_ids, B,
                        c->d_state, d_mel); }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -269,10 +311,18 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
     lyra_hip_destroy(c);
     return fail(nullptr, code, "%s", msg.c_str());
   };
-  if (hipStreamCreateWithFlags(&c->se, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->sd, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_enc, hipEventDisableTiming) != hipSuccess)
-    return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
+  {
+    const char* ev = getenv("LYRA_HIP_SUBBATCHES");
+    int ns = ev ? atoi(ev) : 1;  // measured on MI355X at B = 4096: 1 -> 488 us/step, 2 -> 548, 4 -> 737
+    c->nsub = ns < 1 ? 1 : (ns > lyra_hip_ctx::KMAX ? lyra_hip_ctx::KMAX : ns);
+  }
+  for (int k = 0; k < c->nsub; ++k)
+    if (hipStreamCreateWithFlags(&c->se[k], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->sd[k], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_enc[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dec[0][k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dec[1][k], hipEventDisableTiming) != hipSuccess)
+      return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
@@ -280,7 +330,7 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
-  enc_side_done(c);
+  for (int k = 0; k < c->nsub; ++k) enc_side_done(c, k);
   *out = c;
   int rc = lyra_hip_reset_streams(c, nullptr, 0);
   if (rc == 0) rc = sync_all(c);
@@ -291,16 +341,19 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
 void lyra_hip_destroy(lyra_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->se) (void)hipStreamSynchronize(c->se);
-  if (c->sd) (void)hipStreamSynchronize(c->sd);
+  (void)sync_all(c);
   free_scratch(c);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-  if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
+  for (int k = 0; k < lyra_hip_ctx::KMAX; ++k) {
+    if (c->ev_enc[k]) (void)hipEventDestroy(c->ev_enc[k]);
+    if (c->ev_dec[0][k]) (void)hipEventDestroy(c->ev_dec[0][k]);
+    if (c->ev_dec[1][k]) (void)hipEventDestroy(c->ev_dec[1][k]);
+    if (c->se[k]) (void)hipStreamDestroy(c->se[k]);
+    if (c->sd[k]) (void)hipStreamDestroy(c->sd[k]);
+  }
   if (c->d_state) (void)hipFree(c->d_state);
   free_model(&c->model);
-  if (c->se) (void)hipStreamDestroy(c->se);
-  if (c->sd) (void)hipStreamDestroy(c->sd);
   delete c;
 }
 
@@ -310,8 +363,8 @@ const char* lyra_hip_last_error(const lyra_hip_ctx* c) {
   return g_create_error.c_str();
 }
 
-void* lyra_hip_stream(lyra_hip_ctx* c) { return c ? (void*)c->se : nullptr; }
-void* lyra_hip_stream_decode(lyra_hip_ctx* c) { return c ? (void*)c->sd : nullptr; }
+void* lyra_hip_stream(lyra_hip_ctx* c) { return c ? (void*)c->se[0] : nullptr; }
+void* lyra_hip_stream_decode(lyra_hip_ctx* c) { return c ? (void*)c->sd[0] : nullptr; }
 int lyra_hip_synchronize(lyra_hip_ctx* c) {
   if (!c) return LYRA_HIP_EINVAL;
   return sync_all(c);
@@ -325,31 +378,36 @@ int lyra_hip_reset_streams(lyra_hip_ctx* c, const int32_t* ids, int n) {
   int rc = sync_all(c);  // the reset touches encoder and decoder state: nothing may be in flight
   if (rc) return rc;
   if (!ids) {
-    hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->se, c->model.d_reset,
+    hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->se[0], c->model.d_reset,
                        (const int32_t*)nullptr, c->max_streams, 1, c->d_state);
     HIPCHK(c, hipGetLastError());
-    enc_side_done(c);
     return sync_all(c);
   }
   if ((rc = check_batch(c, n))) return rc;
   if ((rc = check_ids_host(c, ids, n))) return rc;
   if ((rc = ensure_scratch(c, n))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->se));
-  hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->se, c->model.d_reset, (const int32_t*)c->d_ids, n, 0,
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->se[0]));
+  hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->se[0], c->model.d_reset, (const int32_t*)c->d_ids, n, 0,
                      c->d_state);
   HIPCHK(c, hipGetLastError());
-  enc_side_done(c);
   return sync_all(c);
 }
 
-// ---- device-pointer variants ------------------------------------------------------------------------------
+// ---- device-pointer variants (asynchronous; split into nsub independent sub-batches) --------------------------
 int lyra_hip_extract_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
   int rc = check_batch(c, B);
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
-  rc = launch_extract(c, d_ids, B, d_pcm, d_feat);
-  enc_side_done(c);
+  const int nk = chunks_for(c, B);
+  for (int k = 0; k < nk && !rc; ++k) {
+    int lo = 0, n = B;
+    if (nk > 1) chunk_of(c, B, k, &lo, &n);
+    if (n <= 0) continue;
+    enc_side_begin(c, k);
+    rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, d_feat + (size_t)lo * 64);
+    enc_side_done(c, k);
+  }
   return rc;
 }
 
@@ -358,16 +416,20 @@ int lyra_hip_rvq_encode_dev(lyra_hip_ctx* c, int B, const float* d_feat, int num
   int rc = check_bits(c, num_bits);
   if (rc) return rc;
   if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
-  rc = launch_rvq_encode(c, B, d_feat, num_bits / 4, d_idx, nullptr);
-  enc_side_done(c);
+  enc_side_begin(c, 0);
+  rc = launch_rvq_encode(c, 0, B, d_feat, num_bits / 4, d_idx, nullptr);
+  enc_side_done(c, 0);
   return rc;
 }
 
 int lyra_hip_rvq_decode_dev(lyra_hip_ctx* c, int B, const int32_t* d_idx, float* d_feat) {
   if (!c) return LYRA_HIP_EINVAL;
   if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
-  dec_side_begin(c);
-  return launch_rvq_decode(c, B, d_idx, nullptr, 46, d_feat);
+  dec_side_begin(c, 0);
+  int rc = launch_rvq_decode(c, 0, B, d_idx, nullptr, 46, d_feat);
+  dec_side_done(c, 0, 1);
+  c->n_dec_calls++;
+  return rc;
 }
 
 int lyra_hip_generate_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
@@ -375,16 +437,28 @@ int lyra_hip_generate_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const fl
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
-  dec_side_begin(c);
-  return launch_generate(c, d_ids, B, d_feat, d_pcm);
+  const int nk = chunks_for(c, B);
+  for (int k = 0; k < nk && !rc; ++k) {
+    int lo = 0, n = B;
+    if (nk > 1) chunk_of(c, B, k, &lo, &n);
+    if (n <= 0) continue;
+    dec_side_begin(c, k);
+    rc = launch_generate(c, k, lo, d_ids + lo, n, d_feat + (size_t)lo * 64, d_pcm + (size_t)lo * 320);
+    dec_side_done(c, k, nk);
+  }
+  c->n_dec_calls++;
+  return rc;
 }
 
 int lyra_hip_logmel_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
   int rc = check_batch(c, B);
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
-  dec_side_begin(c);
-  return launch_logmel(c, d_ids, B, d_pcm, d_mel);
+  dec_side_begin(c, 0);
+  rc = launch_logmel(c, d_ids, B, d_pcm, d_mel);
+  dec_side_done(c, 0, 1);
+  c->n_dec_calls++;
+  return rc;
 }
 
 int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, int num_bits,
@@ -394,9 +468,18 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
   if ((rc = check_bits(c, num_bits))) return rc;
   if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
-  if ((rc = launch_extract(c, d_ids, B, d_pcm, c->d_feat))) return rc;
-  rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, nullptr, d_packets);
-  enc_side_done(c);
+  const int nbytes = (num_bits + 7) / 8;
+  const int nk = chunks_for(c, B);
+  for (int k = 0; k < nk && !rc; ++k) {
+    int lo = 0, n = B;
+    if (nk > 1) chunk_of(c, B, k, &lo, &n);
+    if (n <= 0) continue;
+    enc_side_begin(c, k);
+    float* feat = c->d_feat + (size_t)lo * 64;
+    rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, feat);
+    if (!rc) rc = launch_rvq_encode(c, k, n, feat, num_bits / 4, nullptr, d_packets + (size_t)lo * nbytes);
+    enc_side_done(c, k);
+  }
   return rc;
 }
 
@@ -407,9 +490,20 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
   if ((rc = check_bits(c, num_bits))) return rc;
   if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = ensure_scratch(c, B))) return rc;
-  dec_side_begin(c);
-  if ((rc = launch_rvq_decode(c, B, nullptr, d_packets, num_bits / 4, c->d_lossy))) return rc;
-  return launch_generate(c, d_ids, B, c->d_lossy, d_pcm);
+  const int nbytes = (num_bits + 7) / 8;
+  const int nk = chunks_for(c, B);
+  for (int k = 0; k < nk && !rc; ++k) {
+    int lo = 0, n = B;
+    if (nk > 1) chunk_of(c, B, k, &lo, &n);
+    if (n <= 0) continue;
+    dec_side_begin(c, k);
+    float* lossy = c->d_lossy + (size_t)lo * 64;
+    rc = launch_rvq_decode(c, k, n, nullptr, d_packets + (size_t)lo * nbytes, num_bits / 4, lossy);
+    if (!rc) rc = launch_generate(c, k, lo, d_ids + lo, n, lossy, d_pcm + (size_t)lo * 320);
+    dec_side_done(c, k, nk);
+  }
+  c->n_dec_calls++;
+  return rc;
 }
 
 // ---- host-pointer variants (synchronous) --------------------------------------------------------------------
@@ -417,18 +511,19 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
   int rc = check_batch(c, B);               \
   if (rc) return rc;                        \
   HIPCHK(c, hipSetDevice(c->device));       \
-  if ((rc = ensure_scratch(c, B))) return rc
+  if ((rc = ensure_scratch(c, B))) return rc; \
+  if ((rc = sync_all(c))) return rc
 
 int lyra_hip_extract(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, float* features) {
   PROLOGUE(c, B);
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se));
-  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se));
-  if ((rc = launch_extract(c, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
-  HIPCHK(c, hipMemcpyAsync(features, c->d_feat, (size_t)B * 256, hipMemcpyDeviceToHost, c->se));
-  enc_side_done(c);
-  HIPCHK(c, hipStreamSynchronize(c->se));
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se[0]));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se[0]));
+  if ((rc = launch_extract(c, 0, 0, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
+  HIPCHK(c, hipMemcpyAsync(features, c->d_feat, (size_t)B * 256, hipMemcpyDeviceToHost, c->se[0]));
+  enc_side_done(c, 0);
+  HIPCHK(c, hipStreamSynchronize(c->se[0]));
   return 0;
 }
 
@@ -439,11 +534,11 @@ int lyra_hip_rvq_encode(lyra_hip_ctx* c, int B, const float* features, int num_b
   if (B <= 0 || !features || !indices) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
   HIPCHK(c, hipSetDevice(c->device));
   if ((rc = ensure_scratch(c, B))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_feat, features, (size_t)B * 256, hipMemcpyHostToDevice, c->se));
-  if ((rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, c->d_idx, nullptr))) return rc;
-  HIPCHK(c, hipMemcpyAsync(indices, c->d_idx, (size_t)B * 46 * 4, hipMemcpyDeviceToHost, c->se));
-  enc_side_done(c);
-  HIPCHK(c, hipStreamSynchronize(c->se));
+  HIPCHK(c, hipMemcpyAsync(c->d_feat, features, (size_t)B * 256, hipMemcpyHostToDevice, c->se[0]));
+  if ((rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, c->d_idx, nullptr))) return rc;
+  HIPCHK(c, hipMemcpyAsync(indices, c->d_idx, (size_t)B * 46 * 4, hipMemcpyDeviceToHost, c->se[0]));
+  enc_side_done(c, 0);
+  HIPCHK(c, hipStreamSynchronize(c->se[0]));
   return 0;
 }
 
@@ -453,11 +548,11 @@ int lyra_hip_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* indices, float* f
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = ensure_scratch(c, B))) return rc;
-  dec_side_begin(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_idx, indices, (size_t)B * 46 * 4, hipMemcpyHostToDevice, c->sd));
-  if ((rc = launch_rvq_decode(c, B, c->d_idx, nullptr, 46, c->d_lossy))) return rc;
-  HIPCHK(c, hipMemcpyAsync(features, c->d_lossy, (size_t)B * 256, hipMemcpyDeviceToHost, c->sd));
-  HIPCHK(c, hipStreamSynchronize(c->sd));
+  dec_side_begin(c, 0);
+  HIPCHK(c, hipMemcpyAsync(c->d_idx, indices, (size_t)B * 46 * 4, hipMemcpyHostToDevice, c->sd[0]));
+  if ((rc = launch_rvq_decode(c, 0, B, c->d_idx, nullptr, 46, c->d_lossy))) return rc;
+  HIPCHK(c, hipMemcpyAsync(features, c->d_lossy, (size_t)B * 256, hipMemcpyDeviceToHost, c->sd[0]));
+  HIPCHK(c, hipStreamSynchronize(c->sd[0]));
   return 0;
 }
 
@@ -465,12 +560,12 @@ int lyra_hip_generate(lyra_hip_ctx* c, const int32_t* ids, int B, const float* f
   PROLOGUE(c, B);
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  dec_side_begin(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd));
-  HIPCHK(c, hipMemcpyAsync(c->d_lossy, features, (size_t)B * 256, hipMemcpyHostToDevice, c->sd));
-  if ((rc = launch_generate(c, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
-  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->sd));
-  HIPCHK(c, hipStreamSynchronize(c->sd));
+  dec_side_begin(c, 0);
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd[0]));
+  HIPCHK(c, hipMemcpyAsync(c->d_lossy, features, (size_t)B * 256, hipMemcpyHostToDevice, c->sd[0]));
+  if ((rc = launch_generate(c, 0, 0, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->sd[0]));
+  HIPCHK(c, hipStreamSynchronize(c->sd[0]));
   return 0;
 }
 
@@ -478,12 +573,12 @@ int lyra_hip_logmel(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* p
   PROLOGUE(c, B);
   if (!pcm || !mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  dec_side_begin(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd));
-  HIPCHK(c, hipMemcpyAsync(c->d_pcm_out, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->sd));
+  dec_side_begin(c, 0);
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd[0]));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_out, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->sd[0]));
   if ((rc = launch_logmel(c, c->d_ids_dec, B, c->d_pcm_out, c->d_mel))) return rc;
-  HIPCHK(c, hipMemcpyAsync(mel, c->d_mel, (size_t)B * 160 * 4, hipMemcpyDeviceToHost, c->sd));
-  HIPCHK(c, hipStreamSynchronize(c->sd));
+  HIPCHK(c, hipMemcpyAsync(mel, c->d_mel, (size_t)B * 160 * 4, hipMemcpyDeviceToHost, c->sd[0]));
+  HIPCHK(c, hipStreamSynchronize(c->sd[0]));
   return 0;
 }
 
@@ -493,13 +588,13 @@ int lyra_hip_encode(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* p
   if (!pcm || !packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
   const int nbytes = (num_bits + 7) / 8;
-  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se));
-  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se));
-  if ((rc = launch_extract(c, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
-  if ((rc = launch_rvq_encode(c, B, c->d_feat, num_bits / 4, nullptr, c->d_pkt))) return rc;
-  HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->se));
-  enc_side_done(c);
-  HIPCHK(c, hipStreamSynchronize(c->se));
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se[0]));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se[0]));
+  if ((rc = launch_extract(c, 0, 0, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
+  if ((rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, nullptr, c->d_pkt))) return rc;
+  HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->se[0]));
+  enc_side_done(c, 0);
+  HIPCHK(c, hipStreamSynchronize(c->se[0]));
   return 0;
 }
 
@@ -509,15 +604,15 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
   if (!pcm || !packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
   const int nbytes = (num_bits + 7) / 8;
-  dec_side_begin(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd));
+  dec_side_begin(c, 0);
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd[0]));
   // decode-side packet staging reuses the idx scratch (the encode side owns d_pkt)
   uint8_t* d_pk = reinterpret_cast<uint8_t*>(c->d_idx);
-  HIPCHK(c, hipMemcpyAsync(d_pk, packets, (size_t)B * nbytes, hipMemcpyHostToDevice, c->sd));
-  if ((rc = launch_rvq_decode(c, B, nullptr, d_pk, num_bits / 4, c->d_lossy))) return rc;
-  if ((rc = launch_generate(c, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
-  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->sd));
-  HIPCHK(c, hipStreamSynchronize(c->sd));
+  HIPCHK(c, hipMemcpyAsync(d_pk, packets, (size_t)B * nbytes, hipMemcpyHostToDevice, c->sd[0]));
+  if ((rc = launch_rvq_decode(c, 0, B, nullptr, d_pk, num_bits / 4, c->d_lossy))) return rc;
+  if ((rc = launch_generate(c, 0, 0, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->sd[0]));
+  HIPCHK(c, hipStreamSynchronize(c->sd[0]));
   return 0;
 }
 

@@ -18,39 +18,55 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
                                                           const float* __restrict__ feats, int B, int num_stages,
                                                           int32_t* __restrict__ indices,
                                                           uint8_t* __restrict__ packets) {
-  __shared__ __attribute__((aligned(16))) float cbs[2][16 * 68];
+  // Codebooks are staged through LDS in windows of W stages, double-buffered: window w+1 is fetched from L2
+  // while window w computes (a whole window of compute hides the load latency; one barrier per window).
+  constexpr int W = 4, WFLOATS = W * 16 * 68;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float cbs[2][WFLOATS];
   const int tid = threadIdx.x;
   const int j = tid & 15;
   const int frame = blockIdx.x * 16 + (tid >> 4);
   const int f = min(frame, B - 1);
-  const int ldrow = tid >> 4, ldc4 = tid & 15;  // this thread's float4 of a stage's [16][64] codebook
-  *reinterpret_cast<f32x4*>(&cbs[0][ldrow * 68 + ldc4 * 4]) =
-      *reinterpret_cast<const f32x4*>(&cb[(size_t)ldrow * 64 + ldc4 * 4]);
-  float r[64];
+  const int ldrow = tid >> 4, ldc4 = tid & 15;  // this thread's float4 of each stage's [16][64] codebook
+  f32x4 nxt[W];
+#pragma unroll
+  for (int u = 0; u < W; ++u)
+    nxt[u] = *reinterpret_cast<const f32x4*>(&cb[((size_t)min(u, 45) * 16 + ldrow) * 64 + ldc4 * 4]);
+  f32x2 r[32];  // the residual, replicated in the 16 code lanes of a frame (packed pairs -> v_pk_* math)
 #pragma unroll
   for (int d4 = 0; d4 < 16; ++d4) {
     f32x4 v = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + d4 * 4]);
-    r[d4 * 4 + 0] = v[0]; r[d4 * 4 + 1] = v[1]; r[d4 * 4 + 2] = v[2]; r[d4 * 4 + 3] = v[3];
+    r[d4 * 2] = (f32x2){v[0], v[1]};
+    r[d4 * 2 + 1] = (f32x2){v[2], v[3]};
   }
   const int nbytes = (num_stages + 1) >> 1;
   int cur = 0;
 #pragma unroll 1
   for (int k = 0; k < num_stages; ++k) {
-    __syncthreads();  // stage k rows visible; everyone is done with the buffer stage k+1 will land in
-    f32x4 nxt = {0.f, 0.f, 0.f, 0.f};
-    if (k + 1 < num_stages)
-      nxt = *reinterpret_cast<const f32x4*>(&cb[((size_t)(k + 1) * 16 + ldrow) * 64 + ldc4 * 4]);
-    const float* c = cbs[k & 1];
+    const int u = k & (W - 1), win = k / W;
+    if (u == 0) {
+      // window `win` -> LDS (its loads were issued a window ago), then request window win+1
+#pragma unroll
+      for (int v = 0; v < W; ++v)
+        *reinterpret_cast<f32x4*>(&cbs[win & 1][v * 16 * 68 + ldrow * 68 + ldc4 * 4]) = nxt[v];
+#pragma unroll
+      for (int v = 0; v < W; ++v)
+        nxt[v] = *reinterpret_cast<const f32x4*>(&cb[((size_t)min((win + 1) * W + v, 45) * 16 + ldrow) * 64 + ldc4 * 4]);
+      __syncthreads();  // window visible; (the previous barrier already guarantees nobody still reads this buffer:
+                        //  it was last read two windows ago, and every thread passed the barrier in between)
+    }
+    const float* c = cbs[win & 1] + u * 16 * 68;
     float sum = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < 16; ++d4) {
       f32x4 cv = *reinterpret_cast<const f32x4*>(&c[j * 68 + d4 * 4]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float df = r[d4 * 4 + e] - cv[e];
-        float sq = df * df;
-        sum = sum + sq;
-      }
+      f32x2 df0 = r[d4 * 2] - (f32x2){cv[0], cv[1]};
+      f32x2 df1 = r[d4 * 2 + 1] - (f32x2){cv[2], cv[3]};
+      f32x2 sq0 = df0 * df0, sq1 = df1 * df1;
+      sum = sum + sq0[0];
+      sum = sum + sq0[1];
+      sum = sum + sq1[0];
+      sum = sum + sq1[1];
     }
     int best = j;
     float bd = sum;
@@ -68,14 +84,12 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
 #pragma unroll
     for (int d4 = 0; d4 < 16; ++d4) {
       f32x4 qv = *reinterpret_cast<const f32x4*>(&c[best * 68 + d4 * 4]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t1 = qv[e] - r[d4 * 4 + e];
-        float t2 = r[d4 * 4 + e] + t1;
-        r[d4 * 4 + e] = r[d4 * 4 + e] - t2;
-      }
+      f32x2 q0 = {qv[0], qv[1]}, q1 = {qv[2], qv[3]};
+      f32x2 t10 = q0 - r[d4 * 2], t11 = q1 - r[d4 * 2 + 1];       // the graph's three separate fp32 ops
+      f32x2 t20 = r[d4 * 2] + t10, t21 = r[d4 * 2 + 1] + t11;
+      r[d4 * 2] = r[d4 * 2] - t20;
+      r[d4 * 2 + 1] = r[d4 * 2 + 1] - t21;
     }
-    if (k + 1 < num_stages) *reinterpret_cast<f32x4*>(&cbs[(k + 1) & 1][ldrow * 68 + ldc4 * 4]) = nxt;
     if (j == 0 && frame < B) {
       if (indices) indices[(size_t)frame * 46 + k] = best;
       if (packets) {

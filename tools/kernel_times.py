@@ -15,18 +15,12 @@ pcm = torch.randint(-32768, 32768, (10 + N, B, 320), generator=g, device=dev, dt
 ids = torch.arange(B, device=dev, dtype=torch.int32)
 pks = [torch.empty((B, 23), device=dev, dtype=torch.uint8) for _ in range(2)]
 outs = [torch.empty((B, 320), device=dev, dtype=torch.int16) for _ in range(2)]
-s_enc = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
-s_dec = torch.cuda.ExternalStream(ctx.stream_handle_decode(), device=dev)
-evs = [torch.cuda.Event(), torch.cuda.Event()]
 SERIAL = os.environ.get("SERIAL") == "1"
 
 
 def step(i):
-    if i >= 2:
-        s_enc.wait_event(evs[i & 1])
     ctx.encode_dev(ids, pcm[i], bits, pks[i & 1])
     ctx.decode_dev(ids, pks[i & 1], bits, outs[i & 1])
-    evs[i & 1].record(s_dec)
     if SERIAL:
         ctx.synchronize()
 torch.cuda.synchronize()
