@@ -119,6 +119,25 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     const int R2 = 2 * d;
     const int off = r == 0 ? off0 : (r == 1 ? off1 : off2);
     LYRA_TSTAMP(10 + r * 8 + 0);
+    // 0. request the history rows this lane will need (HBM latency overlaps the a-write and the barrier)
+    f32x4 h0[5], h1[5];
+    const float LYRA_GLOBAL* hist[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int s = (S >= 4) ? (e & (S - 1)) : 0;  // with S >= 4 a lane's four rows are four streams at one t
+      hist[e] = as_global(reinterpret_cast<const float*>(cx.sbase(s) + off));
+    }
+    static_assert(S == 4 || S == 8, "row -> (t, s) mapping below");
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / S, s = R & (S - 1);
+        const float LYRA_GLOBAL* hp = (S == 4) ? hist[e] : as_global(reinterpret_cast<const float*>(cx.sbase(s) + off));
+        const int t0 = t - 2 * d, t1 = t - d;
+        h0[i][e] = t0 < 0 ? hp[(R2 + t0) * 64 + pcol] : 0.f;
+        h1[i][e] = t1 < 0 ? hp[(R2 + t1) * 64 + pcol] : 0.f;
+      }
     // 1. a = lrelu(X) -> A
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -126,7 +145,7 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
       for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = lrelu(xr[i][0][e]);
     __syncthreads();
     LYRA_TSTAMP(10 + r * 8 + 1);
-    // 2. depthwise k3 (dilation d) for the elements this lane owns; history rows come from HBM
+    // 2. depthwise k3 (dilation d) for the elements this lane owns
     f32x4 dreg[5];
     {
       const float LYRA_GLOBAL* w = as_global(dws[r].w);
@@ -137,16 +156,9 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / S, s = R & (S - 1);
-          const float* hist = reinterpret_cast<const float*>(cx.sbase(s) + off);
           const int t0 = t - 2 * d, t1 = t - d;
-#ifdef LYRA_ABL_NOHIST
-          float v0 = A[((t0 >= 0 ? t0 : 0) * S + s) * CS + pcol];
-          float v1 = A[((t1 >= 0 ? t1 : 0) * S + s) * CS + pcol];
-          (void)hist;
-#else
-          float v0 = t0 >= 0 ? A[(t0 * S + s) * CS + pcol] : hist[(R2 + t0) * 64 + pcol];
-          float v1 = t1 >= 0 ? A[(t1 * S + s) * CS + pcol] : hist[(R2 + t1) * 64 + pcol];
-#endif
+          float v0 = t0 >= 0 ? A[(t0 * S + s) * CS + pcol] : h0[i][e];
+          float v1 = t1 >= 0 ? A[(t1 * S + s) * CS + pcol] : h1[i][e];
           float v2 = A[R * CS + pcol];
           float acc = __builtin_fmaf(v0, w0, 0.f);
           acc = __builtin_fmaf(v1, w1, acc);
