@@ -8,6 +8,12 @@
 // one 16-row MFMA tile.
 #include "resblock_q.h"
 
+#ifdef LYRA_TIMING
+extern "C" int lyra_hip_debug_timing_s2(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_tdbg), sizeof(long long) * 128);
+}
+#endif
+
 namespace lyra {
 
 namespace {
@@ -47,6 +53,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * S2;
   const int mode = P.mode;
+  LYRA_TSTAMP(0);
   if (tid < S2) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
@@ -63,6 +70,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
   }
   __syncthreads();
 
+  LYRA_TSTAMP(1);
   // ---- resblock 0, fp32 half: depthwise (dil 1, history 2 rows, replaced) + pointwise 256->256 ----
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
@@ -85,6 +93,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
       *reinterpret_cast<f32x4*>(cx.sbase(s) + st::E_R2_0 + (j * 256 + p4 * 4) * 4) =
           lrelu4(*reinterpret_cast<const f32x4*>(&XF[(j * S2 + s) * CS2 + p4 * 4]));
   }
+  LYRA_TSTAMP(2);
   {  // pointwise fp32 -> QUANTIZE -> int8 LeakyReLU -> QP
     f32x4 acc[MT2][2];
     auto aoff = [&](int i, int c) { return (i * 16 + m) * CS2 + c * 16 + q * 4; };
@@ -103,6 +112,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
     }
   }
   __syncthreads();
+  LYRA_TSTAMP(3);
   {  // grouped 1x1 int8 (4 groups 64->64) -> DEQUANTIZE + float skip -> QUANTIZE = X1
     i32x4 acc[MT2][2];
     const int g = wave >> 1;
@@ -126,10 +136,13 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
   }
   __syncthreads();
 
+  LYRA_TSTAMP(4);
   // ---- int8 resblocks 1, 2 (dilation 3 / 9; ring histories of 6 / 18 rows, T = 2) ---------------
   resblock_q256<S2>(QX, QA, QD, QP, cx, 3, st::E_R2_1, P.lr[1], P.lr[2], P.dwq[0], P.pwq[0], P.cvq[0], P.add[0], mode);
+  LYRA_TSTAMP(5);
   resblock_q256<S2>(QX, QA, QD, QP, cx, 9, st::E_R2_2, P.lr[3], P.lr[4], P.dwq[1], P.pwq[1], P.cvq[1], P.add[1], mode);
 
+  LYRA_TSTAMP(6);
   // ---- int8 LeakyReLU, 2-row history (replaced), conv k4/s2 g4 -> [1][512] --------------------------
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int w4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
@@ -147,6 +160,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
       *reinterpret_cast<int*>(cx.sbase(s) + st::E_D2 + t * 256 + w4 * 4) =
           *reinterpret_cast<const int*>(&QB4[((2 + t) * S2 + s) * QS + w4 * 4]);
   }
+  LYRA_TSTAMP(7);
   i32x4 dacc[1][4];
   {  // GEMM rows = streams (rows >= S are over-read padding and discarded)
     const int g = wave >> 1;
@@ -180,6 +194,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
       *reinterpret_cast<int*>(cx.sbase(s) + st::E_BOTT + slot * 512 + w4 * 4) =
           *reinterpret_cast<const int*>(&QC[(2 * S2 + s) * QS5 + w4 * 4]);
   }
+  LYRA_TSTAMP(8);
   // ---- bottleneck conv k3 g4: per group K = 3*128, N = 16 -> 64 int8 codes ----------------------------
   if (wave < 4) {
     i32x4 acc[1][1];
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
       }
     }
   }
+  LYRA_TSTAMP(9);
   if (tid < S2 && cx.valid(tid)) {
     int ph = sphase[tid] + 1;
     *reinterpret_cast<int*>(cx.sbase(tid) + st::ENC_PHASE) = ph >= st::PHASE_MOD ? 0 : ph;

@@ -49,22 +49,27 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
 // ---------------------------------------------------------------------------------------------
 // fixed point (TFLite common.h semantics; same formulas as oracle/lyra_oracle.c)
 // ---------------------------------------------------------------------------------------------
+// SaturatingRoundingDoublingHighMul: gemmlowp nudges by +2^30 (ab >= 0) or 1-2^30 (ab < 0) and divides by 2^31
+// truncating toward zero -- which is exactly floor((ab + 2^30) / 2^31), i.e. round-half-up, for either sign.
+// Done on the 32-bit halves of the product (v_mul_lo / v_mul_hi_i32 + carry) instead of 64-bit VALU sequences.
 __device__ __forceinline__ int32_t srdhm(int32_t a, int32_t b) {
-  if (a == INT32_MIN && b == INT32_MIN) return INT32_MAX;
-  int64_t ab = (int64_t)a * (int64_t)b;
-  int64_t nudge = ab >= 0 ? (1ll << 30) : (1 - (1ll << 30));
-  return (int32_t)((ab + nudge) / (1ll << 31));
+  const uint32_t lo = (uint32_t)a * (uint32_t)b;
+  int32_t hi = __mulhi(a, b);
+  const uint32_t lo2 = lo + 0x40000000u;
+  hi += (lo2 < lo) ? 1 : 0;
+  const int32_t r = (int32_t)(((uint32_t)hi << 1) | (lo2 >> 31));
+  return (a == INT32_MIN && b == INT32_MIN) ? INT32_MAX : r;
 }
 __device__ __forceinline__ int32_t rdivpot(int32_t x, int e) {
-  int32_t mask = (int32_t)((1ll << e) - 1);
-  int32_t rem = x & mask;
-  int32_t thr = (mask >> 1) + (x < 0 ? 1 : 0);
+  const int32_t mask = (int32_t)((1u << e) - 1u);
+  const int32_t rem = x & mask;
+  const int32_t thr = (mask >> 1) + (x < 0 ? 1 : 0);
   return (x >> e) + (rem > thr ? 1 : 0);
 }
 __device__ __forceinline__ int32_t mbqm_double(int32_t x, int32_t M, int shift) {
-  int left = shift > 0 ? shift : 0;
-  int right = shift > 0 ? 0 : -shift;
-  return rdivpot(srdhm((int32_t)((int64_t)x * (1ll << left)), M), right);
+  const int left = shift > 0 ? shift : 0;
+  const int right = shift > 0 ? 0 : -shift;
+  return rdivpot(srdhm((int32_t)((uint32_t)x << left), M), right);
 }
 __device__ __forceinline__ int32_t mbqm_exact(int32_t x, int32_t M, int shift) {
   int total = 31 - shift;

@@ -20,6 +20,9 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int R2 = 2 * d;
+  const int tb = d == 3 ? 20 : 30;
+  (void)tb;
+  LYRA_TSTAMP(tb + 0);
   for (int idx = tid; idx < 2 * S * 64; idx += NT) {
     int w4 = idx & 63, rs = idx >> 6;
     int w = *reinterpret_cast<const int*>(&QX[rs * QS + w4 * 4]);
@@ -27,6 +30,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
         pack8(lrelu_q(sx8(w, 0), la), lrelu_q(sx8(w, 1), la), lrelu_q(sx8(w, 2), la), lrelu_q(sx8(w, 3), la));
   }
   __syncthreads();
+  LYRA_TSTAMP(tb + 1);
   for (int idx = tid; idx < 2 * S * 64; idx += NT) {
     int w4 = idx & 63, s = (idx >> 6) & (S - 1), t = (idx >> 6) / S;
     int base = (cx.sphase[s] * 2) % R2;
@@ -55,6 +59,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
     *reinterpret_cast<int*>(&QD[(t * S + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
   }
   __syncthreads();
+  LYRA_TSTAMP(tb + 2);
   for (int idx = tid; idx < 2 * S * 64; idx += NT) {
     int w4 = idx & 63, s = (idx >> 6) & (S - 1), t = (idx >> 6) / S;
     int row = (cx.sphase[s] * 2) % R2 + t;
@@ -63,6 +68,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
       *reinterpret_cast<int*>(cx.sbase(s) + off + row * 256 + w4 * 4) =
           *reinterpret_cast<const int*>(&QA[(t * S + s) * QS + w4 * 4]);
   }
+  LYRA_TSTAMP(tb + 3);
   {
     i32x4 acc[MT][2];
     auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
@@ -81,6 +87,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD
     }
   }
   __syncthreads();
+  LYRA_TSTAMP(tb + 4);
   {
     i32x4 acc[MT][2];
     const int g = wave >> 1;

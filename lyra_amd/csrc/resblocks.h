@@ -119,7 +119,11 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     const int R2 = 2 * d;
     const int off = r == 0 ? off0 : (r == 1 ? off1 : off2);
     LYRA_TSTAMP(10 + r * 8 + 0);
-    // 0. request the history rows this lane will need (HBM latency overlaps the a-write and the barrier)
+    // 0. request the per-channel depthwise parameters and the history rows this lane will need
+    //    (L2 / HBM latency overlaps the a-write and the barrier)
+    const float LYRA_GLOBAL* dww = as_global(dws[r].w);
+    const float w0 = dww[pcol], w1 = dww[64 + pcol], w2 = dww[128 + pcol];
+    const float bb = as_global(dws[r].b)[pcol];
     f32x4 h0[5], h1[5];
     const float LYRA_GLOBAL* hist[4];
 #pragma unroll
@@ -148,9 +152,6 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     // 2. depthwise k3 (dilation d) for the elements this lane owns
     f32x4 dreg[5];
     {
-      const float LYRA_GLOBAL* w = as_global(dws[r].w);
-      const float w0 = w[pcol], w1 = w[64 + pcol], w2 = w[128 + pcol];
-      const float bb = as_global(dws[r].b)[pcol];
 #pragma unroll
       for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -186,8 +187,8 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     auto aoff = [&](int i, int c) { return ((wm * 5 + i) * 16 + m) * CS + c * 16 + q * 4; };
     {  // 4. pointwise 64 -> 64, LeakyReLU -> A
       f32x4 acc[5][1];
-      gemm_f32<5, 1, 4>(A, aoff, pws[r].w + wn * 4 * 64, acc);
       float bias = as_global(pws[r].b)[ncol];
+      gemm_f32<5, 1, 4>(A, aoff, pws[r].w + wn * 4 * 64, acc);
       LYRA_TSTAMP(10 + r * 8 + 5);
       __syncthreads();
 #pragma unroll
@@ -199,8 +200,8 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     }
     {  // 5. 1x1 conv 64 -> 64 + residual (registers)
       f32x4 acc[5][1];
-      gemm_f32<5, 1, 4>(A, aoff, cvs[r].w + wn * 4 * 64, acc);
       float bias = as_global(cvs[r].b)[ncol];
+      gemm_f32<5, 1, 4>(A, aoff, cvs[r].w + wn * 4 * 64, acc);
 #pragma unroll
       for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -268,12 +269,15 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
     {  // pointwise 128 -> 128, LeakyReLU
       f32x4 acc[MT][NTW];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + c * 16 + q * 4; };
+      float biasv[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) biasv[j] = as_global(pws[r].b)[(wave * NTW + j) * 16 + (lane & 15)];
       gemm_f32<MT, NTW, 8>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, acc);
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int ncol = (wave * NTW + j) * 16 + (lane & 15);
-        const float bias = as_global(pws[r].b)[ncol];
+        const float bias = biasv[j];
         const int pcol = at16(ncol);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -286,11 +290,14 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
       f32x4 acc[MT][NTW];
       const int g = (wave * NTW) >> 2;
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + g * 64 + c * 16 + q * 4; };
+      float biasv[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) biasv[j] = as_global(cvs[r].b)[(wave * NTW + j) * 16 + (lane & 15)];
       gemm_f32<MT, NTW, 4>(D, aoff, cvs[r].w + (wave * NTW) * 4 * 64, acc);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int ncol = (wave * NTW + j) * 16 + (lane & 15);
-        const float bias = as_global(cvs[r].b)[ncol];
+        const float bias = biasv[j];
         const int pcol = at16(ncol);
 #pragma unroll
         for (int i = 0; i < MT; ++i)

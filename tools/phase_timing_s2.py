@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+os.environ["LYRA_HIP_LIB"] = os.path.join(ROOT, "lyra_amd", "variants", "timing.so")
+import lyra_amd
+ctx = lyra_amd.LyraHip(max_streams=4096)
+pcm = np.random.default_rng(0).integers(-32768, 32768, size=(4096, 320)).astype(np.int16)
+for _ in range(3):
+    ctx.extract(pcm)
+buf = (ctypes.c_longlong * 128)()
+ctx.L.lyra_hip_debug_timing_s2(buf)
+t = np.array(buf[:])
+names = ["ids+phase", "load XF", "dw0+state", "pw0 gemm+q", "r0b gemm+X1", "resblock1", "resblock2", "lrelu+d2 hist", "down2+bott hist", "bott+feats"]
+print("enc_s2 total", t[9] - t[0])
+for i in range(1, 10):
+    print(f"  {names[i]:18s} {t[i] - t[i-1]:7d}")
+for base in (20, 30):
+    print("  resblock@", base, " lrelu", t[base+1]-t[base], " dw", t[base+2]-t[base+1], " statewr", t[base+3]-t[base+2], " pw gemm+epi", t[base+4]-t[base+3])
