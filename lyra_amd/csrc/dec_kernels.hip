@@ -13,6 +13,15 @@
 // the bias removed, as the graph does.
 #include "resblock_q.h"
 
+#ifdef LYRA_TIMING
+extern "C" int lyra_hip_debug_timing_d0(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_tdbg), sizeof(long long) * 128);
+}
+extern "C" int lyra_hip_debug_wgtrace_d0(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_wgtrace), sizeof(long long) * 2048 * 4);
+}
+#endif
+
 namespace lyra {
 
 // =============================================================================================
@@ -30,14 +39,19 @@ constexpr int MTD0 = (2 * SD0) / 16;
 constexpr int FB_FLOATS = 3 * 16 * FS;      // sized for a full 16-row M tile (rows >= S are padding)
 constexpr int XF_FLOATS = 2 * SD0 * CS2;
 constexpr int H8_BYTES = 16 * QS5;
-constexpr int QB_BYTES = 2 * 16 * QS;       // 2 M tiles of 16 rows: the up1 GEMM reads [t][16 rows]
-static_assert(SD0 == 8 || SD0 == 16, "tile sizes the index math below supports");
+constexpr int QB_BYTES = 2 * SD0 * QS;      // [2][S] rows = one 16-row M tile
+constexpr int QA_BYTES = 2 * 16 * QS;       // 2 M tiles of 16 rows: the up1 GEMM reads [t][16 rows]
+constexpr int NLR = 6, NADD = 2;            // LeakyReLU / ADD lookup tables (resblock_q.h)
+static_assert(SD0 == 8, "tile size the index math below supports");
 }  // namespace
 
-size_t dec_s0_lds_bytes() { return (size_t)(FB_FLOATS + XF_FLOATS) * 4 + H8_BYTES + 4 * QB_BYTES + 2 * SD0 * 4; }
+size_t dec_s0_lds_bytes() {
+  return (size_t)(FB_FLOATS + XF_FLOATS) * 4 + H8_BYTES + 3 * QB_BYTES + QA_BYTES + 2 * SD0 * 4 + NLR * 256 +
+         NADD * 2048;
+}
 int dec_s0_streams_per_wg() { return SD0; }
 
-__global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+__global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                        const int32_t* __restrict__ ids, int B,
                                                        uint8_t* __restrict__ state, float* __restrict__ out0) {
   const DecS0P& P = *Pp;
@@ -47,19 +61,26 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
   int8_t* H8 = reinterpret_cast<int8_t*>(XF + XF_FLOATS);  // [16][544]
   int8_t* QX = H8 + H8_BYTES;
   int8_t* QA = QX + QB_BYTES;
-  int8_t* QD = QA + QB_BYTES;
+  int8_t* QD = QA + QA_BYTES;
   int8_t* QP = QD + QB_BYTES;
   int* sids = reinterpret_cast<int*>(QP + QB_BYTES);
   int* sphase = sids + SD0;
+  int32_t* LA = sphase + SD0;                                // [NADD][2][256] ADD operand tables
+  int8_t* LQ = reinterpret_cast<int8_t*>(LA + NADD * 512);   // [NLR][256] LeakyReLU tables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * SD0;
   const int mode = P.mode;
+  LYRA_TSTAMP(40);
+  LYRA_WSTAMP(100);
+  LYRA_WG_BEGIN();
   if (tid < SD0) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
     sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
   }
+  load_luts<NTD0>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
+  const auto warm = l2_warm<NTD0, 1>(P.warm);
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
 
@@ -83,6 +104,7 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
       *reinterpret_cast<f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4) =
           *reinterpret_cast<const f32x4*>(&FB[(2 * 16 + s) * FS + p4 * 4]);
   }
+  LYRA_TSTAMP(41);
   {  // conv k3 g4: per group [16 rows] x K=48 x N=128; LeakyReLU; QUANTIZE -> H8
     f32x4 acc[1][4];
     const int g = wave >> 1;
@@ -98,6 +120,7 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
     }
   }
   __syncthreads();
+  LYRA_TSTAMP(42);
   {  // 4 grouped int8 transposed convs k4/s2 (one input row -> 4 output rows), carried tail of 2 rows
     i32x4 acc[1][8];
     const int g = wave >> 1;
@@ -129,13 +152,16 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
     }
   }
   __syncthreads();
+  LYRA_TSTAMP(43);
   // ---- a0 = QUANTIZE(lrelu(x164)) ------------------------------------------------------------------
   for (int idx = tid; idx < 2 * SD0 * 256; idx += NTD0) {
     int c = idx & 255, rs = idx >> 8;
     QA[rs * QS + c] = (int8_t)quantize_f(lrelu(XF[rs * CS2 + at16(c)]), P.q1.s, P.q1.z);
   }
   __syncthreads();
+  LYRA_TSTAMP(44);
   // ---- resblock 0 (int8 body, float skip): dilation 1, history of 2 rows (replaced) -----------------
+  const RbqPre pre1 = resblock_q_prefetch<SD0>(cx, 3, st::D_R0_1, P.dwq[1], P.pwq[1], P.cvq[1]);
   {
     const DwQ dq = P.dwq[0];
     for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
@@ -149,7 +175,7 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
         else w = *reinterpret_cast<const int*>(cx.sbase(s) + st::D_R0_0 + (2 + tau) * 256 + w4 * 4);
         int ww = *reinterpret_cast<const int*>(&dq.w[j * 256 + w4 * 4]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += (sx8(w, e) - dq.zin) * sx8(ww, e);
+        for (int e = 0; e < 4; ++e) acc[e] += sx8(w, e) * sx8(ww, e);   // zero point folded into dq.b
       }
       int o[4];
 #pragma unroll
@@ -179,7 +205,7 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.pwq[0].zout);
-            QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lrelu_q(c8, P.lr[0]);
+            QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lut8(LQ, c8);
           }
       }
     }
@@ -207,17 +233,22 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
     }
     __syncthreads();
   }
-  resblock_q256<SD0>(QX, QA, QD, QP, cx, 3, st::D_R0_1, P.lr[1], P.lr[2], P.dwq[1], P.pwq[1], P.cvq[1], P.add[0], mode);
-  resblock_q256<SD0>(QX, QA, QD, QP, cx, 9, st::D_R0_2, P.lr[3], P.lr[4], P.dwq[2], P.pwq[2], P.cvq[2], P.add[1], mode);
+  LYRA_TSTAMP(45);
+  const RbqPre pre2 = resblock_q_prefetch<SD0>(cx, 9, st::D_R0_2, P.dwq[2], P.pwq[2], P.cvq[2]);
+  resblock_q256<SD0>(QX, QD, QP, cx, 3, st::D_R0_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[1], P.pwq[1], P.cvq[1],
+                     P.add[0], LA, mode, pre1, 20);
+  resblock_q256<SD0>(QX, QD, QP, cx, 9, st::D_R0_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[2], P.pwq[2], P.cvq[2],
+                     P.add[1], LA + 512, mode, pre2, 30);
+  LYRA_TSTAMP(46);
   // a = int8 LeakyReLU(X3), laid out for the up1 GEMM as [t][16 rows][QS] (rows s >= S are padding)
   for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
     int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
     int w = *reinterpret_cast<const int*>(&QX[(t * SD0 + s) * QS + w4 * 4]);
     *reinterpret_cast<int*>(&QA[(t * 16 + s) * QS + w4 * 4]) =
-        pack8(lrelu_q(sx8(w, 0), P.lr[5]), lrelu_q(sx8(w, 1), P.lr[5]), lrelu_q(sx8(w, 2), P.lr[5]),
-              lrelu_q(sx8(w, 3), P.lr[5]));
+        lut8w(LQ + 5 * 256, w);
   }
   __syncthreads();
+  LYRA_TSTAMP(47);
   {  // 2 grouped int8 transposed convs k4/s2: rows t=0,1 -> 6 output rows (integer overlap-add), tail of 2
     i32x4 acc[2][4];
     const int g = wave >> 2, ct = wave & 3;
@@ -261,6 +292,10 @@ __global__ __launch_bounds__(NTD0) void dec_s0_kernel(const DecS0P* __restrict__
       }
     }
   }
+  LYRA_TSTAMP(48);
+  LYRA_WSTAMP(101);
+  LYRA_WG_END();
+  l2_warm_sink(warm, state, B);
 }
 
 // =============================================================================================
@@ -293,6 +328,7 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
     sids[tid] = id;
     sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
   }
+  const auto warm = l2_warm<NTD1, 2>(P.warm);
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
@@ -350,6 +386,7 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
         }
     }
   }
+  l2_warm_sink(warm, state, B);
 }
 
 // =============================================================================================
@@ -381,6 +418,7 @@ __global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restric
     sids[tid] = id;
     sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
   }
+  const auto warm = l2_warm<NTD2, 1>(P.warm);
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
   const int wn = wave & 3, wm = wave >> 2;
@@ -446,6 +484,7 @@ __global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restric
     int ph = sphase[tid] + 1;
     *reinterpret_cast<int*>(cx.sbase(tid) + st::DEC_PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
   }
+  l2_warm_sink(warm, state, B);
 }
 
 }  // namespace lyra

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   for (int k = (int)(((blockIdx.x >> 8) + (blockIdx.x >> 3)) & 3) * LYRA_STAGGER; k > 0; --k) __builtin_amdgcn_s_sleep(32);
 #endif
   if (tid < S0) sids[tid] = ids[min(b0 + tid, B - 1)];
+  const auto warm = l2_warm<NT0, 1>(P.warm);
   __syncthreads();
   auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B; };
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
     }
   }
   LYRA_TSTAMP(6);
+  l2_warm_sink(warm, state, B);
 }
 
 // =============================================================================================
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict
     sids[tid] = id;
     sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::ENC_PHASE);
   }
+  const auto warm = l2_warm<NT1, 2>(P.warm);
   __syncthreads();
   auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B; };
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict
         }
     }
   }
+  l2_warm_sink(warm, state, B);
 }
 
 }  // namespace lyra

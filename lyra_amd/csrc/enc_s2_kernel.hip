@@ -12,6 +12,9 @@
 extern "C" int lyra_hip_debug_timing_s2(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_tdbg), sizeof(long long) * 128);
 }
+extern "C" int lyra_hip_debug_wgtrace_s2(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_wgtrace), sizeof(long long) * 2048 * 4);
+}
 #endif
 
 namespace lyra {
@@ -25,15 +28,16 @@ constexpr int NT2 = 512;
 constexpr int MT2 = (2 * S2) / 16;          // M tiles of a [2][S] matrix
 constexpr int XF_BYTES = 2 * S2 * CS2 * 4;
 constexpr int QB_BYTES = 2 * S2 * QS;
+constexpr int NLR = 7, NADD = 2;            // LeakyReLU / ADD lookup tables (resblock_q.h)
 static_assert(S2 == 8 || S2 == 16, "tile sizes the index math below supports");
-static_assert(4 * S2 * QS + 16 * QS <= XF_BYTES && 3 * S2 * QS5 + 16 * QS5 <= XF_BYTES + 4 * QB_BYTES,
+static_assert(4 * S2 * QS + 16 * QS <= XF_BYTES && 3 * S2 * QS5 + 16 * QS5 <= XF_BYTES + 3 * QB_BYTES,
               "aliased int8 staging buffers (incl. the rows a partial M tile over-reads) must fit");
 }  // namespace
 
-size_t enc_s2_lds_bytes() { return (size_t)2 * XF_BYTES + 4 * QB_BYTES + 2 * S2 * 4; }
+size_t enc_s2_lds_bytes() { return (size_t)2 * XF_BYTES + 3 * QB_BYTES + 2 * S2 * 4 + NLR * 256 + NADD * 2048; }
 int enc_s2_streams_per_wg() { return S2; }
 
-__global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+__global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, float* __restrict__ feats,
                                                       float* __restrict__ codes_dbg) {
@@ -42,11 +46,12 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
   float* DF = smem;                                  // [2][S][CS2] depthwise out; later int8 staging QB4
   float* XF = DF + 2 * S2 * CS2;                     // [2][S][CS2] stage input (float skip); later QC (with QX..)
   int8_t* QX = reinterpret_cast<int8_t*>(XF + 2 * S2 * CS2);  // residual stream (int8)
-  int8_t* QA = QX + QB_BYTES;
-  int8_t* QD = QA + QB_BYTES;
+  int8_t* QD = QX + QB_BYTES;
   int8_t* QP = QD + QB_BYTES;
   int* sids = reinterpret_cast<int*>(QP + QB_BYTES);
   int* sphase = sids + S2;
+  int32_t* LA = sphase + S2;                         // [NADD][2][256] ADD operand tables
+  int8_t* LQ = reinterpret_cast<int8_t*>(LA + NADD * 512);  // [NLR][256] LeakyReLU tables
   int8_t* QB4 = reinterpret_cast<int8_t*>(DF);       // [4][S][QS]   (aliases DF once it is dead)
   int8_t* QC = reinterpret_cast<int8_t*>(XF);        // [3][S][QS5]  (aliases XF and, past it, QX.. once dead)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,13 +59,18 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
   const int b0 = blockIdx.x * S2;
   const int mode = P.mode;
   LYRA_TSTAMP(0);
+  LYRA_WSTAMP(100);
+  LYRA_WG_BEGIN();
   if (tid < S2) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
     sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::ENC_PHASE);
   }
+  load_luts<NT2>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
+  const auto warm = l2_warm<NT2, 1>(P.warm);
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
+  const RbqPre pre1 = resblock_q_prefetch<S2>(cx, 3, st::E_R2_1, P.dwq[0], P.pwq[0], P.cvq[0]);
 
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int q8 = quantize_f(acc[i][j][e] + bias, P.q_r0.s, P.q_r0.z);
-          QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lrelu_q(q8, P.lr[0]);
+          QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lut8(LQ, q8);
         }
     }
   }
@@ -138,9 +148,12 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
 
   LYRA_TSTAMP(4);
   // ---- int8 resblocks 1, 2 (dilation 3 / 9; ring histories of 6 / 18 rows, T = 2) ---------------
-  resblock_q256<S2>(QX, QA, QD, QP, cx, 3, st::E_R2_1, P.lr[1], P.lr[2], P.dwq[0], P.pwq[0], P.cvq[0], P.add[0], mode);
+  const RbqPre pre2 = resblock_q_prefetch<S2>(cx, 9, st::E_R2_2, P.dwq[1], P.pwq[1], P.cvq[1]);
+  resblock_q256<S2>(QX, QD, QP, cx, 3, st::E_R2_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[0], P.pwq[0], P.cvq[0], P.add[0],
+                    LA, mode, pre1, 20);
   LYRA_TSTAMP(5);
-  resblock_q256<S2>(QX, QA, QD, QP, cx, 9, st::E_R2_2, P.lr[3], P.lr[4], P.dwq[1], P.pwq[1], P.cvq[1], P.add[1], mode);
+  resblock_q256<S2>(QX, QD, QP, cx, 9, st::E_R2_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[1], P.pwq[1], P.cvq[1], P.add[1],
+                    LA + 512, mode, pre2, 30);
 
   LYRA_TSTAMP(6);
   // ---- int8 LeakyReLU, 2-row history (replaced), conv k4/s2 g4 -> [1][512] --------------------------
@@ -148,8 +161,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
     int w4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
     int w = *reinterpret_cast<const int*>(&QX[(t * S2 + s) * QS + w4 * 4]);
     *reinterpret_cast<int*>(&QB4[((2 + t) * S2 + s) * QS + w4 * 4]) =
-        pack8(lrelu_q(sx8(w, 0), P.lr[5]), lrelu_q(sx8(w, 1), P.lr[5]), lrelu_q(sx8(w, 2), P.lr[5]),
-              lrelu_q(sx8(w, 3), P.lr[5]));
+        lut8w(LQ + 5 * 256, w);
     *reinterpret_cast<int*>(&QB4[(t * S2 + s) * QS + w4 * 4]) =
         *reinterpret_cast<const int*>(cx.sbase(s) + st::E_D2 + t * 256 + w4 * 4);
   }
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
     for (int e = 0; e < 4; ++e) {
       int s = q * 4 + e;
       int c8 = clamp8(requant(dacc[0][j][e] + bias, M, sh, mode) + P.down2.zout);
-      if (s < S2) QC[(2 * S2 + s) * QS5 + n] = (int8_t)lrelu_q(c8, P.lr[6]);
+      if (s < S2) QC[(2 * S2 + s) * QS5 + n] = (int8_t)lut8(LQ + 6 * 256, c8);
     }
   }
   __syncthreads();
@@ -214,10 +226,13 @@ __global__ __launch_bounds__(NT2) void enc_s2_kernel(const EncS2P* __restrict__ 
     }
   }
   LYRA_TSTAMP(9);
+  LYRA_WSTAMP(101);
+  LYRA_WG_END();
   if (tid < S2 && cx.valid(tid)) {
     int ph = sphase[tid] + 1;
     *reinterpret_cast<int*>(cx.sbase(tid) + st::ENC_PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
   }
+  l2_warm_sink(warm, state, B);
 }
 
 }  // namespace lyra

@@ -6,16 +6,19 @@
 namespace lyra {
 
 // ---- encoder ---------------------------------------------------------------------------------
-struct EncS0P { ConvF first; DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF down; };
-struct EncS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF down; };
+struct EncS0P { ConvF first; DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF down; WarmRange warm; };
+struct EncS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF down; WarmRange warm; };
 struct EncS2P {
   DwF dw0; ConvF pw0;
   QP q_r0, dq_r0, q_x1, out;
   LreluQ lr[7];
+  const int8_t* lr_lut;    // [7][256]   lrelu_q tabulated (model.hip lrelu_luts)
+  const int32_t* add_lut;  // [2][2][256] ADD operand rescalings
   ConvQ r0b;
   DwQ dwq[2]; ConvQ pwq[2]; ConvQ cvq[2]; AddQ add[2];
   ConvQ down2, bott;
   int mode;
+  WarmRange warm;
 };
 
 __global__ void enc_s0_kernel(const EncS0P* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* out0);
@@ -37,12 +40,15 @@ struct DecS0P {
   QP q1;                      // QUANTIZE of lrelu(x164)
   DwQ dwq[3]; ConvQ pwq[3]; ConvQ cvq[3];
   LreluQ lr[6]; AddQ add[2];
+  const int8_t* lr_lut;       // [6][256]
+  const int32_t* add_lut;     // [2][2][256]
   QP dq_r0, q3;               // DEQUANTIZE of resblock-0 conv out; QUANTIZE of (conv + float skip)
   TconvQ up1[2]; QP up1_dq[2]; const float* up1_sub[2];
   int mode;
+  WarmRange warm;
 };
-struct DecS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; const float* up_sub; };
-struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; };
+struct DecS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; const float* up_sub; WarmRange warm; };
+struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; WarmRange warm; };
 
 __global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0);
 __global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);

@@ -56,6 +56,27 @@ QM quantize_multiplier(double d) {
   return r;
 }
 
+// Host restatement of gemmlowp's fixed-point primitives (TFLite common.h MultiplyByQuantizedMultiplier), used only
+// to tabulate the int8 LeakyReLU / ADD operand rescalings below; the kernels' lyra_dev.h versions are the same
+// functions on 32-bit halves.
+int32_t h_srdhm(int32_t a, int32_t b) {
+  if (a == INT32_MIN && b == INT32_MIN) return INT32_MAX;
+  long long ab = (long long)a * (long long)b;
+  long long nudge = ab >= 0 ? (1ll << 30) : (1 - (1ll << 30));
+  return (int32_t)((ab + nudge) / (1ll << 31));
+}
+int32_t h_rdivpot(int32_t x, int e) {
+  int32_t mask = (int32_t)((1ll << e) - 1);
+  int32_t rem = x & mask;
+  int32_t thr = (mask >> 1) + (x < 0 ? 1 : 0);
+  return (x >> e) + (rem > thr ? 1 : 0);
+}
+int32_t h_mbqm(int32_t x, int32_t M, int shift) {
+  int left = shift > 0 ? shift : 0, right = shift > 0 ? 0 : -shift;
+  return h_rdivpot(h_srdhm((int32_t)((uint32_t)x << left), M), right);
+}
+int32_t h_clamp8(int32_t v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
+
 class Arena {
  public:
   template <class T>
@@ -66,6 +87,7 @@ class Arena {
     return off;
   }
   const std::vector<uint8_t>& bytes() const { return buf_; }
+  size_t aligned_size() const { return (buf_.size() + 255) / 256 * 256; }
 
  private:
   std::vector<uint8_t> buf_;
@@ -80,6 +102,11 @@ struct Builder {
   void put(P* field, const std::vector<T>& v) {
     size_t off = arena.push(v);
     fixups.emplace_back((void*)field, off);
+  }
+  size_t mark() const { return arena.aligned_size(); }
+  void range(WarmRange* r, size_t begin) {
+    r->bytes = (uint32_t)(arena.aligned_size() - begin);
+    fixups.emplace_back((void*)&r->base, begin);
   }
   std::string key(const char* pre, const char* kind, int idx, const char* leaf) const {
     return std::string(pre) + "." + kind + "." + std::to_string(idx) + "." + leaf;
@@ -193,13 +220,17 @@ struct Builder {
     const float* ws = pk.data<float>(key(pre, "dw", idx, "wscale"));
     if (!e || !w || !b || !q || !ws) return;
     int k = e->shape[0], C = e->shape[1];
-    std::vector<int32_t> M(C), sh(C);
+    const int zin = (int)q[1];
+    std::vector<int32_t> M(C), sh(C), bf(C);
     for (int c = 0; c < C; ++c) {
       QM m = quantize_multiplier((double)q[0] * (double)ws[c] / (double)q[2]);
       M[c] = m.m; sh[c] = m.shift;
+      long long sum = 0;
+      for (int j = 0; j < k; ++j) sum += w[(size_t)j * C + c];
+      bf[c] = (int32_t)(b[c] - (long long)zin * sum);  // the kernel accumulates raw codes
     }
     put(&out->w, std::vector<int8_t>(w, w + (size_t)k * C));
-    put(&out->b, std::vector<int32_t>(b, b + C));
+    put(&out->b, bf);
     put(&out->M, M);
     put(&out->sh, sh);
     out->zin = (int)q[1];
@@ -263,6 +294,27 @@ struct Builder {
     out->z1 = (int)q[1]; out->z2 = (int)q[3]; out->zo = (int)q[5];
     out->m1 = m1.m; out->s1 = m1.shift; out->m2 = m2.m; out->s2 = m2.shift; out->mo = mo.m; out->so = mo.shift;
   }
+  // int8 LeakyReLU tabulated over its 256 possible inputs: lut[i][c + 128] = lrelu_q(c)
+  void lrelu_luts(const LreluQ* L, int n, const int8_t** out) {
+    std::vector<int8_t> lut((size_t)n * 256);
+    for (int i = 0; i < n; ++i)
+      for (int c = -128; c < 128; ++c) {
+        int32_t v = c - L[i].zin;
+        int32_t r = v >= 0 ? h_mbqm(v, L[i].mpos, L[i].spos) : h_mbqm(v, L[i].mneg, L[i].sneg);
+        lut[(size_t)i * 256 + c + 128] = (int8_t)h_clamp8(r + L[i].zout);
+      }
+    put(out, lut);
+  }
+  // int8 ADD: the two operand rescalings, lut[i][0][a + 128] and lut[i][1][b + 128] (int32)
+  void add_luts(const AddQ* A, int n, const int32_t** out) {
+    std::vector<int32_t> lut((size_t)n * 512);
+    for (int i = 0; i < n; ++i)
+      for (int c = -128; c < 128; ++c) {
+        lut[(size_t)i * 512 + c + 128] = h_mbqm((c - A[i].z1) * (1 << 20), A[i].m1, A[i].s1);
+        lut[(size_t)i * 512 + 256 + c + 128] = h_mbqm((c - A[i].z2) * (1 << 20), A[i].m2, A[i].s2);
+      }
+    put(out, lut);
+  }
   QP qp(const char* pre, const char* kind, int idx) {
     const float* q = pk.data<float>(key(pre, kind, idx, "q"));
     QP r{1.f, 0};
@@ -279,18 +331,27 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   const int32_t* ver = pk.data<int32_t>("meta.version");
   if (!ver || ver[0] != 3) { *err = "weight container version identifier is not 3 (lyra_config.h:145-166)"; return false; }
   Builder B{pk};
+  // Each kernel's weights are packed contiguously so that the kernel can warm its XCD's L2 / TLBs with one
+  // pass over [warm.base, warm.base + warm.bytes) (l2_warm in lyra_dev.h).
   // ---- encoder (op numbering: tools/pack_weights.py) ----------------------------------
+  size_t mark = B.mark();
   B.conv_f("enc", 0, &M->enc0.first);
   for (int r = 0; r < 3; ++r) {
     B.dw_f("enc", r, &M->enc0.dw[r]);
     B.conv_f("enc", 1 + 2 * r, &M->enc0.pw[r]);
     B.conv_f("enc", 2 + 2 * r, &M->enc0.cv[r]);
+  }
+  B.conv_f("enc", 7, &M->enc0.down);
+  B.range(&M->enc0.warm, mark);
+  mark = B.mark();
+  for (int r = 0; r < 3; ++r) {
     B.dw_f("enc", 3 + r, &M->enc1.dw[r]);
     B.conv_f("enc", 8 + 2 * r, &M->enc1.pw[r]);
     B.conv_f("enc", 9 + 2 * r, &M->enc1.cv[r]);
   }
-  B.conv_f("enc", 7, &M->enc0.down);
   B.conv_f("enc", 14, &M->enc1.down);
+  B.range(&M->enc1.warm, mark);
+  mark = B.mark();
   EncS2P& E2 = M->enc2;
   B.dw_f("enc", 6, &E2.dw0);
   B.conv_f("enc", 15, &E2.pw0);
@@ -299,6 +360,7 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   E2.q_x1 = B.qp("enc", "quant", 1);
   E2.out = B.qp("enc", "dequant", 9);
   for (int i = 0; i < 7; ++i) B.lrelu_q("enc", i, &E2.lr[i]);
+  B.lrelu_luts(E2.lr, 7, &E2.lr_lut);
   B.conv_q("enc", 16, &E2.r0b);
   for (int r = 0; r < 2; ++r) {
     B.dw_q("enc", 7 + r, &E2.dwq[r]);
@@ -306,10 +368,13 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
     B.conv_q("enc", 18 + 2 * r, &E2.cvq[r]);
     B.add_q("enc", r, &E2.add[r]);
   }
+  B.add_luts(E2.add, 2, &E2.add_lut);
   B.conv_q("enc", 21, &E2.down2);
   B.conv_q("enc", 22, &E2.bott);
   E2.mode = requant_mode;
+  B.range(&E2.warm, mark);
   // ---- decoder -----------------------------------------------------------------------------
+  mark = B.mark();
   DecS0P& D0 = M->dec0;
   B.conv_f("dec", 0, &D0.head);
   D0.q0 = B.qp("dec", "quant", 0);
@@ -322,6 +387,8 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   }
   for (int i = 0; i < 6; ++i) B.lrelu_q("dec", i, &D0.lr[i]);
   for (int i = 0; i < 2; ++i) B.add_q("dec", i, &D0.add[i]);
+  B.lrelu_luts(D0.lr, 6, &D0.lr_lut);
+  B.add_luts(D0.add, 2, &D0.add_lut);
   {
     const float* q = pk.data<float>("dec.conv.2.q");  // output quantisation of resblock-0's grouped conv
     if (q) { D0.dq_r0.s = q[2]; D0.dq_r0.z = (int)q[3]; }
@@ -329,24 +396,31 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   D0.q3 = B.qp("dec", "quant", 3);
   for (int g = 0; g < 2; ++g) B.tconv_q("dec", 4 + g, &D0.up1[g], &D0.up1_dq[g], &D0.up1_sub[g], 4 + g);
   D0.mode = requant_mode;
+  B.range(&D0.warm, mark);
+  mark = B.mark();
   for (int r = 0; r < 3; ++r) {
     B.dw_f("dec", 3 + r, &M->dec1.dw[r]);
     B.conv_f("dec", 7 + 2 * r, &M->dec1.pw[r]);
     B.conv_f("dec", 8 + 2 * r, &M->dec1.cv[r]);
-    B.dw_f("dec", 6 + r, &M->dec2.dw[r]);
-    B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r]);
-    B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r]);
   }
   B.tconv_f("dec", 6, &M->dec1.up, nullptr);
   {
     const float* sc = pk.data<float>("dec.sub.6.c");
     if (sc) B.put(&M->dec1.up_sub, std::vector<float>(sc, sc + 64));
   }
+  B.range(&M->dec1.warm, mark);
+  mark = B.mark();
+  for (int r = 0; r < 3; ++r) {
+    B.dw_f("dec", 6 + r, &M->dec2.dw[r]);
+    B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r]);
+    B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r]);
+  }
   B.tconv_f("dec", 7, &M->dec2.up, nullptr);
   {
     const float* sc = pk.data<float>("dec.sub.7.c");
     if (sc) M->dec2.up_sub = sc[0];
   }
+  B.range(&M->dec2.warm, mark);
   // ---- RVQ codebooks -------------------------------------------------------------------------------------
   {
     const float* cb = pk.data<float>("rvq.codebooks");

@@ -1,6 +1,16 @@
 // resblock_q.h -- the int8 residual block at 256 channels x 2 rows shared by encoder stage 2 and decoder
-// stage 0 (graph ops 107-133 of soundstream_encoder.tflite / 93-117 of lyragan.tflite).
-// QX residual stream, QA/QD/QP scratch, all [2][S][288] int8.  Ring history of R2 = 2*d rows, T = 2.
+// stage 0 (graph ops 107-133 of soundstream_encoder.tflite / 93-117 of lyragan.tflite), plus the lookup
+// tables that replace the int8 LeakyReLU / ADD rescaling arithmetic.
+//
+// These stages are bound by VALU issue (fixed-point emulation) and by exposed global-load latency, not by
+// MFMA or HBM, so:
+//   * int8 LeakyReLU is a function of one int8 code -> a 256-byte table in LDS (built on the host with the
+//     same gemmlowp arithmetic, model.hip lrelu_luts); the int8 ADD's two operand rescalings are int32 tables.
+//   * thread (s, w4) owns channels 4*w4..4*w4+3 of stream s for BOTH rows of the frame, so LeakyReLU ->
+//     depthwise conv -> history write are thread-local (no LDS round trip, no barrier);
+//   * every global load a block needs (ring history words, per-channel requantisation parameters) is issued
+//     by resblock_q_prefetch() ahead of the previous phase's work.
+// QX residual stream, QD/QP scratch, all [2][S][288] int8.  Ring history of R2 = 2*d rows, T = 2.
 #pragma once
 #include "resblocks.h"
 
@@ -11,104 +21,135 @@ __device__ __forceinline__ int pack8(int a, int b, int c, int d) {
   return (a & 255) | ((b & 255) << 8) | ((c & 255) << 16) | ((d & 255) << 24);
 }
 
+// ---- lookup tables (LDS) ----------------------------------------------------------------------------
+__device__ __forceinline__ int lut8(const int8_t* lut, int c8) { return (int)lut[c8 + 128]; }
+// four packed codes at once
+__device__ __forceinline__ int lut8w(const int8_t* lut, int w) {
+  const uint32_t u = (uint32_t)w ^ 0x80808080u;
+  return pack8(lut[u & 255], lut[(u >> 8) & 255], lut[(u >> 16) & 255], lut[u >> 24]);
+}
+__device__ __forceinline__ int add_q_lut(const int32_t* lut, int a, int b, const AddQ& L) {
+  return clamp8(mbqm_double(lut[a + 128] + lut[256 + b + 128], L.mo, L.so) + L.zo);
+}
+// copies n_lr LeakyReLU tables and n_add ADD tables from the weight arena to LDS (caller syncs)
+template <int NT>
+__device__ __forceinline__ void load_luts(int8_t* LQ, const int8_t* lr_lut, int n_lr, int32_t* LA,
+                                          const int32_t* add_lut, int n_add) {
+  for (int i = threadIdx.x; i < n_lr * 64; i += NT)
+    reinterpret_cast<int*>(LQ)[i] = reinterpret_cast<const int*>(lr_lut)[i];
+  for (int i = threadIdx.x; i < n_add * 512; i += NT) LA[i] = add_lut[i];
+}
+
+// ---- per-thread prefetch of everything global a block touches -------------------------------------------
+struct RbqPre {
+  int h[2][2];        // ring history words: [t][0] = row t - 2d, [t][1] = row t - d
+  int ww[3];          // depthwise taps, 4 channels each
+  i32x4 b, M, sh;     // depthwise requantisation, 4 channels
+  int pb[2], pM[2], psh[2];   // pointwise epilogue (2 N tiles)
+  int cb[2], cM[2], csh[2];   // grouped-conv epilogue
+};
+
 template <int S>
-__device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QA, int8_t* QD, int8_t* QP, const TileCtx& cx,
-                                              int d, int off, const LreluQ& la, const LreluQ& lm, const DwQ& dq,
-                                              const ConvQ& pw, const ConvQ& cv, const AddQ& add, int mode) {
-  // rows = (t, s) -> t * S + s, T = 2; S = 16: two M tiles, S = 8: one.
-  constexpr int QS = 288, NT = 512, MT = (2 * S) / 16;
+__device__ __forceinline__ RbqPre resblock_q_prefetch(const TileCtx& cx, int d, int off, const DwQ& dq,
+                                                      const ConvQ& pw, const ConvQ& cv) {
+  static_assert(S == 8, "thread <-> (stream, channel word) mapping below assumes 8 streams x 64 words = 512 threads");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w4 = tid & 63, s = tid >> 6;
+  const int R2 = 2 * d;
+  const int base = (cx.sphase[s] * 2) % R2;
+  RbqPre p;
+  const uint8_t* hp = cx.sbase(s) + off + w4 * 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int r1 = base + t + d;
+    r1 = r1 >= R2 ? r1 - R2 : r1;
+    p.h[t][0] = *reinterpret_cast<const int*>(hp + (base + t) * 256);   // row t - 2d (about to be replaced)
+    p.h[t][1] = *reinterpret_cast<const int*>(hp + r1 * 256);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) p.ww[j] = *reinterpret_cast<const int*>(&dq.w[j * 256 + w4 * 4]);
+  p.b = *reinterpret_cast<const i32x4*>(&dq.b[w4 * 4]);
+  p.M = *reinterpret_cast<const i32x4*>(&dq.M[w4 * 4]);
+  p.sh = *reinterpret_cast<const i32x4*>(&dq.sh[w4 * 4]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int n = (wave * 2 + j) * 16 + (lane & 15);
+    p.pb[j] = pw.b[n]; p.pM[j] = pw.M[n]; p.psh[j] = pw.sh[n];
+    p.cb[j] = cv.b[n]; p.cM[j] = cv.M[n]; p.csh[j] = cv.sh[n];
+  }
+  return p;
+}
+
+// la / lm: LDS tables of the block's two LeakyReLUs; addlut: LDS table pair of its ADD.
+template <int S>
+__device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP, const TileCtx& cx, int d, int off,
+                                              const int8_t* la, const int8_t* lm, const DwQ& dq, const ConvQ& pw,
+                                              const ConvQ& cv, const AddQ& add, const int32_t* addlut, int mode,
+                                              const RbqPre& pre, int tb) {
+  static_assert(S == 8, "see resblock_q_prefetch");
+  constexpr int QS = 288;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
+  const int w4 = tid & 63, s = tid >> 6;
   const int R2 = 2 * d;
-  const int tb = d == 3 ? 20 : 30;
   (void)tb;
   LYRA_TSTAMP(tb + 0);
-  for (int idx = tid; idx < 2 * S * 64; idx += NT) {
-    int w4 = idx & 63, rs = idx >> 6;
-    int w = *reinterpret_cast<const int*>(&QX[rs * QS + w4 * 4]);
-    *reinterpret_cast<int*>(&QA[rs * QS + w4 * 4]) =
-        pack8(lrelu_q(sx8(w, 0), la), lrelu_q(sx8(w, 1), la), lrelu_q(sx8(w, 2), la), lrelu_q(sx8(w, 3), la));
+  {  // a = LeakyReLU(X); depthwise over [a(t-2d), a(t-d), a(t)]; the ring row t-2d is replaced by a(t)
+    const int base = (cx.sphase[s] * 2) % R2;
+    uint8_t* hp = cx.sbase(s) + off + w4 * 4;
+    const bool valid = cx.valid(s);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int a = lut8w(la, *reinterpret_cast<const int*>(&QX[(t * S + s) * QS + w4 * 4]));
+      if (valid) *reinterpret_cast<int*>(hp + (base + t) * 256) = a;
+      const int x[3] = {pre.h[t][0], pre.h[t][1], a};
+      int o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int acc = pre.b[e];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += sx8(x[j], e) * sx8(pre.ww[j], e);
+        o[e] = clamp8(requant(acc, pre.M[e], pre.sh[e], mode) + dq.zout);
+      }
+      *reinterpret_cast<int*>(&QD[(t * S + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
+    }
   }
   __syncthreads();
   LYRA_TSTAMP(tb + 1);
-  for (int idx = tid; idx < 2 * S * 64; idx += NT) {
-    int w4 = idx & 63, s = (idx >> 6) & (S - 1), t = (idx >> 6) / S;
-    int base = (cx.sphase[s] * 2) % R2;
-    int acc[4] = {0, 0, 0, 0};
+  {
+    i32x4 acc[1][2];
+    auto aoff = [&](int i, int c) { return m * QS + c * 64 + q * 16; };
+    gemm_i8<1, 2, 4>(QD, aoff, pw.w + (wave * 2) * 4 * 64, acc);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      int tau = t - (2 - j) * d;
-      int w;
-      if (tau >= 0) {
-        w = *reinterpret_cast<const int*>(&QA[(tau * S + s) * QS + w4 * 4]);
-      } else {
-        int row = base + tau + R2;
-        row = row >= R2 ? row - R2 : row;
-        w = *reinterpret_cast<const int*>(cx.sbase(s) + off + row * 256 + w4 * 4);
+    for (int j = 0; j < 2; ++j) {
+      int n = (wave * 2 + j) * 16 + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int c8 = clamp8(requant(acc[0][j][e] + pre.pb[j], pre.pM[j], pre.psh[j], mode) + pw.zout);
+        QP[(q * 4 + e) * QS + n] = (int8_t)lut8(lm, c8);
       }
-      int ww = *reinterpret_cast<const int*>(&dq.w[j * 256 + w4 * 4]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += (sx8(w, e) - dq.zin) * sx8(ww, e);
     }
-    int o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int c = w4 * 4 + e;
-      o[e] = clamp8(requant(acc[e] + dq.b[c], dq.M[c], dq.sh[c], mode) + dq.zout);
-    }
-    *reinterpret_cast<int*>(&QD[(t * S + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
   }
   __syncthreads();
   LYRA_TSTAMP(tb + 2);
-  for (int idx = tid; idx < 2 * S * 64; idx += NT) {
-    int w4 = idx & 63, s = (idx >> 6) & (S - 1), t = (idx >> 6) / S;
-    int row = (cx.sphase[s] * 2) % R2 + t;
-    row = row >= R2 ? row - R2 : row;
-    if (cx.valid(s))
-      *reinterpret_cast<int*>(cx.sbase(s) + off + row * 256 + w4 * 4) =
-          *reinterpret_cast<const int*>(&QA[(t * S + s) * QS + w4 * 4]);
-  }
-  LYRA_TSTAMP(tb + 3);
   {
-    i32x4 acc[MT][2];
-    auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
-    gemm_i8<MT, 2, 4>(QD, aoff, pw.w + (wave * 2) * 4 * 64, acc);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int n = (wave * 2 + j) * 16 + (lane & 15);
-      int bias = pw.b[n], M = pw.M[n], sh = pw.sh[n];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + pw.zout);
-          QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lrelu_q(c8, lm);
-        }
-    }
-  }
-  __syncthreads();
-  LYRA_TSTAMP(tb + 4);
-  {
-    i32x4 acc[MT][2];
+    i32x4 acc[1][2];
     const int g = wave >> 1;
-    auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 64 + q * 16; };
-    gemm_i8<MT, 2, 1>(QP, aoff, cv.w + (wave * 2) * 64, acc);
+    auto aoff = [&](int i, int c) { return m * QS + g * 64 + q * 16; };
+    gemm_i8<1, 2, 1>(QP, aoff, cv.w + (wave * 2) * 64, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
-      int bias = cv.b[n], M = cv.M[n], sh = cv.sh[n];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int row = i * 16 + q * 4 + e;
-          int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + cv.zout);
-          QX[row * QS + n] = (int8_t)add_q(c8, (int)QX[row * QS + n], add);
-        }
+      for (int e = 0; e < 4; ++e) {
+        int row = q * 4 + e;
+        int c8 = clamp8(requant(acc[0][j][e] + pre.cb[j], pre.cM[j], pre.csh[j], mode) + cv.zout);
+        QX[row * QS + n] = (int8_t)add_q_lut(addlut, c8, (int)QX[row * QS + n], add);
+      }
     }
   }
   __syncthreads();
+  LYRA_TSTAMP(tb + 3);
 }
-
 
 }  // namespace lyra

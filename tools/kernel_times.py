@@ -6,7 +6,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 import torch
 import lyra_amd
-B, bits = 4096, 184
+B, bits = int(os.environ.get("B", 4096)), 184
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device("cuda", 0)
 ctx = lyra_amd.LyraHip(max_streams=B)

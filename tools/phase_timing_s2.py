@@ -17,4 +17,6 @@ print("enc_s2 total", t[9] - t[0])
 for i in range(1, 10):
     print(f"  {names[i]:18s} {t[i] - t[i-1]:7d}")
 for base in (20, 30):
-    print("  resblock@", base, " lrelu", t[base+1]-t[base], " dw", t[base+2]-t[base+1], " statewr", t[base+3]-t[base+2], " pw gemm+epi", t[base+4]-t[base+3])
+    print("  resblock@", base, " lrelu+dw+state", t[base+1]-t[base], " pw gemm+epi", t[base+2]-t[base+1], " cv gemm+add", t[base+3]-t[base+2])
+wall = (t[101] - t[100]) / 100.0  # wall_clock64 ticks at 100 MHz
+print(f"  WG0 wall {wall:.1f} us  -> shader clock {(t[9]-t[0])/wall/1e3:.2f} GHz")
