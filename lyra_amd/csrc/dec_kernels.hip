@@ -110,13 +110,14 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
     const int g = wave >> 1;
     auto aoff = [&](int i, int c) { return (c * 16 + m) * FS + g * 16 + q * 4; };
     gemm_f32<1, 4, 3>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, acc);
+    fold_rows8<2>(acc[0]);   // rows = 8 streams: lanes 32-63 take over N tiles 2, 3
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int n = (wave * 4 + j) * 16 + (lane & 15);
+    for (int j = 0; j < 2; ++j) {
+      int n = (wave * 4 + j + 2 * (lane >> 5)) * 16 + (lane & 15);
       float bias = P.head.b[n];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        H8[(q * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0.s, P.q0.z);
+        H8[((q & 1) * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0.s, P.q0.z);
     }
   }
   __syncthreads();
@@ -127,19 +128,20 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
     const TconvQ U = P.up0[g];
     auto aoff = [&](int i, int c) { return m * QS5 + g * 128 + c * 64 + q * 16; };
     gemm_i8<1, 8, 2>(H8, aoff, U.w + ((wave & 1) * 8) * 2 * 64, acc);
+    fold_rows8<4>(acc[0]);   // lanes 32-63 take over this wave's second channel tile (N tiles 4..7)
+    const int ct = (wave & 1) * 2 + (lane >> 5);
+    const int co = ct * 16 + (lane & 15);
+    const int bias = U.bias[co];
+    const float sub = P.up0_sub[g][co];
+    const int pc = at16(g * 64 + co);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ct = (wave & 1) * 2 + (j >> 2), tap = j & 3;
-      const int co = ct * 16 + (lane & 15);
-      const int zf = U.zfold[tap * 64 + co], bias = U.bias[co];
-      const float sub = P.up0_sub[g][co];
-      const int pc = at16(g * 64 + co);
+    for (int tap = 0; tap < 4; ++tap) {
+      const int zf = U.zfold[tap * 64 + co];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int s = q * 4 + e;
-        if (s >= SD0) continue;
+        const int s = (q & 1) * 4 + e;
         float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP0 + g * 512);
-        int c8 = clamp8(requant(acc[0][j][e] + zf + bias, U.M, U.sh, mode) + U.zout);
+        int c8 = clamp8(requant(acc[0][tap][e] + zf + bias, U.M, U.sh, mode) + U.zout);
         float y = dequantize_f(c8, P.up0_dq[g].s, P.up0_dq[g].z);
         if (tap < 2) {
           y = y + stp[tap * 64 + co];

@@ -187,15 +187,16 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
     *reinterpret_cast<int*>(&QC[(j * S2 + s) * QS5 + w4 * 4]) =
         *reinterpret_cast<const int*>(cx.sbase(s) + st::E_BOTT + slot * 512 + w4 * 4);
   }
+  fold_rows8<2>(dacc[0]);   // lanes 32-63 take over N tiles 2, 3
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int n = (wave * 4 + j) * 16 + (lane & 15);
+  for (int j = 0; j < 2; ++j) {
+    int n = (wave * 4 + j + 2 * (lane >> 5)) * 16 + (lane & 15);
     int bias = P.down2.b[n], M = P.down2.M[n], sh = P.down2.sh[n];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      int s = q * 4 + e;
+      int s = (q & 1) * 4 + e;
       int c8 = clamp8(requant(dacc[0][j][e] + bias, M, sh, mode) + P.down2.zout);
-      if (s < S2) QC[(2 * S2 + s) * QS5 + n] = (int8_t)lut8(LQ + 6 * 256, c8);
+      QC[(2 * S2 + s) * QS5 + n] = (int8_t)lut8(LQ + 6 * 256, c8);
     }
   }
   __syncthreads();

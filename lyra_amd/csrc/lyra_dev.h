@@ -209,6 +209,28 @@ __device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32
   }
 }
 
+// A 16-row tile whose rows 8..15 are padding (GEMM rows = 8 streams) leaves lanes 32-63 idle in the epilogue.
+// fold_rows8() moves the valid rows of tile j + H into the upper lanes of tile j (v_permlane32_swap: upper half of
+// the first operand <-> lower half of the second): afterwards lane L holds in acc[j] (j < H) the accumulators of
+// tile j + H * (L >> 5), row ((L >> 4) & 1) * 4 + reg, and every lane carries valid rows.
+template <int H>
+__device__ __forceinline__ void fold_rows8(i32x4 (&acc)[2 * H]) {
+#pragma unroll
+  for (int j = 0; j < H; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc[j][e] = (int)__builtin_amdgcn_permlane32_swap((unsigned)acc[j][e], (unsigned)acc[j + H][e], false, false)[0];
+}
+template <int H>
+__device__ __forceinline__ void fold_rows8(f32x4 (&acc)[2 * H]) {
+#pragma unroll
+  for (int j = 0; j < H; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc[j][e] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][e]),
+                                                                   __float_as_uint(acc[j + H][e]), false, false)[0]);
+}
+
 // C/D layout of every 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 __device__ __forceinline__ int cd_col() { return threadIdx.x & 15; }
 __device__ __forceinline__ int cd_row(int reg) { return (((threadIdx.x & 63) >> 4) << 2) + reg; }
