@@ -307,7 +307,6 @@ namespace {
 constexpr int SD1 = 8;
 constexpr int CS1 = 136;
 constexpr int NTD1 = 256;
-constexpr int MTD1 = (6 * SD1) / 16;   // M tiles of the [6 blocks][S] polyphase GEMM (block 5 is padding)
 }  // namespace
 
 size_t dec_s1_lds_bytes() { return (size_t)(7 * SD1 * CS1 + 4 * SD1 * CS1) * 4 + 2 * SD1 * 4; }
@@ -358,14 +357,30 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
         *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
   }
   __syncthreads();
-  {  // tconv k10/s5, polyphase: blocks b = 0..4 (+1 of padding), rows (b, s); K = [x[b-1] | x[b]] = 256; N = 5 x 64
-    f32x4 acc[MTD1][5];
+  {  // tconv k10/s5, polyphase: output block b (5 rows x 64 ch = N 320) = x[b-1] . W[taps 5..9] then x[b] . W[taps 0..4],
+     // ONE fp32 chain per output (earlier input first).  Pass 1 runs every input row t against taps 5..9 (the
+     // partial chains of block t+1), the C tiles are shifted down by one input row (8 of a tile's 16 rows:
+     // a 32-lane rotation) and become pass 2's initial accumulators; block 4 = x[3] alone is the carried tail.
+    f32x4 acc[2][5];
     auto aoff = [&](int i, int c) {
-      int R = i * 16 + m, b = R / SD1, s = R & (SD1 - 1);
-      int row = (c < 8 ? b - 1 : b) + 1;
-      return (row * SD1 + s) * CS1 + (c & 7) * 16 + q * 4;
+      int R = i * 16 + m, t = R / SD1, s = R & (SD1 - 1);
+      return ((1 + t) * SD1 + s) * CS1 + c * 16 + q * 4;
     };
-    gemm_f32<MTD1, 5, 16>(XB, aoff, P.up.w + (wave * 5) * 16 * 64, acc);
+    const f32x4* wfrag = P.up.w + (wave * 5) * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 5..9, 8-15 taps 0..4
+    gemm_f32<2, 5, 8, 16>(XB, aoff, wfrag, acc);
+    f32x4 tail[5];
+    const bool lo = lane < 32;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = acc[0][j][e], bb = acc[1][j][e];
+        rot32_pair(a, bb);                       // a = [Y(t1), Y(t0)], bb = [Y(t3), Y(t2)]
+        acc[0][j][e] = lo ? 0.f : a;             // blocks 0 | 1  <-  0     | Y(t0)
+        acc[1][j][e] = lo ? a : bb;              // blocks 2 | 3  <-  Y(t1) | Y(t2)
+        tail[j][e] = bb;                         // lanes 0-31: block 4 = Y(t3)
+      }
+    gemm_f32<2, 5, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int n = (wave * 5 + j) * 16 + (lane & 15);
@@ -373,19 +388,24 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
       const float bias = as_global(P.up.b)[co], sub = as_global(P.up_sub)[co];
       const int pc = at16(co);
 #pragma unroll
-      for (int i = 0; i < MTD1; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int R = i * 16 + q * 4 + e, b = R / SD1, s = R & (SD1 - 1);
-          if (b > 4) continue;
           const int tau = 5 * b + jj;
           float y = acc[i][j][e] + bias;
           y = y + (tau < 5 ? SB[(tau * SD1 + s) * 72 + co] : 0.f);
-          if (cx.valid(s)) {
-            if (tau < 20) out1[((size_t)(b0 + s) * 20 + tau) * 64 + pc] = y;
-            else reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[(tau - 20) * 64 + co] = y - sub;
-          }
+          if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + tau) * 64 + pc] = y;
         }
+      if (lo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s = q * 4 + e;
+          float y = tail[j][e] + bias;
+          y = y + 0.f;
+          if (cx.valid(s)) reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y - sub;
+        }
+      }
     }
   }
   l2_warm_sink(warm, state, B);

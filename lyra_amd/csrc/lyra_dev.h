@@ -138,22 +138,26 @@ __device__ __forceinline__ const T LYRA_GLOBAL* as_global(const T* p) {
 #ifndef LYRA_PF_SCALE
 #define LYRA_PF_SCALE 1
 #endif
-template <int MTW, int NTW, int KC,
+//   KS   = K-chunk stride between a tile's fragments in memory (> KC when only part of the packed K range is run)
+//   ZERO = start the chains from 0; otherwise acc carries values in (a chain continued from an earlier GEMM)
+template <int MTW, int NTW, int KC, int KS = KC, bool ZERO = true,
           int PF = LYRA_PF_SCALE * (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
 __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                          f32x4 (&acc)[MTW][NTW]) {
   const int lane = threadIdx.x & 63;
   const f32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic) + lane;
+  if (ZERO) {
 #pragma unroll
-  for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   f32x4 bq[PF + 1][NTW], aq[PF + 1][MTW];
 #pragma unroll
   for (int p = 0; p < PF; ++p)
     if (p < KC) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[p][j] = bfrag[(j * KC + p) * 64];
+      for (int j = 0; j < NTW; ++j) bq[p][j] = bfrag[(j * KS + p) * 64];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[p][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, p));
     }
@@ -162,7 +166,7 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
     if (c + PF < KC) {
       const int sl = (c + PF) % (PF + 1);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[sl][j] = bfrag[(j * KC + c + PF) * 64];
+      for (int j = 0; j < NTW; ++j) bq[sl][j] = bfrag[(j * KS + c + PF) * 64];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[sl][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c + PF));
     }
@@ -229,6 +233,14 @@ __device__ __forceinline__ void fold_rows8(f32x4 (&acc)[2 * H]) {
     for (int e = 0; e < 4; ++e)
       acc[j][e] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][e]),
                                                                    __float_as_uint(acc[j + H][e]), false, false)[0]);
+}
+
+// Rotates two registers by 32 lanes (rows +-8 of a 16-row C tile): a <- [a.hi, a.lo], b <- [b.hi, b.lo].
+__device__ __forceinline__ void rot32_pair(float& a, float& b) {
+  auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);  // [a.lo,b.lo],[a.hi,b.hi]
+  auto r2 = __builtin_amdgcn_permlane32_swap(r1[1], r1[0], false, false);                            // [a.hi,a.lo],[b.hi,b.lo]
+  a = __uint_as_float(r2[0]);
+  b = __uint_as_float(r2[1]);
 }
 
 // C/D layout of every 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg

@@ -6,8 +6,9 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 os.environ["LYRA_HIP_LIB"] = os.path.join(ROOT, "lyra_amd", "variants", "timing.so")
 import lyra_amd
-ctx = lyra_amd.LyraHip(max_streams=4096)
-pcm = np.random.default_rng(0).integers(-32768, 32768, size=(4096, 320)).astype(np.int16)
+B = int(os.environ.get("B", 4096))
+ctx = lyra_amd.LyraHip(max_streams=B)
+pcm = np.random.default_rng(0).integers(-32768, 32768, size=(B, 320)).astype(np.int16)
 for _ in range(3):
     ctx.extract(pcm)
 buf = (ctypes.c_longlong * 128)()
