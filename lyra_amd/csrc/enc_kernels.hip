@@ -12,6 +12,9 @@
 #include "resblocks.h"
 
 #ifdef LYRA_TIMING
+extern "C" int lyra_hip_debug_wgtrace_s0(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_wgtrace), sizeof(long long) * 2048 * 4);
+}
 extern "C" int lyra_hip_debug_timing(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_tdbg), sizeof(long long) * 128);
 }
@@ -45,6 +48,7 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * S0;
+  LYRA_WG_BEGIN();
   LYRA_TSTAMP(0);
 #ifdef LYRA_STAGGER
   // Workgroups that share a CU (blockIdx differing by multiples of 256) start in lock-step and, running identical
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
         }
     }
   }
+  LYRA_WG_END();
   LYRA_TSTAMP(6);
   l2_warm_sink(warm, state, B);
 }

@@ -108,40 +108,45 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
                                              const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2) {
   constexpr int CS = 72;
   static_assert(20 * S / 16 == 5 * (NT / 256), "5 M tiles per wave");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, q = lane >> 4;
-  const int wn = wave & 3, wm = wave >> 2;
-  const int ncol = wn * 16 + (lane & 15);
-  const int pcol = at16(ncol);
 #pragma unroll 1
   for (int r = 0; r < 3; ++r) {
+    // The per-thread index math is recomputed inside the loop on purpose: hoisted out of it (LICM) its ~25
+    // loop-invariant address registers do not fit next to the resident X under 128 VGPRs and get spilled.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int wn = wave & 3, wm = wave >> 2;
+    const int ncol = wn * 16 + (lane & 15);
+    const int pcol = at16(ncol);
     const int d = r == 0 ? 1 : (r == 1 ? 3 : 9);
     const int R2 = 2 * d;
     const int off = r == 0 ? off0 : (r == 1 ? off1 : off2);
     LYRA_TSTAMP(10 + r * 8 + 0);
-    // 0. request the per-channel depthwise parameters and the history rows this lane will need
-    //    (L2 / HBM latency overlaps the a-write and the barrier)
+    // 0. request the depthwise parameters and the history rows this thread will need (L2 / HBM latency overlaps
+    //    the a-write and the barrier).  The depthwise conv runs on (row, channel quad) items -- 5 per thread, rows
+    //    rq + k * RSTEP -- so history and LDS traffic are 16-byte accesses (a few dwordx4 loads per thread instead
+    //    of up to ~100 dword loads in the MFMA C layout, which saturated the CU's address path).
+    constexpr int RSTEP = NT / 16;
+    const int p4 = tid & 15, rq = tid >> 4;
     const float LYRA_GLOBAL* dww = as_global(dws[r].w);
-    const float w0 = dww[pcol], w1 = dww[64 + pcol], w2 = dww[128 + pcol];
-    const float bb = as_global(dws[r].b)[pcol];
+    // RSTEP is a multiple of S: a thread's five items are rows t = tq + k * TSTEP of ONE stream sq.  Tap 0 of row t
+    // reads history row 2d + (t - 2d) = t (when t < 2d), tap 1 reads history row t + d (when t < d): two base
+    // pointers + immediate offsets.
+    static_assert(RSTEP % S == 0, "one stream per thread");
+    constexpr int TSTEP = RSTEP / S;
+    const int sq = rq & (S - 1), tq = rq / S;
+    const char LYRA_GLOBAL* hb0 = as_global(reinterpret_cast<const char*>(cx.sbase(sq) + off)) + (tq * 64 + p4 * 4) * 4;
+    const char LYRA_GLOBAL* hb1 = hb0 + d * 256;
     f32x4 h0[5], h1[5];
-    const float LYRA_GLOBAL* hist[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int s = (S >= 4) ? (e & (S - 1)) : 0;  // with S >= 4 a lane's four rows are four streams at one t
-      hist[e] = as_global(reinterpret_cast<const float*>(cx.sbase(s) + off));
+    for (int k = 0; k < 5; ++k) {
+      const int t = tq + k * TSTEP;
+      h0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      h1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t < 2 * d) h0[k] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hb0 + k * TSTEP * 256);
+      if (t < d) h1[k] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hb1 + k * TSTEP * 256);
     }
-    static_assert(S == 4 || S == 8, "row -> (t, s) mapping below");
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / S, s = R & (S - 1);
-        const float LYRA_GLOBAL* hp = (S == 4) ? hist[e] : as_global(reinterpret_cast<const float*>(cx.sbase(s) + off));
-        const int t0 = t - 2 * d, t1 = t - d;
-        h0[i][e] = t0 < 0 ? hp[(R2 + t0) * 64 + pcol] : 0.f;
-        h1[i][e] = t1 < 0 ? hp[(R2 + t1) * 64 + pcol] : 0.f;
-      }
     // 1. a = lrelu(X) -> A
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -149,39 +154,45 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
       for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = lrelu(xr[i][0][e]);
     __syncthreads();
     LYRA_TSTAMP(10 + r * 8 + 1);
-    // 2. depthwise k3 (dilation d) for the elements this lane owns
+    // 2. depthwise k3 (dilation d), one tap at a time over the thread's 5 items: the chain value replaces the
+    //    tap-0 history register, so the live set stays small (xr + two history sets) under the 128-VGPR budget
     f32x4 dreg[5];
     {
+      const f32x4 w0 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + p4 * 4);
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
+      for (int k = 0; k < 5; ++k) {
+        const int t0 = tq + k * TSTEP - 2 * d;
+        const f32x4 v0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(&A[(t0 * S + sq) * CS + p4 * 4]) : h0[k];
+        dreg[k] = fma4(v0, w0, (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+      const f32x4 w1 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 64 + p4 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / S, s = R & (S - 1);
-          const int t0 = t - 2 * d, t1 = t - d;
-          float v0 = t0 >= 0 ? A[(t0 * S + s) * CS + pcol] : h0[i][e];
-          float v1 = t1 >= 0 ? A[(t1 * S + s) * CS + pcol] : h1[i][e];
-          float v2 = A[R * CS + pcol];
-          float acc = __builtin_fmaf(v0, w0, 0.f);
-          acc = __builtin_fmaf(v1, w1, acc);
-          acc = __builtin_fmaf(v2, w2, acc);
-          dreg[i][e] = acc + bb;
-        }
+      for (int k = 0; k < 5; ++k) {
+        const int t1 = tq + k * TSTEP - d;
+        const f32x4 v1 = t1 >= 0 ? *reinterpret_cast<const f32x4*>(&A[(t1 * S + sq) * CS + p4 * 4]) : h1[k];
+        dreg[k] = fma4(v1, w1, dreg[k]);
+      }
+      const f32x4 w2 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 128 + p4 * 4);
+      const f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dws[r].b) + p4 * 4);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(&A[(rq + k * RSTEP) * CS + p4 * 4]);
+        dreg[k] = fma4(v2, w2, dreg[k]) + bb;
+      }
     }
     LYRA_TSTAMP(10 + r * 8 + 2);
-    __syncthreads();  // every lane has read its history rows and A
+    __syncthreads();  // every thread has consumed its history rows and read A
     for (int idx = tid; idx < R2 * S * 16; idx += NT) {  // new history = last R2 rows of a (T = 20 >= R2)
-      int p4 = idx & 15, s = (idx >> 4) & (S - 1), j = (idx >> 4) / S;
+      int c4 = idx & 15, s = (idx >> 4) & (S - 1), j = (idx >> 4) / S;
       if (cx.valid(s))
-        *reinterpret_cast<f32x4*>(cx.sbase(s) + off + (j * 64 + p4 * 4) * 4) =
-            *reinterpret_cast<const f32x4*>(&A[((20 - R2 + j) * S + s) * CS + p4 * 4]);
+        *reinterpret_cast<f32x4*>(cx.sbase(s) + off + (j * 64 + c4 * 4) * 4) =
+            *reinterpret_cast<const f32x4*>(&A[((20 - R2 + j) * S + s) * CS + c4 * 4]);
     }
     __syncthreads();
     LYRA_TSTAMP(10 + r * 8 + 3);
     // 3. depthwise out -> A
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = dreg[i][e];
+    for (int k = 0; k < 5; ++k) *reinterpret_cast<f32x4*>(&A[(rq + k * RSTEP) * CS + p4 * 4]) = dreg[k];
     __syncthreads();
     LYRA_TSTAMP(10 + r * 8 + 4);
     auto aoff = [&](int i, int c) { return ((wm * 5 + i) * 16 + m) * CS + c * 16 + q * 4; };
