@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 4 + j + 2 * (lane >> 5)) * 16 + (lane & 15);
-      float bias = P.head.b[n];
+      float bias = as_global(P.head.b)[n];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         H8[((q & 1) * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0.s, P.q0.z);
@@ -131,12 +131,12 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
     fold_rows8<4>(acc[0]);   // lanes 32-63 take over this wave's second channel tile (N tiles 4..7)
     const int ct = (wave & 1) * 2 + (lane >> 5);
     const int co = ct * 16 + (lane & 15);
-    const int bias = U.bias[co];
-    const float sub = P.up0_sub[g][co];
+    const int bias = as_global(U.bias)[co];
+    const float sub = as_global(P.up0_sub[g])[co];
     const int pc = at16(g * 64 + co);
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
-      const int zf = U.zfold[tap * 64 + co];
+      const int zf = as_global(U.zfold)[tap * 64 + co];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = (q & 1) * 4 + e;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
         int w;
         if (tau >= 0) w = *reinterpret_cast<const int*>(&QA[(tau * SD0 + s) * QS + w4 * 4]);
         else w = *reinterpret_cast<const int*>(cx.sbase(s) + st::D_R0_0 + (2 + tau) * 256 + w4 * 4);
-        int ww = *reinterpret_cast<const int*>(&dq.w[j * 256 + w4 * 4]);
+        int ww = *reinterpret_cast<const int LYRA_GLOBAL*>(&as_global(dq.w)[j * 256 + w4 * 4]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += sx8(w, e) * sx8(ww, e);   // zero point folded into dq.b
       }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int c = w4 * 4 + e;
-        o[e] = clamp8(requant(acc[e] + dq.b[c], dq.M[c], dq.sh[c], mode) + dq.zout);
+        o[e] = clamp8(requant(acc[e] + as_global(dq.b)[c], as_global(dq.M)[c], as_global(dq.sh)[c], mode) + dq.zout);
       }
       *reinterpret_cast<int*>(&QD[(t * SD0 + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
     }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int n = (wave * 2 + j) * 16 + (lane & 15);
-        int bias = P.pwq[0].b[n], M = P.pwq[0].M[n], sh = P.pwq[0].sh[n];
+        int bias = as_global(P.pwq[0].b)[n], M = as_global(P.pwq[0].M)[n], sh = as_global(P.pwq[0].sh)[n];
 #pragma unroll
         for (int i = 0; i < MTD0; ++i)
 #pragma unroll
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int n = (wave * 2 + j) * 16 + (lane & 15);
-        int bias = P.cvq[0].b[n], M = P.cvq[0].M[n], sh = P.cvq[0].sh[n];
+        int bias = as_global(P.cvq[0].b)[n], M = as_global(P.cvq[0].M)[n], sh = as_global(P.cvq[0].sh)[n];
         int pc = at16(n);
 #pragma unroll
         for (int i = 0; i < MTD0; ++i)
@@ -258,12 +258,12 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
     auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 128 + c * 64 + q * 16; };
     gemm_i8<2, 4, 2>(QA, aoff, U.w + (ct * 4) * 2 * 64, acc);
     const int co = ct * 16 + (lane & 15);
-    const int bias = U.bias[co];
-    const float sub = P.up1_sub[g][co];
+    const int bias = as_global(U.bias)[co];
+    const float sub = as_global(P.up1_sub[g])[co];
     const int pc = at16(g * 64 + co);
     int zf[4];
 #pragma unroll
-    for (int tap = 0; tap < 4; ++tap) zf[tap] = U.zfold[tap * 64 + co];
+    for (int tap = 0; tap < 4; ++tap) zf[tap] = as_global(U.zfold)[tap * 64 + co];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = q * 4 + e;

@@ -91,9 +91,9 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
       f32x4 v;
       if (tau >= 0) v = lrelu4(*reinterpret_cast<const f32x4*>(&XF[(tau * S2 + s) * CS2 + p4 * 4]));
       else v = *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::E_R2_0 + ((2 + tau) * 256 + p4 * 4) * 4);
-      acc = fma4(v, *reinterpret_cast<const f32x4*>(&P.dw0.w[j * 256 + p4 * 4]), acc);
+      acc = fma4(v, *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(&as_global(P.dw0.w)[j * 256 + p4 * 4]), acc);
     }
-    f32x4 bb = *reinterpret_cast<const f32x4*>(&P.dw0.b[p4 * 4]);
+    f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(&as_global(P.dw0.b)[p4 * 4]);
     *reinterpret_cast<f32x4*>(&DF[(t * S2 + s) * CS2 + p4 * 4]) = acc + bb;
   }
   __syncthreads();
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
-      float bias = P.pw0.b[n];
+      float bias = as_global(P.pw0.b)[n];
 #pragma unroll
       for (int i = 0; i < MT2; ++i)
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
-      int bias = P.r0b.b[n], M = P.r0b.M[n], sh = P.r0b.sh[n];
+      int bias = as_global(P.r0b.b)[n], M = as_global(P.r0b.M)[n], sh = as_global(P.r0b.sh)[n];
       int pc = at16(n);
 #pragma unroll
       for (int i = 0; i < MT2; ++i)
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int n = (wave * 4 + j + 2 * (lane >> 5)) * 16 + (lane & 15);
-    int bias = P.down2.b[n], M = P.down2.M[n], sh = P.down2.sh[n];
+    int bias = as_global(P.down2.b)[n], M = as_global(P.down2.M)[n], sh = as_global(P.down2.sh)[n];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = (q & 1) * 4 + e;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
     auto aoff = [&](int i, int c) { return ((c >> 1) * S2 + m) * QS5 + g * 128 + (c & 1) * 64 + q * 16; };
     gemm_i8<1, 1, 6>(QC, aoff, P.bott.w + g * 6 * 64, acc);
     int n = g * 16 + (lane & 15);
-    int bias = P.bott.b[n], M = P.bott.M[n], sh = P.bott.sh[n];
+    int bias = as_global(P.bott.b)[n], M = as_global(P.bott.M)[n], sh = as_global(P.bott.sh)[n];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = q * 4 + e;

@@ -284,7 +284,7 @@ __device__ __forceinline__ WarmTok<MAXIT> l2_warm(const WarmRange& w) {
   for (int it = 0; it < MAXIT; ++it) {
     const uint32_t l = lo + it * NT + threadIdx.x;
     tok.v[it] = 0;
-    if (l < hi) tok.v[it] = *reinterpret_cast<const uint32_t*>(w.base + ((size_t)l << 7));
+    if (l < hi) tok.v[it] = *reinterpret_cast<const uint32_t LYRA_GLOBAL*>(as_global(w.base) + ((size_t)l << 7));
   }
   return tok;
 }

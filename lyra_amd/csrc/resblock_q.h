@@ -36,8 +36,8 @@ template <int NT>
 __device__ __forceinline__ void load_luts(int8_t* LQ, const int8_t* lr_lut, int n_lr, int32_t* LA,
                                           const int32_t* add_lut, int n_add) {
   for (int i = threadIdx.x; i < n_lr * 64; i += NT)
-    reinterpret_cast<int*>(LQ)[i] = reinterpret_cast<const int*>(lr_lut)[i];
-  for (int i = threadIdx.x; i < n_add * 512; i += NT) LA[i] = add_lut[i];
+    reinterpret_cast<int*>(LQ)[i] = as_global(reinterpret_cast<const int*>(lr_lut))[i];
+  for (int i = threadIdx.x; i < n_add * 512; i += NT) LA[i] = as_global(add_lut)[i];
 }
 
 // ---- per-thread prefetch of everything global a block touches -------------------------------------------
@@ -67,15 +67,15 @@ __device__ __forceinline__ RbqPre resblock_q_prefetch(const TileCtx& cx, int d, 
     p.h[t][1] = *reinterpret_cast<const int*>(hp + r1 * 256);
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) p.ww[j] = *reinterpret_cast<const int*>(&dq.w[j * 256 + w4 * 4]);
-  p.b = *reinterpret_cast<const i32x4*>(&dq.b[w4 * 4]);
-  p.M = *reinterpret_cast<const i32x4*>(&dq.M[w4 * 4]);
-  p.sh = *reinterpret_cast<const i32x4*>(&dq.sh[w4 * 4]);
+  for (int j = 0; j < 3; ++j) p.ww[j] = *reinterpret_cast<const int LYRA_GLOBAL*>(&as_global(dq.w)[j * 256 + w4 * 4]);
+  p.b = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.b)[w4 * 4]);
+  p.M = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.M)[w4 * 4]);
+  p.sh = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.sh)[w4 * 4]);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int n = (wave * 2 + j) * 16 + (lane & 15);
-    p.pb[j] = pw.b[n]; p.pM[j] = pw.M[n]; p.psh[j] = pw.sh[n];
-    p.cb[j] = cv.b[n]; p.cM[j] = cv.M[n]; p.csh[j] = cv.sh[n];
+    p.pb[j] = as_global(pw.b)[n]; p.pM[j] = as_global(pw.M)[n]; p.psh[j] = as_global(pw.sh)[n];
+    p.cb[j] = as_global(cv.b)[n]; p.cM[j] = as_global(cv.M)[n]; p.csh[j] = as_global(cv.sh)[n];
   }
   return p;
 }
