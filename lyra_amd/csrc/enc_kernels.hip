@@ -190,6 +190,8 @@ __global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * S1;
+  LYRA_TSTAMP(70);
+  LYRA_WSTAMP(102);
   if (tid < S1) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
@@ -208,9 +210,11 @@ __global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict
   }
   __syncthreads();
 
+  LYRA_TSTAMP(71);
   TileCtx cx{state, sids, sphase, B - b0};
   resblocks128<S1, NT1>(XB + 2 * S1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::E_R1_0, st::E_R1_1, st::E_R1_2);
 
+  LYRA_TSTAMP(72);
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, rs = idx >> 5;
     f32x4* x = reinterpret_cast<f32x4*>(&XB[(2 * S1 + rs) * CS1 + p4 * 4]);
@@ -253,6 +257,8 @@ __global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict
         }
     }
   }
+  LYRA_TSTAMP(73);
+  LYRA_WSTAMP(103);
   l2_warm_sink(warm, state, B);
 }
 

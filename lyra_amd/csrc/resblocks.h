@@ -223,60 +223,95 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
   }
 }
 
-// ---- 128 channels x 4 rows; (S, NT) = (8, 256) or (16, 512) -------------------------------------------------------
+// ---- 128 channels x 4 rows; S = 8 streams, 256 threads ------------------------------------------------------------
 // X: [4][S][136] floats, D: same.  Dilation 1 keeps the last two rows; dilations 3 and 9 use ring histories of
 // 6 / 18 rows (T = 4 new rows per step at slot (phase*4 + t) mod R).
-// GEMM [4*S rows] x 128 x 128: MT = S/4 M tiles per wave, 8 N tiles spread over the NT/64 waves.
+// GEMM [4*S rows] x 128 x 128: 2 M tiles per wave, 8 N tiles spread over the 4 waves.
+// Thread (s = tid >> 5, p4 = tid & 31) owns channel quad p4 of stream s for all four rows: LeakyReLU, the
+// depthwise conv and the history update are thread-local, every history tap is a 16-byte global load, and the
+// loads of block r+1 are issued before block r's second GEMM so their HBM latency is never exposed.
+struct Hist128 { f32x4 h[4][2]; };   // [row t][tap 0 (t-2d), tap 1 (t-d)], valid where the tap predates the frame
+
+template <int S>
+__device__ __forceinline__ Hist128 hist128_prefetch(const TileCtx& cx, int d, int off) {
+  const int tid = threadIdx.x, p4 = tid & 31, s = tid >> 5;
+  const int R2 = 2 * d;
+  const bool ring = R2 > 4;
+  const int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
+  const float LYRA_GLOBAL* hp = as_global(reinterpret_cast<const float*>(cx.sbase(s) + off)) + p4 * 4;
+  Hist128 H;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tau = t - (2 - j) * d;
+      H.h[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (tau < 0) {
+        int row = R2 + tau;
+        if (ring) { row = base + tau + R2; row = row >= R2 ? row - R2 : row; }
+        H.h[t][j] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hp + row * 128);
+      }
+    }
+  return H;
+}
+
 template <int S, int NT>
 __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& cx, const DwF* dws,
                                              const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2) {
-  constexpr int CS = 136, NW = NT / 64, NTW = 8 / NW, MT = (4 * S) / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, q = lane >> 4;
+  static_assert(S == 8 && NT == 256, "thread <-> (stream, channel quad) mapping");
+  constexpr int CS = 136, NTW = 2, MT = 2;
+  Hist128 H = hist128_prefetch<S>(cx, 1, off0);
 #pragma unroll 1
   for (int r = 0; r < 3; ++r) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // keep the index math inside the loop (see resblocks64r)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int p4 = tid & 31, s = tid >> 5;
     const int d = r == 0 ? 1 : (r == 1 ? 3 : 9);
     const int R2 = 2 * d;
     const int off = r == 0 ? off0 : (r == 1 ? off1 : off2);
     const bool ring = R2 > 4;
-    const DwF dw = dws[r];
-    for (int idx = tid; idx < 4 * S * 32; idx += NT) {
-      int p4 = idx & 31, s = (idx >> 5) & (S - 1), t = (idx >> 5) / S;
-      int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    LYRA_TSTAMP(40 + r * 8 + 0);
+    {  // a = lrelu(X); depthwise [a(t-2d), a(t-d), a(t)]; history update -- all on this thread's own quad
+      const float LYRA_GLOBAL* dww = as_global(dws[r].w) + p4 * 4;
+      const f32x4 w0 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww);
+      const f32x4 w1 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 128);
+      const f32x4 w2 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 256);
+      const f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dws[r].b) + p4 * 4);
+      f32x4 a[4];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        int tau = t - (2 - j) * d;
-        f32x4 v;
-        if (tau >= 0) {
-          v = lrelu4(*reinterpret_cast<const f32x4*>(&X[(tau * S + s) * CS + p4 * 4]));
-        } else {
-          int row = R2 + tau;
-          if (ring) { row = base + tau + R2; row = row >= R2 ? row - R2 : row; }
-          v = *reinterpret_cast<const f32x4*>(cx.sbase(s) + off + (row * 128 + p4 * 4) * 4);
+      for (int t = 0; t < 4; ++t) a[t] = lrelu4(*reinterpret_cast<const f32x4*>(&X[(t * S + s) * CS + p4 * 4]));
+      float* hp = reinterpret_cast<float*>(cx.sbase(s) + off) + p4 * 4;
+      const int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
+      const bool valid = cx.valid(s);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        // taps that fall inside the frame are earlier rows of a[] (only possible for d <= 3)
+        f32x4 v0 = H.h[t][0], v1 = H.h[t][1];
+        if (d == 1) {
+          if (t >= 2) v0 = a[t >= 2 ? t - 2 : 0];
+          if (t >= 1) v1 = a[t >= 1 ? t - 1 : 0];
+        } else if (d == 3) {
+          if (t == 3) v1 = a[0];
         }
-        acc = fma4(v, *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dw.w) + j * 128 + p4 * 4), acc);
+        f32x4 acc = fma4(v0, w0, (f32x4){0.f, 0.f, 0.f, 0.f});
+        acc = fma4(v1, w1, acc);
+        acc = fma4(a[t], w2, acc);
+        *reinterpret_cast<f32x4*>(&D[(t * S + s) * CS + p4 * 4]) = acc + bb;
+        if (valid) {
+          if (ring) {
+            int row = base + t;
+            row = row >= R2 ? row - R2 : row;
+            *reinterpret_cast<f32x4*>(hp + row * 128) = a[t];
+          } else if (t >= 2) {
+            *reinterpret_cast<f32x4*>(hp + (t - 2) * 128) = a[t];
+          }
+        }
       }
-      f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dw.b) + p4 * 4);
-      *reinterpret_cast<f32x4*>(&D[(t * S + s) * CS + p4 * 4]) = acc + bb;
     }
     __syncthreads();
-    {
-      const int nrows = ring ? 4 : 2;
-      for (int idx = tid; idx < nrows * S * 32; idx += NT) {
-        int p4 = idx & 31, s = (idx >> 5) & (S - 1), j = (idx >> 5) / S;
-        int src_t, row;
-        if (ring) {
-          int base = (cx.sphase[s] * 4) % R2;
-          src_t = j; row = base + j; row = row >= R2 ? row - R2 : row;
-        } else {
-          src_t = 2 + j; row = j;
-        }
-        if (cx.valid(s))
-          *reinterpret_cast<f32x4*>(cx.sbase(s) + off + (row * 128 + p4 * 4) * 4) =
-              lrelu4(*reinterpret_cast<const f32x4*>(&X[(src_t * S + s) * CS + p4 * 4]));
-      }
-    }
+    LYRA_TSTAMP(40 + r * 8 + 2);
     {  // pointwise 128 -> 128, LeakyReLU
       f32x4 acc[MT][NTW];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + c * 16 + q * 4; };
@@ -284,6 +319,11 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
 #pragma unroll
       for (int j = 0; j < NTW; ++j) biasv[j] = as_global(pws[r].b)[(wave * NTW + j) * 16 + (lane & 15)];
       gemm_f32<MT, NTW, 8>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, acc);
+      LYRA_TSTAMP(40 + r * 8 + 3);
+      // The next block's history rows.  vmcnt retires in order, so these loads would stall the first weight
+      // fetch of a GEMM issued right after them; here they have the two barriers and the LDS-only P write
+      // (no younger global load) to land in.
+      if (r < 2) H = hist128_prefetch<S>(cx, r == 0 ? 3 : 9, r == 0 ? off1 : off2);
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
@@ -296,6 +336,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
           for (int e = 0; e < 4; ++e) D[(i * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][j][e] + bias);
       }
       __syncthreads();
+      LYRA_TSTAMP(40 + r * 8 + 4);
     }
     {  // grouped 1x1 (2 groups of 64 -> 64) + residual; a wave's N tiles lie in one group
       f32x4 acc[MT][NTW];
@@ -305,6 +346,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
 #pragma unroll
       for (int j = 0; j < NTW; ++j) biasv[j] = as_global(cvs[r].b)[(wave * NTW + j) * 16 + (lane & 15)];
       gemm_f32<MT, NTW, 4>(D, aoff, cvs[r].w + (wave * NTW) * 4 * 64, acc);
+      LYRA_TSTAMP(40 + r * 8 + 5);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int ncol = (wave * NTW + j) * 16 + (lane & 15);
@@ -320,6 +362,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
       }
     }
     __syncthreads();
+    LYRA_TSTAMP(40 + r * 8 + 6);
   }
 }
 
