@@ -309,7 +309,7 @@ constexpr int CS1 = 136;
 constexpr int NTD1 = 256;
 }  // namespace
 
-size_t dec_s1_lds_bytes() { return (size_t)(7 * SD1 * CS1 + 4 * SD1 * CS1) * 4 + 2 * SD1 * 4; }
+size_t dec_s1_lds_bytes() { return (size_t)(4 * SD1 * CS1 + 4 * SD1 * CS1 + 5 * SD1 * 72) * 4 + 2 * SD1 * 4; }
 int dec_s1_streams_per_wg() { return SD1; }
 
 __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
@@ -317,9 +317,10 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
                                                           uint8_t* __restrict__ state, float* __restrict__ out1) {
   const DecS1P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XB = smem;                     // [7][S][136]: row 0 zeros, rows 1-4 X[t], rows 5-6 zeros
-  float* DB = XB + 7 * SD1 * CS1;       // [4][S][136]; later: old tconv tail [5][S][72]
-  int* sids = reinterpret_cast<int*>(DB + 4 * SD1 * CS1);
+  float* XB = smem;                     // [4][S][136]: X[t]
+  float* DB = XB + 4 * SD1 * CS1;       // [4][S][136]
+  float* SB = DB + 4 * SD1 * CS1;       // [5][S][72]: tail of the previous frame's transposed conv
+  int* sids = reinterpret_cast<int*>(SB + 5 * SD1 * 72);
   int* sphase = sids + SD1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
@@ -335,26 +336,20 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
     int b = min(b0 + s, B - 1);
-    *reinterpret_cast<f32x4*>(&XB[((1 + t) * SD1 + s) * CS1 + p4 * 4]) =
+    *reinterpret_cast<f32x4*>(&XB[(t * SD1 + s) * CS1 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
   }
-  for (int idx = tid; idx < 3 * SD1 * 32; idx += NTD1) {
-    int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), j = (idx >> 5) / SD1;
-    int row = j == 0 ? 0 : 4 + j;
-    *reinterpret_cast<f32x4*>(&XB[(row * SD1 + s) * CS1 + p4 * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  resblocks128<SD1, NTD1>(XB + SD1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2);
-  for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
-    int p4 = idx & 31, rs = idx >> 5;
-    f32x4* x = reinterpret_cast<f32x4*>(&XB[(SD1 + rs) * CS1 + p4 * 4]);
-    *x = lrelu4(*x);
-  }
-  float* SB = DB;  // old carried tail [5][S][72]
-  for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {
+  for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {   // carried tail: fetched with the input, used at the end
     int p4 = idx & 15, s = (idx >> 4) & (SD1 - 1), j = (idx >> 4) / SD1;
     *reinterpret_cast<f32x4*>(&SB[(j * SD1 + s) * 72 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
+  }
+  __syncthreads();
+  resblocks128<SD1, NTD1>(XB, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2);
+  for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
+    int p4 = idx & 31, rs = idx >> 5;
+    f32x4* x = reinterpret_cast<f32x4*>(&XB[rs * CS1 + p4 * 4]);
+    *x = lrelu4(*x);
   }
   __syncthreads();
   {  // tconv k10/s5, polyphase: output block b (5 rows x 64 ch = N 320) = x[b-1] . W[taps 5..9] then x[b] . W[taps 0..4],
@@ -364,7 +359,7 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
     f32x4 acc[2][5];
     auto aoff = [&](int i, int c) {
       int R = i * 16 + m, t = R / SD1, s = R & (SD1 - 1);
-      return ((1 + t) * SD1 + s) * CS1 + c * 16 + q * 4;
+      return (t * SD1 + s) * CS1 + c * 16 + q * 4;
     };
     const f32x4* wfrag = P.up.w + (wave * 5) * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 5..9, 8-15 taps 0..4
     gemm_f32<2, 5, 8, 16>(XB, aoff, wfrag, acc);

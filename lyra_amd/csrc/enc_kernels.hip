@@ -61,6 +61,17 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B; };
 
+  // The 5 history rows of the strided conv (needed only in phase D/E) are requested together with the PCM so
+  // that their HBM latency is paid once, up front; they are parked in registers until the staging area is free.
+  f32x4 halo[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * NT0;
+    const int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
+    halo[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (idx < 5 * S0 * 16) halo[k] = *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D0 + (j * 64 + p4 * 4) * 4);
+  }
+
   // ---- A. window = [48 history samples | 320 new samples] / 32768, AT16 order ----------------
   float* PB = XB;
   for (int idx = tid; idx < S0 * 46; idx += NT0) {   // 46 = 6 history + 40 PCM pieces of 8 samples
@@ -108,6 +119,12 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
       for (int e = 0; e < 4; ++e) xr[i][0][e] = xr[i][0][e] + bias;
   }
   __syncthreads();  // PCM staging area is free again
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * NT0;
+    const int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
+    if (idx < 5 * S0 * 16) *reinterpret_cast<f32x4*>(&XB[(j * S0 + s) * CS0 + p4 * 4]) = halo[k];
+  }
   LYRA_TSTAMP(2);
 
   // ---- C. three residual blocks, dilation 1 / 3 / 9 --------------------------------------------
@@ -115,17 +132,12 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   resblocks64r<S0, NT0>(xr, XB + 5 * S0 * CS0, cx, P.dw, P.pw, P.cv, st::E_R0_0, st::E_R0_1, st::E_R0_2);
   LYRA_TSTAMP(3);
 
-  // ---- D. a = lrelu(X) -> rows 5..24; prepend the 5 history rows of the strided conv ------------------
+  // ---- D. a = lrelu(X) -> rows 5..24 (rows 0-4 already hold the strided conv's history) ----------------
 #pragma unroll
   for (int i = 0; i < 5; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       XB[(5 * S0 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
-  for (int idx = tid; idx < 5 * S0 * 16; idx += NT0) {
-    int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
-    *reinterpret_cast<f32x4*>(&XB[(j * S0 + s) * CS0 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D0 + (j * 64 + p4 * 4) * 4);
-  }
   __syncthreads();
   for (int idx = tid; idx < 5 * S0 * 16; idx += NT0) {
     int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
