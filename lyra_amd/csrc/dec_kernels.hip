@@ -333,6 +333,7 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
   const auto warm = l2_warm<NTD1, 2>(P.warm);
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
+  const Hist128 H0 = hist128_prefetch<SD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
     int b = min(b0 + s, B - 1);
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
         *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
   }
   __syncthreads();
-  resblocks128<SD1, NTD1>(XB, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2);
+  resblocks128<SD1, NTD1>(XB, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2, H0);
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, rs = idx >> 5;
     f32x4* x = reinterpret_cast<f32x4*>(&XB[rs * CS1 + p4 * 4]);

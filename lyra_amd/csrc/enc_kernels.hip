@@ -214,28 +214,29 @@ __global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict
   auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B; };
 
+  TileCtx cx{state, sids, sphase, B - b0};
+  const Hist128 H0 = hist128_prefetch<S1>(cx, 1, st::E_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
     int b = min(b0 + s, B - 1);
     *reinterpret_cast<f32x4*>(&XB[((2 + t) * S1 + s) * CS1 + p4 * 4]) =
         *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
   }
+  for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {   // strided conv's 2 history rows: fetched with the input
+    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), j = (idx >> 5) / S1;
+    *reinterpret_cast<f32x4*>(&XB[(j * S1 + s) * CS1 + p4 * 4]) =
+        *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D1 + (j * 128 + p4 * 4) * 4);
+  }
   __syncthreads();
 
   LYRA_TSTAMP(71);
-  TileCtx cx{state, sids, sphase, B - b0};
-  resblocks128<S1, NT1>(XB + 2 * S1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::E_R1_0, st::E_R1_1, st::E_R1_2);
+  resblocks128<S1, NT1>(XB + 2 * S1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::E_R1_0, st::E_R1_1, st::E_R1_2, H0);
 
   LYRA_TSTAMP(72);
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, rs = idx >> 5;
     f32x4* x = reinterpret_cast<f32x4*>(&XB[(2 * S1 + rs) * CS1 + p4 * 4]);
     *x = lrelu4(*x);
-  }
-  for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {
-    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), j = (idx >> 5) / S1;
-    *reinterpret_cast<f32x4*>(&XB[(j * S1 + s) * CS1 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D1 + (j * 128 + p4 * 4) * 4);
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {

@@ -256,11 +256,12 @@ __device__ __forceinline__ Hist128 hist128_prefetch(const TileCtx& cx, int d, in
 }
 
 template <int S, int NT>
+// H: hist128_prefetch(cx, 1, off0), requested by the caller together with the stage input.
 __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& cx, const DwF* dws,
-                                             const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2) {
+                                             const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2,
+                                             Hist128 H) {
   static_assert(S == 8 && NT == 256, "thread <-> (stream, channel quad) mapping");
   constexpr int CS = 136, NTW = 2, MT = 2;
-  Hist128 H = hist128_prefetch<S>(cx, 1, off0);
 #pragma unroll 1
   for (int r = 0; r < 3; ++r) {
     int tid = threadIdx.x;
