@@ -96,6 +96,66 @@ __global__ void probe(long long* out, const int* gmem, const int* chain, int see
   if (x == 0x12345678) out[63] = x;
 }
 
+// ---- throughput under full occupancy: every thread runs 4 independent chains of one instruction class ----------
+template <int CLS>
+__global__ void tput(int* out, int seed, int iters) {
+  __shared__ unsigned char lut[4096];
+  const int tid = threadIdx.x;
+  if (CLS == 4 || CLS == 5) {
+    for (int i = tid; i < 4096; i += blockDim.x) lut[i] = (unsigned char)((i * 7 + 3) & 255);
+    __syncthreads();
+  }
+  int a = seed + tid, b = a * 3 + 1, c = a * 5 + 2, d = a * 7 + 3;
+  long long la = a, lb = b, lc = c, ld = d;
+  i32x4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
+  f32x4 f0 = {0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0;
+  const i32x4 av = {a, b, c, d}, bv = {d, c, b, a};
+  for (int i = 0; i < iters; ++i) {
+    if (CLS == 0) { a = a * 3 + i; b = b * 5 + i; c = c * 7 + i; d = d * 9 + i; a ^= a >> 3; b ^= b >> 5; c ^= c >> 7; d ^= d >> 9; }  // plain 32-bit VALU mix
+    if (CLS == 1) { a = __mulhi(a, 0x5A17C3D1) + i; b = __mulhi(b, 0x6B28D4E3) + i; c = __mulhi(c, 0x7C39E5F5) + i; d = __mulhi(d, 0x4D4AF607) + i; }
+    if (CLS == 2) {
+      la = ((long long)(int)la * 0x5A17C3D1ll + (1ll << 35)) >> ((i & 7) + 30);
+      lb = ((long long)(int)lb * 0x6B28D4E3ll + (1ll << 35)) >> ((i & 7) + 30);
+      lc = ((long long)(int)lc * 0x7C39E5F5ll + (1ll << 35)) >> ((i & 7) + 30);
+      ld = ((long long)(int)ld * 0x4D4AF607ll + (1ll << 35)) >> ((i & 7) + 30);
+    }
+    if (CLS == 3) { a = (a << 8 >> 24) * (b << 16 >> 24) + c; b = (b << 8 >> 24) * (c << 16 >> 24) + d; c = (c << 8 >> 24) * (d << 16 >> 24) + a; d = (d << 8 >> 24) * (a << 16 >> 24) + b; }  // bfe + mad
+    if (CLS == 4) { a = lut[a & 4095] + (a >> 1) + i; b = lut[b & 4095] + (b >> 1) + i; c = lut[c & 4095] + (c >> 1) + i; d = lut[d & 4095] + (d >> 1) + i; }
+    if (CLS == 5) {
+      i32x4 v = *reinterpret_cast<const i32x4*>(&lut[(a & 255) * 16]);
+      a += v[0] + v[3] + i; b += v[1]; c += v[2]; d += v[3];
+    }
+    if (CLS == 6) {
+      m0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, m0, 0, 0, 0); m1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, m1, 0, 0, 0);
+      m2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, m2, 0, 0, 0); m3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, m3, 0, 0, 0);
+    }
+    if (CLS == 7) {
+      f0 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, 2.f, f0, 0, 0, 0); f1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, 2.f, f1, 0, 0, 0);
+      f2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, 2.f, f2, 0, 0, 0); f3 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, 2.f, f3, 0, 0, 0);
+    }
+  }
+  int r = a + b + c + d + (int)(la + lb + lc + ld) + m0[0] + m1[1] + m2[2] + m3[3] + (int)(f0[0] + f1[1] + f2[2] + f3[3]);
+  if (r == 0x12345678) out[0] = r;
+}
+
+template <int CLS>
+static void run_tput(const char* name, int* dout) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 2048, blocks = 2048, threads = 256;
+  hipLaunchKernelGGL(tput<CLS>, dim3(blocks), dim3(threads), 0, 0, dout, 1, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(tput<CLS>, dim3(blocks), dim3(threads), 0, 0, dout, 2, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  // per-SIMD cycles per wave-iteration at a nominal 2.4 GHz: waves = blocks*threads/64 over 1024 SIMDs
+  double waves_per_simd = (double)blocks * threads / 64 / 1024.0;
+  printf("   %-36s %8.3f ms   %7.1f cycles/iter/wave-slot @2.4GHz\n", name, ms, ms * 1e-3 * 2.4e9 / (iters * waves_per_simd));
+}
+
 int main() {
   const int CH = 16384;
   std::vector<int> chain(CH), g(CH);
@@ -122,5 +182,16 @@ int main() {
     printf("== %s: cycles per op (WG 0, thread 0)\n", c.what);
     for (int i = 0; i < 9; ++i) printf("   %-32s %7.1f\n", names[i], (double)h[i] / N);
   }
+  printf("== throughput, 2048 WG x 256 threads, 4 independent chains per thread\n");
+  int* dres;
+  hipMalloc(&dres, 64);
+  run_tput<0>("32-bit VALU mix (8 ops/iter)", dres);
+  run_tput<1>("mul_hi + add x4", dres);
+  run_tput<2>("mad64 + shift64 x4", dres);
+  run_tput<3>("bfe + mad x4", dres);
+  run_tput<4>("lds u8 lookup x4", dres);
+  run_tput<5>("lds b128 read", dres);
+  run_tput<6>("mfma i8 16x16x64 x4", dres);
+  run_tput<7>("mfma f32 16x16x4 x4", dres);
   return 0;
 }
