@@ -127,16 +127,29 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
     const int g = wave >> 1;
     const TconvQ U = P.up0[g];
     auto aoff = [&](int i, int c) { return m * QS5 + g * 128 + c * 64 + q * 16; };
-    gemm_i8<1, 8, 2>(H8, aoff, U.w + ((wave & 1) * 8) * 2 * 64, acc);
-    fold_rows8<4>(acc[0]);   // lanes 32-63 take over this wave's second channel tile (N tiles 4..7)
+    // after fold_rows8 lane L works on channel tile ct, streams (q & 1) * 4 + e: request its epilogue operands
+    // (carried tail rows, bias, fold terms) before the GEMM so that their latency overlaps it
     const int ct = (wave & 1) * 2 + (lane >> 5);
     const int co = ct * 16 + (lane & 15);
     const int bias = as_global(U.bias)[co];
     const float sub = as_global(P.up0_sub[g])[co];
     const int pc = at16(g * 64 + co);
+    int zfv[4];
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) zfv[tap] = as_global(U.zfold)[tap * 64 + co];
+    float told[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float LYRA_GLOBAL* stp =
+          as_global(reinterpret_cast<const float*>(cx.sbase((q & 1) * 4 + e) + st::D_UP0 + g * 512));
+      told[0][e] = stp[co];
+      told[1][e] = stp[64 + co];
+    }
+    gemm_i8<1, 8, 2>(H8, aoff, U.w + ((wave & 1) * 8) * 2 * 64, acc);
+    fold_rows8<4>(acc[0]);   // lanes 32-63 take over this wave's second channel tile (N tiles 4..7)
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
-      const int zf = as_global(U.zfold)[tap * 64 + co];
+      const int zf = zfv[tap];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = (q & 1) * 4 + e;
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
         int c8 = clamp8(requant(acc[0][tap][e] + zf + bias, U.M, U.sh, mode) + U.zout);
         float y = dequantize_f(c8, P.up0_dq[g].s, P.up0_dq[g].z);
         if (tap < 2) {
-          y = y + stp[tap * 64 + co];
+          y = y + told[tap < 2 ? tap : 0][e];
           XF[(tap * SD0 + s) * CS2 + pc] = y;
         } else {
           y = y + 0.f;
@@ -155,45 +168,46 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   }
   __syncthreads();
   LYRA_TSTAMP(43);
-  // ---- a0 = QUANTIZE(lrelu(x164)) ------------------------------------------------------------------
-  for (int idx = tid; idx < 2 * SD0 * 256; idx += NTD0) {
-    int c = idx & 255, rs = idx >> 8;
-    QA[rs * QS + c] = (int8_t)quantize_f(lrelu(XF[rs * CS2 + at16(c)]), P.q1.s, P.q1.z);
-  }
-  __syncthreads();
-  LYRA_TSTAMP(44);
-  // ---- resblock 0 (int8 body, float skip): dilation 1, history of 2 rows (replaced) -----------------
+  // ---- a0 = QUANTIZE(lrelu(x164)); resblock 0 (int8 body, float skip) depthwise, dilation 1 --------------
+  // Thread (s, w4) owns channels 4*w4 .. 4*w4+3 of stream s for both rows: quantize -> depthwise over
+  // [a(t-2), a(t-1), a(t)] -> history (2 rows, replaced) stay in registers; no LDS round trip, one barrier.
   const RbqPre pre1 = resblock_q_prefetch<SD0>(cx, 3, st::D_R0_1, P.dwq[1], P.pwq[1], P.cvq[1]);
   {
     const DwQ dq = P.dwq[0];
-    for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
-      int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
-      int acc[4] = {0, 0, 0, 0};
+    const int w4 = tid & 63, s = tid >> 6;
+    uint8_t* hp = cx.sbase(s) + st::D_R0_0 + w4 * 4;
+    const int h0 = *reinterpret_cast<const int*>(hp), h1 = *reinterpret_cast<const int*>(hp + 256);
+    int ww[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        int tau = t - (2 - j);
-        int w;
-        if (tau >= 0) w = *reinterpret_cast<const int*>(&QA[(tau * SD0 + s) * QS + w4 * 4]);
-        else w = *reinterpret_cast<const int*>(cx.sbase(s) + st::D_R0_0 + (2 + tau) * 256 + w4 * 4);
-        int ww = *reinterpret_cast<const int LYRA_GLOBAL*>(&as_global(dq.w)[j * 256 + w4 * 4]);
+    for (int j = 0; j < 3; ++j) ww[j] = *reinterpret_cast<const int LYRA_GLOBAL*>(&as_global(dq.w)[j * 256 + w4 * 4]);
+    const i32x4 db = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.b)[w4 * 4]);
+    const i32x4 dM = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.M)[w4 * 4]);
+    const i32x4 dsh = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.sh)[w4 * 4]);
+    int a[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += sx8(w, e) * sx8(ww, e);   // zero point folded into dq.b
-      }
+    for (int t = 0; t < 2; ++t) {
+      int c8[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        c8[e] = quantize_f(lrelu(XF[(t * SD0 + s) * CS2 + at16(w4 * 4 + e)]), P.q1.s, P.q1.z);
+      a[t] = pack8(c8[0], c8[1], c8[2], c8[3]);
+    }
+    const int x[2][3] = {{h0, h1, a[0]}, {h1, a[0], a[1]}};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
       int o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int c = w4 * 4 + e;
-        o[e] = clamp8(requant(acc[e] + as_global(dq.b)[c], as_global(dq.M)[c], as_global(dq.sh)[c], mode) + dq.zout);
+        int acc = db[e];                                  // zero point folded into dq.b
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc += sx8(x[t][j], e) * sx8(ww[j], e);
+        o[e] = clamp8(requant(acc, dM[e], dsh[e], mode) + dq.zout);
       }
       *reinterpret_cast<int*>(&QD[(t * SD0 + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
+      if (cx.valid(s)) *reinterpret_cast<int*>(hp + t * 256) = a[t];
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
-      int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
-      if (cx.valid(s))
-        *reinterpret_cast<int*>(cx.sbase(s) + st::D_R0_0 + t * 256 + w4 * 4) =
-            *reinterpret_cast<const int*>(&QA[(t * SD0 + s) * QS + w4 * 4]);
-    }
+    LYRA_TSTAMP(44);
     {
       i32x4 acc[MTD0][2];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };

@@ -138,6 +138,40 @@ __global__ void tput(int* out, int seed, int iters) {
   if (r == 0x12345678) out[0] = r;
 }
 
+// ---- instruction fetch: the same 8192 VALU ops per pass as straight-line code (~64 KB, larger than a CU pair's
+// instruction cache) versus a compact loop
+#define R4(x) x x x x
+#define R16(x) R4(R4(x))
+#define R256(x) R16(R16(x))
+__global__ void bigcode(int* out, int seed, int passes) {
+  int a = seed + threadIdx.x, b = a * 3 + 1;
+  for (int p = 0; p < passes; ++p) {
+    R256(R16(asm volatile("v_add_u32 %0, %0, %1\n v_xor_b32 %1, %1, %0" : "+v"(a), "+v"(b));))
+  }
+  if (a + b == 0x12345678) out[0] = a;
+}
+__global__ void smallcode(int* out, int seed, int passes) {
+  int a = seed + threadIdx.x, b = a * 3 + 1;
+  for (int p = 0; p < passes * 256; ++p) {
+    R16(asm volatile("v_add_u32 %0, %0, %1\n v_xor_b32 %1, %1, %0" : "+v"(a), "+v"(b));)
+  }
+  if (a + b == 0x12345678) out[0] = a;
+}
+template <class K>
+static void run_code(const char* name, K kern, int* dout) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(512), dim3(512), 0, 0, dout, 1, 20);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(kern, dim3(512), dim3(512), 0, 0, dout, 2, 20);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("   %-36s %8.3f ms\n", name, ms);
+}
+
 template <int CLS>
 static void run_tput(const char* name, int* dout) {
   hipEvent_t e0, e1;
@@ -193,5 +227,8 @@ int main() {
   run_tput<5>("lds b128 read", dres);
   run_tput<6>("mfma i8 16x16x64 x4", dres);
   run_tput<7>("mfma f32 16x16x4 x4", dres);
+  printf("== instruction fetch: 512 WG x 512 threads, 20 passes of 8192 VALU ops\n");
+  run_code("straight-line 64 KB body", bigcode, dres);
+  run_code("compact loop", smallcode, dres);
   return 0;
 }
