@@ -88,6 +88,12 @@ class Arena {
   }
   const std::vector<uint8_t>& bytes() const { return buf_; }
   size_t aligned_size() const { return (buf_.size() + 255) / 256 * 256; }
+  size_t reserve(size_t n) {   // zero-filled placeholder, patched before the upload
+    size_t off = aligned_size();
+    buf_.resize(off + n);
+    return off;
+  }
+  uint8_t* data() { return buf_.data(); }
 
  private:
   std::vector<uint8_t> buf_;
@@ -342,6 +348,7 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
     B.conv_f("enc", 2 + 2 * r, &M->enc0.cv[r]);
   }
   B.conv_f("enc", 7, &M->enc0.down);
+  const size_t p_enc0 = B.arena.reserve(sizeof(EncS0P));   // the kernel's parameter block rides in its warm range
   B.range(&M->enc0.warm, mark);
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
@@ -350,6 +357,7 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
     B.conv_f("enc", 9 + 2 * r, &M->enc1.cv[r]);
   }
   B.conv_f("enc", 14, &M->enc1.down);
+  const size_t p_enc1 = B.arena.reserve(sizeof(EncS1P));
   B.range(&M->enc1.warm, mark);
   mark = B.mark();
   EncS2P& E2 = M->enc2;
@@ -372,6 +380,7 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   B.conv_q("enc", 21, &E2.down2);
   B.conv_q("enc", 22, &E2.bott);
   E2.mode = requant_mode;
+  const size_t p_enc2 = B.arena.reserve(sizeof(EncS2P));
   B.range(&E2.warm, mark);
   // ---- decoder -----------------------------------------------------------------------------
   mark = B.mark();
@@ -396,6 +405,7 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   D0.q3 = B.qp("dec", "quant", 3);
   for (int g = 0; g < 2; ++g) B.tconv_q("dec", 4 + g, &D0.up1[g], &D0.up1_dq[g], &D0.up1_sub[g], 4 + g);
   D0.mode = requant_mode;
+  const size_t p_dec0 = B.arena.reserve(sizeof(DecS0P));
   B.range(&D0.warm, mark);
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
@@ -408,6 +418,7 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
     const float* sc = pk.data<float>("dec.sub.6.c");
     if (sc) B.put(&M->dec1.up_sub, std::vector<float>(sc, sc + 64));
   }
+  const size_t p_dec1 = B.arena.reserve(sizeof(DecS1P));
   B.range(&M->dec1.warm, mark);
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
@@ -420,6 +431,7 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
     const float* sc = pk.data<float>("dec.sub.7.c");
     if (sc) M->dec2.up_sub = sc[0];
   }
+  const size_t p_dec2 = B.arena.reserve(sizeof(DecS2P));
   B.range(&M->dec2.warm, mark);
   // ---- RVQ codebooks -------------------------------------------------------------------------------------
   {
@@ -491,27 +503,34 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
 
   const std::vector<uint8_t>& bytes = B.arena.bytes();
   if (hipMalloc((void**)&M->d_arena, bytes.size()) != hipSuccess) { *err = "hipMalloc(weights) failed"; return false; }
+  M->arena_bytes = bytes.size();
+  for (auto& fx : B.fixups) *reinterpret_cast<const uint8_t**>(fx.first) = M->d_arena + fx.second;
+  // The six stage kernels read their parameter block through a device pointer (scalar loads).  The block lives
+  // at the end of the kernel's own weight range, so the kernel's L2 warm-up pass covers it too: in steady state
+  // every kernel boundary finds these lines evicted, and each first scalar load of a phase would otherwise be a
+  // miss all waves wait on in the middle of the dependent phase chain.
+  memcpy(B.arena.data() + p_enc0, &M->enc0, sizeof M->enc0);
+  memcpy(B.arena.data() + p_enc1, &M->enc1, sizeof M->enc1);
+  memcpy(B.arena.data() + p_enc2, &M->enc2, sizeof M->enc2);
+  memcpy(B.arena.data() + p_dec0, &M->dec0, sizeof M->dec0);
+  memcpy(B.arena.data() + p_dec1, &M->dec1, sizeof M->dec1);
+  memcpy(B.arena.data() + p_dec2, &M->dec2, sizeof M->dec2);
   if (hipMemcpy(M->d_arena, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
     *err = "hipMemcpy(weights) failed";
     return false;
   }
-  M->arena_bytes = bytes.size();
-  for (auto& fx : B.fixups) *reinterpret_cast<const uint8_t**>(fx.first) = M->d_arena + fx.second;
-  // parameter blocks -> device memory (kernels read them through a pointer: scalar loads from L2, never from a
-  // host-resident kernarg segment)
-  {
+  M->d_enc0 = (EncS0P*)(M->d_arena + p_enc0); M->d_enc1 = (EncS1P*)(M->d_arena + p_enc1);
+  M->d_enc2 = (EncS2P*)(M->d_arena + p_enc2); M->d_dec0 = (DecS0P*)(M->d_arena + p_dec0);
+  M->d_dec1 = (DecS1P*)(M->d_arena + p_dec1); M->d_dec2 = (DecS2P*)(M->d_arena + p_dec2);
+  {  // log-mel / reset parameter blocks (not on the encode/decode path)
     std::vector<uint8_t> pb;
     auto add = [&](const void* p, size_t n) { size_t off = (pb.size() + 255) / 256 * 256; pb.resize(off + n); memcpy(pb.data() + off, p, n); return off; };
-    size_t o0 = add(&M->enc0, sizeof M->enc0), o1 = add(&M->enc1, sizeof M->enc1), o2 = add(&M->enc2, sizeof M->enc2);
-    size_t o3 = add(&M->dec0, sizeof M->dec0), o4 = add(&M->dec1, sizeof M->dec1), o5 = add(&M->dec2, sizeof M->dec2);
     size_t o6 = add(&M->mel, sizeof M->mel), o7 = add(&M->reset, sizeof M->reset);
     if (hipMalloc((void**)&M->d_params, pb.size()) != hipSuccess ||
         hipMemcpy(M->d_params, pb.data(), pb.size(), hipMemcpyHostToDevice) != hipSuccess) {
       *err = "uploading parameter blocks failed";
       return false;
     }
-    M->d_enc0 = (EncS0P*)(M->d_params + o0); M->d_enc1 = (EncS1P*)(M->d_params + o1); M->d_enc2 = (EncS2P*)(M->d_params + o2);
-    M->d_dec0 = (DecS0P*)(M->d_params + o3); M->d_dec1 = (DecS1P*)(M->d_params + o4); M->d_dec2 = (DecS2P*)(M->d_params + o5);
     M->d_mel = (MelP*)(M->d_params + o6); M->d_reset = (ResetP*)(M->d_params + o7);
   }
   return true;

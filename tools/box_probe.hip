@@ -172,6 +172,57 @@ static void run_code(const char* name, K kern, int* dout) {
   printf("   %-36s %8.3f ms\n", name, ms);
 }
 
+// ---- scattered HBM reads (TLB reach / fragment size): every thread reads 16 bytes from `touches` pseudo-random
+// 128-byte lines of a buffer of `span_mb` MB
+__global__ void scatter(const int* buf, unsigned lines, int touches, int* out) {
+  unsigned x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+  int acc = 0;
+  for (int i = 0; i < touches; ++i) {
+    x = x * 1664525u + 1013904223u;
+    const unsigned l = (x >> 4) % lines;
+    acc += buf[(size_t)l * 32 + (threadIdx.x & 3)];
+  }
+  if (acc == 0x12345678) out[0] = acc;
+}
+static void run_scatter(const int* buf, size_t span_mb, int* dout) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const unsigned lines = (unsigned)(span_mb * 1024 * 1024 / 128);
+  const int blocks = 2048, threads = 256, touches = 16;
+  hipLaunchKernelGGL(scatter, dim3(blocks), dim3(threads), 0, 0, buf, lines, touches, dout);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(scatter, dim3(blocks), dim3(threads), 0, 0, buf, lines, touches, dout);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("   random 128 B lines over %4zu MB: %8.3f ms  (%.1f G lines/s)\n", span_mb, ms,
+         (double)blocks * threads * touches / ms / 1e6);
+}
+
+// ---- HBM latency: dependent random loads over a 1 GB buffer (each thread its own chain)
+__global__ void chase(const unsigned* buf, unsigned words, int hops, long long* out) {
+  unsigned p = (blockIdx.x * blockDim.x + threadIdx.x) * 40503u % words;
+  for (int i = 0; i < 4; ++i) p = buf[p] % words;
+  long long t0 = clock64();
+  for (int i = 0; i < hops; ++i) p = buf[p] % words;
+  long long t1 = clock64();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (p == 0xFFFFFFFFu) out[0] = 0;
+}
+static void run_chase(const unsigned* buf, unsigned words, int blocks, int threads, long long* dout) {
+  const int hops = 64;
+  hipLaunchKernelGGL(chase, dim3(blocks), dim3(threads), 0, 0, buf, words, hops, dout);
+  hipDeviceSynchronize();
+  std::vector<long long> h(blocks);
+  hipMemcpy(h.data(), dout, blocks * 8, hipMemcpyDeviceToHost);
+  double s = 0;
+  for (auto v : h) s += (double)v;
+  printf("   dependent random loads over 1 GB, %4d WG x %3d thr: %8.0f cycles per hop\n", blocks, threads,
+         s / blocks / hops);
+}
+
 template <int CLS>
 static void run_tput(const char* name, int* dout) {
   hipEvent_t e0, e1;
@@ -227,6 +278,30 @@ int main() {
   run_tput<5>("lds b128 read", dres);
   run_tput<6>("mfma i8 16x16x64 x4", dres);
   run_tput<7>("mfma f32 16x16x4 x4", dres);
+  printf("== scattered reads\n");
+  {
+    int* big;
+    hipMalloc(&big, (size_t)1024 << 20);
+    hipMemset(big, 1, (size_t)1024 << 20);
+    run_scatter(big, 2, dres);
+    run_scatter(big, 32, dres);
+    run_scatter(big, 256, dres);
+    run_scatter(big, 1024, dres);
+    {  // fill with pseudo-random indices for the latency chase
+      std::vector<unsigned> hidx((size_t)256 << 20);
+      unsigned x = 1;
+      for (auto& v : hidx) { x = x * 1664525u + 1013904223u; v = x >> 2; }
+      hipMemcpy(big, hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice);
+      long long* dl;
+      hipMalloc(&dl, 4096 * 8);
+      printf("== HBM latency\n");
+      run_chase((const unsigned*)big, 256u << 20, 1, 64, dl);
+      run_chase((const unsigned*)big, 256u << 20, 256, 64, dl);
+      run_chase((const unsigned*)big, 256u << 20, 1024, 256, dl);
+      hipFree(dl);
+    }
+    hipFree(big);
+  }
   printf("== instruction fetch: 512 WG x 512 threads, 20 passes of 8192 VALU ops\n");
   run_code("straight-line 64 KB body", bigcode, dres);
   run_code("compact loop", smallcode, dres);
