@@ -65,6 +65,18 @@ def _load():
     if not os.path.exists(path):
         raise LyraHipError(f"{path} not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; if the system copy gets loaded first
+    # (through liblyra_hip.so's dependency) and torch is imported later, torch finds "No HIP GPUs".  Callers that
+    # mix this library with torch tensors (the *_dev entry points) are safe regardless of import order if torch's
+    # runtime is the one already resident when liblyra_hip.so is opened.
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None and \
+            os.environ.get("LYRA_HIP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(path)
     vp, ci, cp = C.c_void_p, C.c_int, C.c_char_p
     L.lyra_hip_create.argtypes = [cp, ci, ci, ci, C.POINTER(vp)]

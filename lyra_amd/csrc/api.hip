@@ -244,14 +244,16 @@ int launch_rvq_decode(lyra_hip_ctx* c, int k, int B, const int32_t* d_idx, const
   return 0;
 }
 
-int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm) {
+// d_feat != nullptr: features -> PCM.  d_feat == nullptr: packets -> PCM with the RVQ decode fused into stage 0.
+int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, const float* d_feat, int16_t* d_pcm,
+                    const uint8_t* d_pkt = nullptr, int num_stages = 0) {
   const Model& M = c->model;
   hipStream_t st_ = c->sd[k];
   float* d0 = c->d_d0 + (size_t)lo * 512;
   float* d1 = c->d_d1 + (size_t)lo * 1280;
   { ProfScope ps(c, K_DEC_S0, st_);
     hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), st_,
-                       M.d_dec0, d_feat, d_ids, B, c->d_state, d0); }
+                       M.d_dec0, d_feat, d_ids, B, c->d_state, d0, d_pkt, num_stages, M.cb); }
   { ProfScope ps(c, K_DEC_S1, st_);
     hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(256), dec_s1_lds_bytes(), st_,
                        M.d_dec1, d0, d_ids, B, c->d_state, d1); }
@@ -497,9 +499,8 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
     dec_side_begin(c, k);
-    float* lossy = c->d_lossy + (size_t)lo * 64;
-    rc = launch_rvq_decode(c, k, n, nullptr, d_packets + (size_t)lo * nbytes, num_bits / 4, lossy);
-    if (!rc) rc = launch_generate(c, k, lo, d_ids + lo, n, lossy, d_pcm + (size_t)lo * 320);
+    rc = launch_generate(c, k, lo, d_ids + lo, n, nullptr, d_pcm + (size_t)lo * 320,
+                         d_packets + (size_t)lo * nbytes, num_bits / 4);
     dec_side_done(c, k, nk);
   }
   c->n_dec_calls++;

@@ -51,9 +51,14 @@ size_t dec_s0_lds_bytes() {
 }
 int dec_s0_streams_per_wg() { return SD0; }
 
+// feats != nullptr: lossy features [B][64] (GenerativeModel::AddFeatures path).  Otherwise the features are rebuilt
+// here from the packets exactly as rvq_decode_kernel does (quantizer.tflite `decode` + DecodeToLossyFeatures,
+// residual_vector_quantizer.cc:112-168): ((v0 + v1) + v2) + ... left to right, unused stages contribute v * 0.0f.
 __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                        const int32_t* __restrict__ ids, int B,
-                                                       uint8_t* __restrict__ state, float* __restrict__ out0) {
+                                                       uint8_t* __restrict__ state, float* __restrict__ out0,
+                                                       const uint8_t* __restrict__ packets, int num_stages,
+                                                       const float* __restrict__ cb) {
   const DecS0P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* FB = smem;                                   // [3][16][72]: two history rows + new features (rows s < S used)
@@ -81,14 +86,31 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   }
   load_luts<NTD0>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NTD0, 1>(P.warm);
+  const auto warm_cb = l2_warm<NTD0, 1>(feats ? WarmRange{nullptr, 0} : WarmRange{reinterpret_cast<const uint8_t*>(cb), 46 * 16 * 64 * 4});
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
 
   // ---- feature window [f-2, f-1, f] (history ring R=2, T=1); GEMM rows = streams, 16-row tile ----------
-  for (int idx = tid; idx < SD0 * 64; idx += NTD0) {
-    int c = idx & 63, s = idx >> 6;
-    int b = min(b0 + s, B - 1);
-    FB[(2 * 16 + s) * FS + at16(c)] = feats[(size_t)b * 64 + c];
+  {
+    const int c = tid & 63, s = tid >> 6;          // SD0 * 64 == NTD0: one feature element per thread
+    const int b = min(b0 + s, B - 1);
+    float f;
+    if (feats) {
+      f = feats[(size_t)b * 64 + c];
+    } else {
+      const int nbytes = (num_stages + 1) >> 1;
+      const uint8_t* pk = packets + (size_t)b * nbytes;
+      f = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 46; ++k) {
+        const int id = k < num_stages ? ((pk[k >> 1] >> ((k & 1) ? 0 : 4)) & 15) : -1;
+        const float mask = id != -1 ? 1.f : 0.f;
+        const int i = id < 0 ? 0 : id;
+        const float v = cb[((size_t)k * 16 + i) * 64 + c] * mask;
+        f = k == 0 ? v : f + v;
+      }
+    }
+    FB[(2 * 16 + s) * FS + at16(c)] = f;
   }
   for (int idx = tid; idx < 2 * SD0 * 16; idx += NTD0) {
     int p4 = idx & 15, s = (idx >> 4) & (SD0 - 1), j = (idx >> 4) / SD0;
@@ -311,6 +333,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   LYRA_TSTAMP(48);
   LYRA_WSTAMP(101);
   LYRA_WG_END();
+  l2_warm_sink(warm_cb, state, B);
   l2_warm_sink(warm, state, B);
 }
 

@@ -50,7 +50,8 @@ struct DecS0P {
 struct DecS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; const float* up_sub; WarmRange warm; };
 struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; WarmRange warm; };
 
-__global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0);
+__global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0,
+                              const uint8_t* packets, int num_stages, const float* cb);
 __global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
 __global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm);
 size_t dec_s0_lds_bytes(); int dec_s0_streams_per_wg();

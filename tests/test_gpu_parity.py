@@ -262,3 +262,40 @@ def test_full_size_properties(ctx, oracle_exact, B, bits):
     ctx.reset()
     b = ctx.decode(r["packets"][0], bits, np.arange(64, dtype=np.int32))
     assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# the device-pointer pipeline exactly as bench.py drives it (two alternating buffers, no caller sync between
+# encode and decode, encode of step i+1 overlapping decode of step i on the library's two streams)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,bits", [(37, 184), (1000, 64), (4096, 184)])
+def test_device_pipeline_as_benchmarked(ctx, oracle_exact, B, bits):
+    import torch
+    import lyra_amd
+    from oracle import lyra_oracle
+    T, R = 6, min(B, 48)
+    base = synth(R, T, seed=4242 + B)
+    r = lyra_oracle.run_batch(oracle_exact, base, bits // 4, do_decode=True, threads=8)
+    dev = torch.device("cuda", 0)
+    pcm = torch.from_numpy(base[:, np.arange(B) % R].copy()).to(dev)
+    ids = torch.arange(B, device=dev, dtype=torch.int32)
+    nb = lyra_amd.packet_size(bits)
+    packets = [torch.empty((B, nb), device=dev, dtype=torch.uint8) for _ in range(2)]
+    out = [torch.empty((B, 320), device=dev, dtype=torch.int16) for _ in range(2)]
+    keep_pk, keep_pcm = [], []
+    ctx.reset()
+    torch.cuda.synchronize()
+    for t in range(T):
+        ctx.encode_dev(ids, pcm[t], bits, packets[t & 1])
+        ctx.decode_dev(ids, packets[t & 1], bits, out[t & 1])
+        if t % 2 == 1:   # sync only every other step: consecutive steps overlap in between
+            ctx.synchronize()
+            keep_pk.append((t, packets[t & 1].cpu().numpy()))
+            keep_pcm.append((t, out[t & 1].cpu().numpy()))
+    ctx.synchronize()
+    for t, pk in keep_pk:
+        assert np.array_equal(pk[:R], r["packets"][t]), f"packets differ at step {t}"
+        assert np.array_equal(pk, pk[np.arange(B) % R])
+    for t, o in keep_pcm:
+        assert np.array_equal(o[:R], r["pcm"][t]), f"PCM differs at step {t}"
+        assert np.array_equal(o, o[np.arange(B) % R])

@@ -213,8 +213,9 @@ __global__ void chase(const unsigned* buf, unsigned words, int hops, long long* 
 }
 static void run_chase(const unsigned* buf, unsigned words, int blocks, int threads, long long* dout) {
   const int hops = 64;
+  hipMemset(dout, 0, blocks * 8);
   hipLaunchKernelGGL(chase, dim3(blocks), dim3(threads), 0, 0, buf, words, hops, dout);
-  hipDeviceSynchronize();
+  if (hipDeviceSynchronize() != hipSuccess) printf("   (chase kernel failed: %s)\n", hipGetErrorString(hipGetLastError()));
   std::vector<long long> h(blocks);
   hipMemcpy(h.data(), dout, blocks * 8, hipMemcpyDeviceToHost);
   double s = 0;
@@ -288,10 +289,12 @@ int main() {
     run_scatter(big, 256, dres);
     run_scatter(big, 1024, dres);
     {  // fill with pseudo-random indices for the latency chase
-      std::vector<unsigned> hidx((size_t)256 << 20);
+      std::vector<unsigned> hidx((size_t)64 << 20);   // 256 MB of pseudo-random indices, replicated 4x
       unsigned x = 1;
       for (auto& v : hidx) { x = x * 1664525u + 1013904223u; v = x >> 2; }
-      hipMemcpy(big, hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice);
+      for (int rep = 0; rep < 4; ++rep)
+        if (hipMemcpy((char*)big + ((size_t)rep << 28), hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+          printf("   (hipMemcpy of the chase table failed: %s)\n", hipGetErrorString(hipGetLastError()));
       long long* dl;
       hipMalloc(&dl, 4096 * 8);
       printf("== HBM latency\n");
