@@ -50,11 +50,6 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   const int b0 = blockIdx.x * S0;
   LYRA_WG_BEGIN();
   LYRA_TSTAMP(0);
-#ifdef LYRA_STAGGER
-  // Workgroups that share a CU (blockIdx differing by multiples of 256) start in lock-step and, running identical
-  // code, stay there: all in MFMA phases together, all in VALU phases together.  Offset their start.
-  for (int k = (int)(((blockIdx.x >> 8) + (blockIdx.x >> 3)) & 3) * LYRA_STAGGER; k > 0; --k) __builtin_amdgcn_s_sleep(32);
-#endif
   if (tid < S0) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NT0, 1>(P.warm);
   __syncthreads();

@@ -135,13 +135,10 @@ __device__ __forceinline__ const T LYRA_GLOBAL* as_global(const T* p) {
 // Software-pipelined: the B fragments (L2, ~500+ cycles) and A fragments (LDS) of chunk c+PF are requested
 // before the MFMAs of chunk c issue; the K loop is fully unrolled so the PF+1 register stages are static and
 // the compiler emits counted s_waitcnt (the prefetches stay in flight across the MFMA block).
-#ifndef LYRA_PF_SCALE
-#define LYRA_PF_SCALE 1
-#endif
 //   KS   = K-chunk stride between a tile's fragments in memory (> KC when only part of the packed K range is run)
 //   ZERO = start the chains from 0; otherwise acc carries values in (a chain continued from an earlier GEMM)
 template <int MTW, int NTW, int KC, int KS = KC, bool ZERO = true,
-          int PF = LYRA_PF_SCALE * (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
 __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                          f32x4 (&acc)[MTW][NTW]) {
   const int lane = threadIdx.x & 63;
@@ -177,11 +174,7 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
-#ifdef LYRA_ABL_NOMFMA
-          asm volatile("" ::"v"(aq[cur][i][kk]), "v"(bq[cur][j][kk]));
-#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], acc[i][j], 0, 0, 0);
-#endif
   }
 }
 
@@ -189,11 +182,7 @@ template <int MTW, int NTW, int KC, class AOff>
 __device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32x4* bfrag_generic,
                                         i32x4 (&acc)[MTW][NTW]) {
   const int lane = threadIdx.x & 63;
-#ifdef LYRA_I8_FLAT
-  const i32x4* bfrag = bfrag_generic;
-#else
   const i32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic);
-#endif
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll

@@ -20,89 +20,13 @@ struct TileCtx {
 };
 
 // ---- 64 channels x 20 rows; S streams per workgroup of NT threads: (S, NT) = (4, 256) or (8, 512) -------------
-// X: [20][S][72] floats, D: same shape.  T = 20 >= 2*dilation, so histories are simply replaced.
-// GEMM [20*S rows] x 64 x 64: wave = (N tile wn = wave & 3, M group wm = wave >> 2), 5 M tiles per wave.
-template <int S, int NT>
-__device__ __forceinline__ void resblocks64(float* X, float* D, const TileCtx& cx, const DwF* dws, const ConvF* pws,
-                                            const ConvF* cvs, int off0, int off1, int off2) {
-  constexpr int CS = 72;
-  static_assert(20 * S / 16 == 5 * (NT / 256), "5 M tiles per wave");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, q = lane >> 4;
-  const int wn = wave & 3, wm = wave >> 2;
-  const int ncol = wn * 16 + (lane & 15);
-  const int pcol = at16(ncol);
-#pragma unroll 1
-  for (int r = 0; r < 3; ++r) {
-    const int d = r == 0 ? 1 : (r == 1 ? 3 : 9);
-    const int R2 = 2 * d;
-    const int off = r == 0 ? off0 : (r == 1 ? off1 : off2);
-    const DwF dw = dws[r];
-    LYRA_TSTAMP(10 + r * 8 + 0);
-#ifndef LYRA_ABL_NODW
-    for (int idx = tid; idx < 20 * S * 16; idx += NT) {
-      int p4 = idx & 15, s = (idx >> 4) & (S - 1), t = (idx >> 4) / S;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        int tau = t - (2 - j) * d;
-        f32x4 v;
-        if (tau >= 0) v = lrelu4(*reinterpret_cast<const f32x4*>(&X[(tau * S + s) * CS + p4 * 4]));
-        else v = *reinterpret_cast<const f32x4*>(cx.sbase(s) + off + ((R2 + tau) * 64 + p4 * 4) * 4);
-        acc = fma4(v, *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dw.w) + j * 64 + p4 * 4), acc);
-      }
-      f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dw.b) + p4 * 4);
-      *reinterpret_cast<f32x4*>(&D[(t * S + s) * CS + p4 * 4]) = acc + bb;
-    }
-#endif
-    __syncthreads();
-    LYRA_TSTAMP(10 + r * 8 + 1);
-    for (int idx = tid; idx < R2 * S * 16; idx += NT) {
-      int p4 = idx & 15, s = (idx >> 4) & (S - 1), j = (idx >> 4) / S;
-      if (cx.valid(s))
-        *reinterpret_cast<f32x4*>(cx.sbase(s) + off + (j * 64 + p4 * 4) * 4) =
-            lrelu4(*reinterpret_cast<const f32x4*>(&X[((20 - R2 + j) * S + s) * CS + p4 * 4]));
-    }
-    LYRA_TSTAMP(10 + r * 8 + 2);
-    auto aoff = [&](int i, int c) { return ((wm * 5 + i) * 16 + m) * CS + c * 16 + q * 4; };
-    {
-      f32x4 acc[5][1];
-      gemm_f32<5, 1, 4>(D, aoff, pws[r].w + wn * 4 * 64, acc);
-      float bias = as_global(pws[r].b)[ncol];
-      LYRA_TSTAMP(10 + r * 8 + 3);
-      __syncthreads();
-      LYRA_TSTAMP(10 + r * 8 + 4);
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) D[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][0][e] + bias);
-      __syncthreads();
-      LYRA_TSTAMP(10 + r * 8 + 5);
-    }
-    {
-      f32x4 acc[5][1];
-      gemm_f32<5, 1, 4>(D, aoff, cvs[r].w + wn * 4 * 64, acc);
-      float bias = as_global(cvs[r].b)[ncol];
-      LYRA_TSTAMP(10 + r * 8 + 6);
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float* x = &X[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol];
-          *x = (acc[i][0][e] + bias) + *x;
-        }
-    }
-    __syncthreads();
-    LYRA_TSTAMP(10 + r * 8 + 7);
-  }
-}
-
-// ---- same triplet with the residual stream X resident in REGISTERS (MFMA C layout) ------------------------------
+// T = 20 >= 2*dilation, so histories are simply replaced.  GEMM [20*S rows] x 64 x 64: wave = (N tile wn = wave & 3,
+// M group wm = wave >> 2), 5 M tiles per wave.  The residual stream X lives in REGISTERS (MFMA C layout):
 // xr[i][0][e] = X[row (wm*5+i)*16 + 4q + e][channel wn*16 + (lane&15)].  Only ONE LDS matrix A[20][S][72] is needed
 // (it carries lrelu(X), then the depthwise output, then the pointwise output in turn), so a tile of S = 4 streams
 // takes < 30 KB and four workgroups fit on a CU -- the whole B = 4096 batch is resident in one wave of workgroups.
-// The depthwise conv runs in the C layout: each lane produces the (row, channel) elements it owns from three
-// LDS rows; the residual add is a register add.
+// The depthwise conv runs on (row, channel quad) items with 16-byte LDS / history accesses; the residual add is a
+// register add.
 template <int S, int NT>
 __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const TileCtx& cx, const DwF* dws,
                                              const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2) {
@@ -255,8 +179,8 @@ __device__ __forceinline__ Hist128 hist128_prefetch(const TileCtx& cx, int d, in
   return H;
 }
 
-template <int S, int NT>
 // H: hist128_prefetch(cx, 1, off0), requested by the caller together with the stage input.
+template <int S, int NT>
 __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& cx, const DwF* dws,
                                              const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2,
                                              Hist128 H) {
