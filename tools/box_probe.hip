@@ -201,29 +201,6 @@ static void run_scatter(const int* buf, size_t span_mb, int* dout) {
          (double)blocks * threads * touches / ms / 1e6);
 }
 
-// ---- HBM latency: dependent random loads over a 1 GB buffer (each thread its own chain)
-__global__ void chase(const unsigned* buf, unsigned words, int hops, long long* out) {
-  unsigned p = (blockIdx.x * blockDim.x + threadIdx.x) * 40503u % words;
-  for (int i = 0; i < 4; ++i) p = buf[p] % words;
-  long long t0 = clock64();
-  for (int i = 0; i < hops; ++i) p = buf[p] % words;
-  long long t1 = clock64();
-  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-  if (p == 0xFFFFFFFFu) out[0] = 0;
-}
-static void run_chase(const unsigned* buf, unsigned words, int blocks, int threads, long long* dout) {
-  const int hops = 64;
-  hipMemset(dout, 0, blocks * 8);
-  hipLaunchKernelGGL(chase, dim3(blocks), dim3(threads), 0, 0, buf, words, hops, dout);
-  if (hipDeviceSynchronize() != hipSuccess) printf("   (chase kernel failed: %s)\n", hipGetErrorString(hipGetLastError()));
-  std::vector<long long> h(blocks);
-  hipMemcpy(h.data(), dout, blocks * 8, hipMemcpyDeviceToHost);
-  double s = 0;
-  for (auto v : h) s += (double)v;
-  printf("   dependent random loads over 1 GB, %4d WG x %3d thr: %8.0f cycles per hop\n", blocks, threads,
-         s / blocks / hops);
-}
-
 template <int CLS>
 static void run_tput(const char* name, int* dout) {
   hipEvent_t e0, e1;
@@ -288,21 +265,6 @@ int main() {
     run_scatter(big, 32, dres);
     run_scatter(big, 256, dres);
     run_scatter(big, 1024, dres);
-    {  // fill with pseudo-random indices for the latency chase
-      std::vector<unsigned> hidx((size_t)64 << 20);   // 256 MB of pseudo-random indices, replicated 4x
-      unsigned x = 1;
-      for (auto& v : hidx) { x = x * 1664525u + 1013904223u; v = x >> 2; }
-      for (int rep = 0; rep < 4; ++rep)
-        if (hipMemcpy((char*)big + ((size_t)rep << 28), hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-          printf("   (hipMemcpy of the chase table failed: %s)\n", hipGetErrorString(hipGetLastError()));
-      long long* dl;
-      hipMalloc(&dl, 4096 * 8);
-      printf("== HBM latency\n");
-      run_chase((const unsigned*)big, 256u << 20, 1, 64, dl);
-      run_chase((const unsigned*)big, 256u << 20, 256, 64, dl);
-      run_chase((const unsigned*)big, 256u << 20, 1024, 256, dl);
-      hipFree(dl);
-    }
     hipFree(big);
   }
   printf("== instruction fetch: 512 WG x 512 threads, 20 passes of 8192 VALU ops\n");
