@@ -101,8 +101,8 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
       const int nbytes = (num_stages + 1) >> 1;
       const uint8_t* pk = packets + (size_t)b * nbytes;
       f = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < 46; ++k) {
+#pragma unroll 23
+      for (int k = 0; k < 46; ++k) {   // addresses depend only on the packet: 23 codebook loads in flight at a time
         const int id = k < num_stages ? ((pk[k >> 1] >> ((k & 1) ? 0 : 4)) & 15) : -1;
         const float mask = id != -1 ? 1.f : 0.f;
         const int i = id < 0 ? 0 : id;
