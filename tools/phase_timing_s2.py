@@ -7,8 +7,22 @@ os.environ["LYRA_HIP_LIB"] = os.path.join(ROOT, "lyra_amd", "variants", "timing.
 import lyra_amd
 ctx = lyra_amd.LyraHip(max_streams=4096)
 pcm = np.random.default_rng(0).integers(-32768, 32768, size=(4096, 320)).astype(np.int16)
-for _ in range(3):
-    ctx.extract(pcm)
+if os.environ.get("MODE") == "full":   # sustained encode+decode pipeline, as benchmarked
+    import torch
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    ids = torch.arange(4096, device=dev, dtype=torch.int32)
+    pk = [torch.empty((4096, 23), device=dev, dtype=torch.uint8) for _ in range(2)]
+    out = [torch.empty((4096, 320), device=dev, dtype=torch.int16) for _ in range(2)]
+    for i in range(int(os.environ.get("STEPS", 200))):
+        ctx.encode_dev(ids, d_pcm, 184, pk[i & 1])
+        ctx.decode_dev(ids, pk[i & 1], 184, out[i & 1])
+        if os.environ.get("SERIAL") == "1":
+            ctx.synchronize()
+    ctx.synchronize()
+else:
+    for _ in range(3):
+        ctx.extract(pcm)
 buf = (ctypes.c_longlong * 128)()
 ctx.L.lyra_hip_debug_timing_s2(buf)
 t = np.array(buf[:])
