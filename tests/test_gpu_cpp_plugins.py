@@ -60,6 +60,61 @@ def test_cpp_batch_codec_twins(oracle_exact, golden_dir, tmp_path, bitrate):
     assert np.array_equal(out, ref["pcm"])
 
 
+def _write_wav(path, pcm, rate=16000):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(np.asarray(pcm, np.int16).tobytes())
+
+
+def _read_wav(path):
+    import wave
+    with wave.open(str(path), "rb") as w:
+        assert w.getnchannels() == 1 and w.getsampwidth() == 2 and w.getframerate() == 16000
+        return np.frombuffer(w.readframes(w.getnframes()), np.int16)
+
+
+@pytest.mark.gpu
+def test_cpp_file_transcode_ragged_batch(oracle_exact, golden_dir, tmp_path):
+    """EncodeFiles / DecodeFiles: several WAV files of different lengths transcoded together
+    (streams leave the batch as they run out of full hops; a trailing partial hop is dropped as
+    encoder_main_lib.cc:71-73 does).  .lyra bytes and decoded samples must equal the oracle's per file."""
+    import lyra_amd
+    from oracle import lyra_oracle
+    demo = os.path.join(ROOT, "lyra_amd", "file_demo")
+    assert os.path.exists(demo), "lyra_amd/file_demo not built (__graft_entry__.build())"
+    speech = np.load(os.path.join(golden_dir, "speech_sample1.npz"))["pcm_in"].reshape(-1)   # 50 hops
+    noise = np.load(os.path.join(golden_dir, "noise_4x6.npz"))["pcm_in"]                      # [6][4][320]
+    files = {
+        "speech_long": speech[:320 * 17 + 111],            # 17 full hops + a partial one
+        "speech_short": speech[320 * 20:320 * 25],          # 5 hops
+        "noise_a": noise[:, 0].reshape(-1),                 # 6 hops
+        "noise_b": np.concatenate([noise[:, 1].reshape(-1), noise[:3, 2].reshape(-1)])[:-7],  # 8 hops + partial
+        "tiny": speech[:100],                               # no full hop at all -> empty .lyra
+    }
+    wavs = []
+    for name, pcm in files.items():
+        _write_wav(tmp_path / f"{name}.wav", pcm)
+        wavs.append(str(tmp_path / f"{name}.wav"))
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    r = subprocess.run([demo, lyra_amd.default_model_dir(), "6000", str(out_dir)] + wavs,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    for name, pcm in files.items():
+        hops = len(pcm) // 320
+        enc = np.fromfile(out_dir / f"{name}.lyra", np.uint8)
+        dec = _read_wav(out_dir / f"{name}_decoded.wav")
+        assert enc.size == hops * 15 and dec.size == hops * 320
+        if hops == 0:
+            continue
+        ref = lyra_oracle.run_batch(oracle_exact, pcm[:hops * 320].reshape(hops, 1, 320), 120 // 4, do_decode=True)
+        assert np.array_equal(enc.reshape(hops, 15), ref["packets"][:, 0]), name
+        assert np.array_equal(dec.reshape(hops, 320), ref["pcm"][:, 0]), name
+
+
 def test_cpp_plugins_build_and_link():
     """CPU side: the adapters compile against the C ABI and export the lyra_components factory names."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "lyra_amd", "host")], stdout=subprocess.DEVNULL)
@@ -67,5 +122,6 @@ def test_cpp_plugins_build_and_link():
                          capture_output=True, text=True).stdout
     for name in ("CreateQuantizer", "CreateGenerativeModel", "CreateFeatureExtractor", "CreateLogMelExtractor",
                  "BatchLyraEncoder::Create", "BatchLyraEncoder::Encode", "BatchLyraDecoder::SetEncodedPackets",
-                 "BatchLyraDecoder::DecodeSamples"):
+                 "BatchLyraDecoder::DecodeSamples", "EncodeFiles", "DecodeFiles", "EncodeWavs",
+                 "DecodeFeaturesBatch", "ReadWav16", "WriteWav16"):
         assert f"chromemedia::codec::{name}(" in out
