@@ -17,7 +17,9 @@
  *
  * Threading: calls on one context must be serialised by the caller (as for one
  * reference codec object); distinct contexts are independent.  A batch must not
- * name the same stream id twice.  All functions return 0 on success or a
+ * name the same stream id twice (two frames of one stream in a call would race on its state): host-pointer variants
+ * reject it with LYRA_HIP_EINVAL, `_dev` variants cannot look at the ids and rely on the caller.
+ * All functions return 0 on success or a
  * negative LYRA_HIP_E* code; lyra_hip_last_error() describes the last failure.
  * There is NO CPU fallback: creating a context without a usable gfx950 device
  * fails.

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -60,6 +61,8 @@ struct lyra_hip_ctx {
   struct Span { int kid; hipEvent_t a, b; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> event_pool;
+  std::vector<uint32_t> id_stamp;  // duplicate detection for host id lists: id_stamp[id] == id_gen <=> seen in this call
+  uint32_t id_gen = 0;
   std::string err;
 };
 
@@ -145,9 +148,15 @@ int check_bits(lyra_hip_ctx* c, int num_bits) {
 
 int check_ids_host(lyra_hip_ctx* c, const int32_t* ids, int B) {
   if (!ids) return fail(c, LYRA_HIP_EINVAL, "stream_ids is null");
-  for (int i = 0; i < B; ++i)
+  if (c->id_stamp.size() != (size_t)c->max_streams) c->id_stamp.assign(c->max_streams, 0);
+  if (++c->id_gen == 0) { std::fill(c->id_stamp.begin(), c->id_stamp.end(), 0u); c->id_gen = 1; }
+  for (int i = 0; i < B; ++i) {
     if (ids[i] < 0 || ids[i] >= c->max_streams)
       return fail(c, LYRA_HIP_EINVAL, "stream id %d at position %d outside 0..%d", ids[i], i, c->max_streams - 1);
+    if (c->id_stamp[ids[i]] == c->id_gen)   // two frames of one stream in a batch would race on its state
+      return fail(c, LYRA_HIP_EINVAL, "stream id %d appears twice in the batch (position %d)", ids[i], i);
+    c->id_stamp[ids[i]] = c->id_gen;
+  }
   return 0;
 }
 

@@ -11,7 +11,17 @@
 using namespace chromemedia::codec;
 namespace fs = ghc::filesystem;
 
+// --selftest-wav <in.wav> <out.wav>: read with ReadWav16, write back with WriteWav16 (CPU only; used by the tests)
+static int SelftestWav(const char* in, const char* out) {
+  std::vector<int16_t> samples;
+  int ch = 0, rate = 0;
+  if (!ReadWav16(in, &samples, &ch, &rate)) return 6;
+  std::printf("%d %d %zu\n", ch, rate, samples.size());
+  return WriteWav16(out, samples, ch, rate) ? 0 : 7;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4 && std::string(argv[1]) == "--selftest-wav") return SelftestWav(argv[2], argv[3]);
   if (argc < 5) { std::fprintf(stderr, "usage: %s model_dir bitrate out_dir a.wav [b.wav ...]\n", argv[0]); return 2; }
   const fs::path model_dir = argv[1], out_dir = argv[3];
   const int bitrate = std::atoi(argv[2]);

@@ -115,6 +115,30 @@ def test_cpp_file_transcode_ragged_batch(oracle_exact, golden_dir, tmp_path):
         assert np.array_equal(dec.reshape(hops, 320), ref["pcm"][:, 0]), name
 
 
+def test_cpp_wav_io_roundtrip(tmp_path):
+    """CPU side: the RIFF/WAVE PCM16 reader/writer of lyra_file_codec (the reference uses audio_dsp's wav_util):
+    reads what Python's wave module writes (also with an odd-sized extra chunk before `data`), writes what it reads."""
+    import struct
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "lyra_amd", "host")], stdout=subprocess.DEVNULL)
+    demo = os.path.join(ROOT, "lyra_amd", "file_demo")
+    pcm = (np.arange(1000) * 37 % 65536 - 32768).astype(np.int16)
+    a, b, c = tmp_path / "a.wav", tmp_path / "b.wav", tmp_path / "c.wav"
+    _write_wav(a, pcm)
+    raw = open(a, "rb").read()
+    # splice a LIST chunk of odd length (padded to even) between fmt and data
+    extra = b"LIST" + struct.pack("<I", 5) + b"hello" + b"\0"
+    spliced = raw[:36] + extra + raw[36:]
+    spliced = spliced[:4] + struct.pack("<I", len(spliced) - 8) + spliced[8:]
+    open(b, "wb").write(spliced)
+    for src in (a, b):
+        r = subprocess.run([demo, "--selftest-wav", str(src), str(c)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, (r.returncode, r.stderr)
+        assert r.stdout.split() == ["1", "16000", "1000"]
+        assert np.array_equal(_read_wav(c), pcm)
+    open(b, "wb").write(raw[:20] + struct.pack("<H", 3) + raw[22:])   # format tag 3 (float): must be rejected
+    assert subprocess.run([demo, "--selftest-wav", str(b), str(c)], capture_output=True).returncode == 6
+
+
 def test_cpp_plugins_build_and_link():
     """CPU side: the adapters compile against the C ABI and export the lyra_components factory names."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "lyra_amd", "host")], stdout=subprocess.DEVNULL)

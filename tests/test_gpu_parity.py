@@ -183,6 +183,10 @@ def test_argument_validation(ctx):
         ctx.encode(pcm, 62)   # not divisible by 4
     with pytest.raises(lyra_amd.LyraHipError):
         ctx.encode(pcm, 64, np.array([0, 999999], np.int32))
+    with pytest.raises(lyra_amd.LyraHipError):
+        ctx.encode(pcm, 64, np.array([3, 3], np.int32))   # one stream twice in a batch would race on its state
+    with pytest.raises(lyra_amd.LyraHipError):
+        ctx.decode(np.zeros((2, 8), np.uint8), 64, np.array([7, 7], np.int32))
     q = lyra_amd.ResidualVectorQuantizer(ctx)
     feat = np.zeros(64, np.float32)
     assert q.Quantize(feat, 185) is None and q.Quantize(feat, 62) is None
