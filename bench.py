@@ -51,7 +51,7 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
     ap.add_argument("--bits", type=int, default=NUM_BITS)
