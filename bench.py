@@ -45,6 +45,7 @@ KERNEL_WORK = {
     "dec_s2_kernel": dict(f32=584960, i8=0, bytes=20 * 64 * 4 + 2 * (26 * 64 + 48) * 4 + 640),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_I8_MFMA_TOPS = 3944.0      # same guide: v_mfma_i32_16x16x64_i8, dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -240,7 +241,10 @@ def main():
             traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    if w["f32"] > 0:
+    # the binding bound of this kernel: whichever of (fp32 MFMA + int8 MFMA time) and HBM time is longer at peak
+    t_mfma = 2 * w["f32"] * B / (PEAK_F32_MFMA_TFLOPS * 1e12) + 2 * w["i8"] * B / (PEAK_I8_MFMA_TOPS * 1e12)
+    t_hbm = w["bytes"] * B / (PEAK_HBM_GBS * 1e9)
+    if t_mfma >= t_hbm:
         ach = 2 * w["f32"] * B / dur / 1e12
         roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
