@@ -18,6 +18,7 @@
 
 #include "../../include/lyra_hip.h"
 #include "model.h"
+#include "tflite_pack.h"
 
 using namespace lyra;
 
@@ -307,8 +308,15 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
 
   Pack pk;
   std::string err;
+  // Either the pre-packed container or -- as the reference's factories get it -- a model directory with the three
+  // .tflite graphs and lyra_config.binarypb (lyra_components.cc:42-55, lyra_config.cc:55-58), converted in memory.
   std::string path = std::string(model_dir) + "/lyra_v1.lyrapack";
-  if (!pk.open(path, &err)) return fail(nullptr, LYRA_HIP_EMODEL, "%s", err.c_str());
+  if (!pk.open(path, &err)) {
+    std::vector<uint8_t> image;
+    std::string err2;
+    if (!pack_from_tflite_dir(model_dir, &image, &err2) || !pk.adopt(std::move(image), &err2))
+      return fail(nullptr, LYRA_HIP_EMODEL, "%s; %s", err.c_str(), err2.c_str());
+  }
   lyra_hip_ctx* c = new lyra_hip_ctx();
   c->device = device;
   c->max_streams = max_streams;

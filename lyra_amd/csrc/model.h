@@ -7,18 +7,14 @@
 #include <vector>
 
 #include "kernels.h"
+#include "pack_format.h"
 
 namespace lyra {
-
-struct PackEntry {
-  char name[56];
-  uint32_t dtype, ndim, shape[4];
-  uint64_t offset, nbytes;
-};
 
 class Pack {
  public:
   bool open(const std::string& path, std::string* err);
+  bool adopt(std::vector<uint8_t>&& image, std::string* err);   // an in-memory LYRAPK01 image (tflite_pack.h)
   const PackEntry* find(const std::string& name) const;
   template <class T>
   const T* data(const std::string& name) const {

@@ -28,6 +28,12 @@ bool Pack::open(const std::string& path, std::string* err) {
   return true;
 }
 
+bool Pack::adopt(std::vector<uint8_t>&& image, std::string* err) {
+  blob_ = std::move(image);
+  if (blob_.size() < 16 || memcmp(blob_.data(), "LYRAPK01", 8) != 0) { *err = "not a LYRAPK01 image"; return false; }
+  return true;
+}
+
 const PackEntry* Pack::find(const std::string& name) const {
   uint32_t n;
   memcpy(&n, blob_.data() + 8, 4);

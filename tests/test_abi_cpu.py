@@ -122,3 +122,60 @@ def test_bench_multi_rank_plumbing_gloo():
     r = json.loads(line)
     assert r["world"] == 2 and r["units"] == 2 * 4096 * 7 and abs(r["seconds"] - 0.75) < 1e-9
     assert r["per_rank"] == 4096 and r["first_id"] == 0
+
+
+REF_MODEL_DIR = "/root/reference/lyra/model_coeffs"
+
+
+def _pack_tool():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "lyra_amd", "csrc"), "../pack_tool"], stdout=subprocess.DEVNULL)
+    return os.path.join(ROOT, "lyra_amd", "pack_tool")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODEL_DIR), reason="reference model directory not present on this box")
+def test_cxx_tflite_reader_reproduces_the_shipped_container(tmp_path):
+    """lyra_hip_create() accepts the reference's model directory as is (three .tflite + lyra_config.binarypb,
+    lyra_components.cc:42-55): its C++ flatbuffer reader (csrc/tflite_pack.cc) must yield, byte for byte, the
+    container the repository ships (written by tools/pack_weights.py from the same directory)."""
+    out = tmp_path / "cxx.lyrapack"
+    subprocess.check_call([_pack_tool(), REF_MODEL_DIR, str(out)], stdout=subprocess.DEVNULL)
+    shipped = open(os.path.join(ROOT, "lyra_amd", "assets", "lyra_v1.lyrapack"), "rb").read()
+    assert open(out, "rb").read() == shipped
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODEL_DIR), reason="reference model directory not present on this box")
+def test_cxx_tflite_reader_rejects_bad_model_dirs(tmp_path):
+    import shutil
+    tool = _pack_tool()
+    names = ["soundstream_encoder.tflite", "quantizer.tflite", "lyragan.tflite", "lyra_config.binarypb"]
+
+    def fresh(name):
+        d = tmp_path / name
+        d.mkdir()
+        for n in names:
+            shutil.copy(os.path.join(REF_MODEL_DIR, n), d / n)
+        return d
+
+    def run(d):
+        return subprocess.run([tool, str(d), str(tmp_path / "o.bin")], capture_output=True, text=True)
+
+    assert run(fresh("ok")).returncode == 0
+    d = fresh("missing")
+    os.remove(d / "quantizer.tflite")
+    r = run(d)
+    assert r.returncode == 1 and "quantizer.tflite" in r.stderr
+    d = fresh("truncated")
+    blob = open(d / "lyragan.tflite", "rb").read()
+    open(d / "lyragan.tflite", "wb").write(blob[: len(blob) // 3])
+    assert run(d).returncode == 1
+    d = fresh("notflatbuffer")
+    open(d / "soundstream_encoder.tflite", "wb").write(b"\x00" * 4096)
+    assert run(d).returncode == 1
+    d = fresh("config")
+    open(d / "lyra_config.binarypb", "wb").write(b"\x10\x03")   # wrong field number
+    r = run(d)
+    assert r.returncode == 1 and "lyra_config.binarypb" in r.stderr
+    # a wrong version identifier converts (meta.version = 2) and is rejected later by the model builder
+    d = fresh("version")
+    open(d / "lyra_config.binarypb", "wb").write(b"\x08\x02")
+    assert run(d).returncode == 0
