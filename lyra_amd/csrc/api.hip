@@ -226,7 +226,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
     hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), st_,
                        M.d_enc0, d_pcm, d_ids, B, c->d_state, e0); }
   { ProfScope ps(c, K_ENC_S1, st_);
-    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(256), enc_s1_lds_bytes(), st_,
+    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes(), st_,
                        M.d_enc1, e0, d_ids, B, c->d_state, e1); }
   { ProfScope ps(c, K_ENC_S2, st_);
     hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), st_,
@@ -265,7 +265,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
     hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), st_,
                        M.d_dec0, d_feat, d_ids, B, c->d_state, d0, d_pkt, num_stages, M.cb); }
   { ProfScope ps(c, K_DEC_S1, st_);
-    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(256), dec_s1_lds_bytes(), st_,
+    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(dec_s1_threads()), dec_s1_lds_bytes(), st_,
                        M.d_dec1, d0, d_ids, B, c->d_state, d1); }
   { ProfScope ps(c, K_DEC_S2, st_);
     hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), st_,

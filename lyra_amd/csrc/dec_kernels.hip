@@ -343,13 +343,75 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
 namespace {
 constexpr int SD1 = 8;
 constexpr int CS1 = 136;
-constexpr int NTD1 = 256;
+#ifndef LYRA_S1_THREADS
+#define LYRA_S1_THREADS 512   // 8 waves per tile: 4 waves per SIMD with two tiles per CU (256 = the 4-wave layout)
+#endif
+constexpr int NTD1 = LYRA_S1_THREADS;
 }  // namespace
+
+// tconv k10/s5, polyphase: output block b (5 rows x 64 ch = N 320) = x[b-1] . W[taps 5..9] then x[b] . W[taps 0..4],
+// ONE fp32 chain per output (earlier input first).  Pass 1 runs every input row t against taps 5..9 (the
+// partial chains of block t+1), the C tiles are shifted down by one input row (8 of a tile's 16 rows:
+// a 32-lane rotation) and become pass 2's initial accumulators; block 4 = x[3] alone is the carried tail.
+// A wave computes NTW of the 20 N tiles starting at tile0.
+template <int NTW>
+__device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, const DecS1P& P, const TileCtx& cx,
+                                             int b0, float* __restrict__ out1, int tile0) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, q = lane >> 4;
+  f32x4 acc[2][NTW];
+  auto aoff = [&](int i, int c) {
+    int R = i * 16 + m, t = R / SD1, s = R & (SD1 - 1);
+    return (t * SD1 + s) * CS1 + c * 16 + q * 4;
+  };
+  const f32x4* wfrag = P.up.w + tile0 * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 5..9, 8-15 taps 0..4
+  gemm_f32<2, NTW, 8, 16>(XB, aoff, wfrag, acc);
+  f32x4 tail[NTW];
+  const bool lo = lane < 32;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = acc[0][j][e], bb = acc[1][j][e];
+      rot32_pair(a, bb);                       // a = [Y(t1), Y(t0)], bb = [Y(t3), Y(t2)]
+      acc[0][j][e] = lo ? 0.f : a;             // blocks 0 | 1  <-  0     | Y(t0)
+      acc[1][j][e] = lo ? a : bb;              // blocks 2 | 3  <-  Y(t1) | Y(t2)
+      tail[j][e] = bb;                         // lanes 0-31: block 4 = Y(t3)
+    }
+  gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int n = (tile0 + j) * 16 + (lane & 15);
+    const int jj = n >> 6, co = n & 63;
+    const float bias = as_global(P.up.b)[co], sub = as_global(P.up_sub)[co];
+    const int pc = at16(co);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int R = i * 16 + q * 4 + e, b = R / SD1, s = R & (SD1 - 1);
+        const int tau = 5 * b + jj;
+        float y = acc[i][j][e] + bias;
+        y = y + (tau < 5 ? SB[(tau * SD1 + s) * 72 + co] : 0.f);
+        if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + tau) * 64 + pc] = y;
+      }
+    if (lo) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = q * 4 + e;
+        float y = tail[j][e] + bias;
+        y = y + 0.f;
+        if (cx.valid(s)) reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y - sub;
+      }
+    }
+  }
+}
 
 size_t dec_s1_lds_bytes() { return (size_t)(4 * SD1 * CS1 + 4 * SD1 * CS1 + 5 * SD1 * 72) * 4 + 2 * SD1 * 4; }
 int dec_s1_streams_per_wg() { return SD1; }
+int dec_s1_threads() { return NTD1; }
 
-__global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
+__global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
                                                           const int32_t* __restrict__ ids, int B,
                                                           uint8_t* __restrict__ state, float* __restrict__ out1) {
   const DecS1P& P = *Pp;
@@ -359,8 +421,7 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
   float* SB = DB + 4 * SD1 * CS1;       // [5][S][72]: tail of the previous frame's transposed conv
   int* sids = reinterpret_cast<int*>(SB + 5 * SD1 * 72);
   int* sphase = sids + SD1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6;
   const int b0 = blockIdx.x * SD1;
   if (tid < SD1) {
     int id = ids[min(b0 + tid, B - 1)];
@@ -370,7 +431,7 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
   const auto warm = l2_warm<NTD1, 2>(P.warm);
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0};
-  const Hist128 H0 = hist128_prefetch<SD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
+  const auto H0 = hist128_prefetch<SD1, NTD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
     int b = min(b0 + s, B - 1);
@@ -390,57 +451,10 @@ __global__ __launch_bounds__(NTD1, 3) void dec_s1_kernel(const DecS1P* __restric
     *x = lrelu4(*x);
   }
   __syncthreads();
-  {  // tconv k10/s5, polyphase: output block b (5 rows x 64 ch = N 320) = x[b-1] . W[taps 5..9] then x[b] . W[taps 0..4],
-     // ONE fp32 chain per output (earlier input first).  Pass 1 runs every input row t against taps 5..9 (the
-     // partial chains of block t+1), the C tiles are shifted down by one input row (8 of a tile's 16 rows:
-     // a 32-lane rotation) and become pass 2's initial accumulators; block 4 = x[3] alone is the carried tail.
-    f32x4 acc[2][5];
-    auto aoff = [&](int i, int c) {
-      int R = i * 16 + m, t = R / SD1, s = R & (SD1 - 1);
-      return (t * SD1 + s) * CS1 + c * 16 + q * 4;
-    };
-    const f32x4* wfrag = P.up.w + (wave * 5) * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 5..9, 8-15 taps 0..4
-    gemm_f32<2, 5, 8, 16>(XB, aoff, wfrag, acc);
-    f32x4 tail[5];
-    const bool lo = lane < 32;
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = acc[0][j][e], bb = acc[1][j][e];
-        rot32_pair(a, bb);                       // a = [Y(t1), Y(t0)], bb = [Y(t3), Y(t2)]
-        acc[0][j][e] = lo ? 0.f : a;             // blocks 0 | 1  <-  0     | Y(t0)
-        acc[1][j][e] = lo ? a : bb;              // blocks 2 | 3  <-  Y(t1) | Y(t2)
-        tail[j][e] = bb;                         // lanes 0-31: block 4 = Y(t3)
-      }
-    gemm_f32<2, 5, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int n = (wave * 5 + j) * 16 + (lane & 15);
-      const int jj = n >> 6, co = n & 63;
-      const float bias = as_global(P.up.b)[co], sub = as_global(P.up_sub)[co];
-      const int pc = at16(co);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int R = i * 16 + q * 4 + e, b = R / SD1, s = R & (SD1 - 1);
-          const int tau = 5 * b + jj;
-          float y = acc[i][j][e] + bias;
-          y = y + (tau < 5 ? SB[(tau * SD1 + s) * 72 + co] : 0.f);
-          if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + tau) * 64 + pc] = y;
-        }
-      if (lo) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int s = q * 4 + e;
-          float y = tail[j][e] + bias;
-          y = y + 0.f;
-          if (cx.valid(s)) reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y - sub;
-        }
-      }
-    }
-  }
+  // transposed conv k10/s5: 20 N tiles over the waves (5 each with 4 waves; 3,3,3,3,2,2,2,2 with 8)
+  if (NTD1 == 256) dec_s1_tconv<5>(XB, SB, P, cx, b0, out1, wave * 5);
+  else if (wave < 4) dec_s1_tconv<3>(XB, SB, P, cx, b0, out1, wave * 3);
+  else dec_s1_tconv<2>(XB, SB, P, cx, b0, out1, 12 + (wave - 4) * 2);
   l2_warm_sink(warm, state, B);
 }
 

@@ -178,14 +178,18 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
 namespace {
 constexpr int S1 = 8;
 constexpr int CS1 = 136;   // 128 + 8
-constexpr int NT1 = 256;
+#ifndef LYRA_S1_THREADS
+#define LYRA_S1_THREADS 512   // 8 waves per tile: 4 waves per SIMD with two tiles per CU (256 = the 4-wave layout)
+#endif
+constexpr int NT1 = LYRA_S1_THREADS;
 constexpr int NW1 = NT1 / 64;
 }  // namespace
 
 size_t enc_s1_lds_bytes() { return (size_t)(6 * S1 * CS1 + 4 * S1 * CS1) * 4 + 2 * S1 * 4; }
 int enc_s1_streams_per_wg() { return S1; }
+int enc_s1_threads() { return NT1; }
 
-__global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict__ Pp, const float* __restrict__ in0,
+__global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const EncS1P* __restrict__ Pp, const float* __restrict__ in0,
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ out1) {
   const EncS1P& P = *Pp;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(NT1, 3) void enc_s1_kernel(const EncS1P* __restrict
   auto valid = [&](int s) -> bool { return b0 + s < B; };
 
   TileCtx cx{state, sids, sphase, B - b0};
-  const Hist128 H0 = hist128_prefetch<S1>(cx, 1, st::E_R1_0);   // first block's history: same round trip as the input
+  const auto H0 = hist128_prefetch<S1, NT1>(cx, 1, st::E_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
     int b = min(b0 + s, B - 1);

@@ -26,7 +26,7 @@ __global__ void enc_s1_kernel(const EncS1P* P, const float* in0, const int32_t* 
 __global__ void enc_s2_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, float* feats,
                               float* codes_dbg);
 size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg();
-size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg();
+size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg(); int enc_s1_threads();
 size_t enc_s2_lds_bytes(); int enc_s2_streams_per_wg();
 
 // ---- decoder ---------------------------------------------------------------------------------
@@ -55,7 +55,7 @@ __global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t
 __global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
 __global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm);
 size_t dec_s0_lds_bytes(); int dec_s0_streams_per_wg();
-size_t dec_s1_lds_bytes(); int dec_s1_streams_per_wg();
+size_t dec_s1_lds_bytes(); int dec_s1_streams_per_wg(); int dec_s1_threads();
 size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg();
 
 // ---- RVQ / packets / log-mel / state ---------------------------------------------------------------

@@ -147,33 +147,35 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
   }
 }
 
-// ---- 128 channels x 4 rows; S = 8 streams, 256 threads ------------------------------------------------------------
+// ---- 128 channels x 4 rows; S = 8 streams, NT = 256 or 512 threads ----------------------------------------------
 // X: [4][S][136] floats, D: same.  Dilation 1 keeps the last two rows; dilations 3 and 9 use ring histories of
 // 6 / 18 rows (T = 4 new rows per step at slot (phase*4 + t) mod R).
-// GEMM [4*S rows] x 128 x 128: 2 M tiles per wave, 8 N tiles spread over the 4 waves.
-// Thread (s = tid >> 5, p4 = tid & 31) owns channel quad p4 of stream s for all four rows: LeakyReLU, the
-// depthwise conv and the history update are thread-local, every history tap is a 16-byte global load, and the
-// loads of block r+1 are issued before block r's second GEMM so their HBM latency is never exposed.
-struct Hist128 { f32x4 h[4][2]; };   // [row t][tap 0 (t-2d), tap 1 (t-d)], valid where the tap predates the frame
+// GEMM [4*S rows] x 128 x 128: 2 M tiles per wave, 8 N tiles spread over the NT/64 waves.
+// Thread (s, p4, half) owns channel quad p4 of stream s for RPT = 1024/NT rows (all four with 256 threads, rows
+// {0,1} / {2,3} with 512): LeakyReLU, the depthwise conv and the history update are thread-local, every history tap
+// is a 16-byte global load, and the loads of block r+1 are issued behind block r's LDS-only phases.
+template <int RPT>
+struct Hist128 { f32x4 h[RPT][2]; };   // [own row][tap 0 (t-2d), tap 1 (t-d)], valid where the tap predates the frame
 
-template <int S>
-__device__ __forceinline__ Hist128 hist128_prefetch(const TileCtx& cx, int d, int off) {
-  const int tid = threadIdx.x, p4 = tid & 31, s = tid >> 5;
+template <int S, int NT>
+__device__ __forceinline__ Hist128<1024 / NT> hist128_prefetch(const TileCtx& cx, int d, int off) {
+  constexpr int RPT = 1024 / NT;
+  const int tid = threadIdx.x, p4 = tid & 31, s = (tid >> 5) & (S - 1), row0 = (tid >> 8) * RPT;
   const int R2 = 2 * d;
   const bool ring = R2 > 4;
   const int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
   const float LYRA_GLOBAL* hp = as_global(reinterpret_cast<const float*>(cx.sbase(s) + off)) + p4 * 4;
-  Hist128 H;
+  Hist128<RPT> H;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int k = 0; k < RPT; ++k)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int tau = t - (2 - j) * d;
-      H.h[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int tau = row0 + k - (2 - j) * d;
+      H.h[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (tau < 0) {
         int row = R2 + tau;
         if (ring) { row = base + tau + R2; row = row >= R2 ? row - R2 : row; }
-        H.h[t][j] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hp + row * 128);
+        H.h[k][j] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hp + row * 128);
       }
     }
   return H;
@@ -183,54 +185,53 @@ __device__ __forceinline__ Hist128 hist128_prefetch(const TileCtx& cx, int d, in
 template <int S, int NT>
 __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& cx, const DwF* dws,
                                              const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2,
-                                             Hist128 H) {
-  static_assert(S == 8 && NT == 256, "thread <-> (stream, channel quad) mapping");
-  constexpr int CS = 136, NTW = 2, MT = 2;
+                                             Hist128<1024 / NT> H) {
+  static_assert(S == 8 && (NT == 256 || NT == 512), "thread <-> (stream, channel quad, row half) mapping");
+  constexpr int CS = 136, NTW = 8 / (NT / 64), MT = 2, RPT = 1024 / NT;
 #pragma unroll 1
   for (int r = 0; r < 3; ++r) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // keep the index math inside the loop (see resblocks64r)
     const int lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
-    const int p4 = tid & 31, s = tid >> 5;
+    const int p4 = tid & 31, s = (tid >> 5) & (S - 1), row0 = (tid >> 8) * RPT;
     const int d = r == 0 ? 1 : (r == 1 ? 3 : 9);
     const int R2 = 2 * d;
     const int off = r == 0 ? off0 : (r == 1 ? off1 : off2);
     const bool ring = R2 > 4;
     LYRA_TSTAMP(40 + r * 8 + 0);
-    {  // a = lrelu(X); depthwise [a(t-2d), a(t-d), a(t)]; history update -- all on this thread's own quad
+    {  // a = lrelu(X); depthwise [a(t-2d), a(t-d), a(t)]; history update -- all on this thread's own quad.
+       // A history slot read here (prefetched) may be rewritten by the thread owning the other row half; its
+       // prefetch retired before the previous block's second GEMM could fetch weights (vmcnt is in order), i.e.
+       // before the barrier that precedes this phase.
       const float LYRA_GLOBAL* dww = as_global(dws[r].w) + p4 * 4;
       const f32x4 w0 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww);
       const f32x4 w1 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 128);
       const f32x4 w2 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 256);
       const f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dws[r].b) + p4 * 4);
-      f32x4 a[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = lrelu4(*reinterpret_cast<const f32x4*>(&X[(t * S + s) * CS + p4 * 4]));
       float* hp = reinterpret_cast<float*>(cx.sbase(s) + off) + p4 * 4;
       const int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
       const bool valid = cx.valid(s);
+      const float* xq = &X[s * CS + p4 * 4];   // this thread's quad of row t at xq[t * S * CS]
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        // taps that fall inside the frame are earlier rows of a[] (only possible for d <= 3)
-        f32x4 v0 = H.h[t][0], v1 = H.h[t][1];
-        if (d == 1) {
-          if (t >= 2) v0 = a[t >= 2 ? t - 2 : 0];
-          if (t >= 1) v1 = a[t >= 1 ? t - 1 : 0];
-        } else if (d == 3) {
-          if (t == 3) v1 = a[0];
-        }
+      for (int k = 0; k < RPT; ++k) {
+        const int t = row0 + k, t0 = t - 2 * d, t1 = t - d;
+        const f32x4 a = lrelu4(*reinterpret_cast<const f32x4*>(xq + t * S * CS));
+        // taps that fall inside the frame are earlier rows of lrelu(X) (only possible for d <= 3)
+        f32x4 v0 = H.h[k][0], v1 = H.h[k][1];
+        if (t0 >= 0) v0 = lrelu4(*reinterpret_cast<const f32x4*>(xq + t0 * S * CS));
+        if (t1 >= 0) v1 = lrelu4(*reinterpret_cast<const f32x4*>(xq + t1 * S * CS));
         f32x4 acc = fma4(v0, w0, (f32x4){0.f, 0.f, 0.f, 0.f});
         acc = fma4(v1, w1, acc);
-        acc = fma4(a[t], w2, acc);
+        acc = fma4(a, w2, acc);
         *reinterpret_cast<f32x4*>(&D[(t * S + s) * CS + p4 * 4]) = acc + bb;
         if (valid) {
           if (ring) {
             int row = base + t;
             row = row >= R2 ? row - R2 : row;
-            *reinterpret_cast<f32x4*>(hp + row * 128) = a[t];
+            *reinterpret_cast<f32x4*>(hp + row * 128) = a;
           } else if (t >= 2) {
-            *reinterpret_cast<f32x4*>(hp + (t - 2) * 128) = a[t];
+            *reinterpret_cast<f32x4*>(hp + (t - 2) * 128) = a;
           }
         }
       }
@@ -248,7 +249,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
       // The next block's history rows.  vmcnt retires in order, so these loads would stall the first weight
       // fetch of a GEMM issued right after them; here they have the two barriers and the LDS-only P write
       // (no younger global load) to land in.
-      if (r < 2) H = hist128_prefetch<S>(cx, r == 0 ? 3 : 9, r == 0 ? off1 : off2);
+      if (r < 2) H = hist128_prefetch<S, NT>(cx, r == 0 ? 3 : 9, r == 0 ? off1 : off2);
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
