@@ -4,7 +4,7 @@
 //
 //   dec_s0  8 streams/WG  features -> conv k3 g4 (fp32) -> int8: 4x tconv k4/s2, 3 resblocks @256ch x 2 rows,
 //                         2x tconv k4/s2 -> [4][128] fp32
-//   dec_s1  8 streams/WG  3 fp32 resblocks @128ch x 4 rows -> tconv k10/s5 -> [20][64]
+//   dec_s1  8 streams/WG  3 fp32 resblocks @128ch x 4 rows -> tconv k10/s5 (two chained GEMM passes) -> [20][64]
 //   dec_s2  4 streams/WG  3 fp32 resblocks @64ch x 20 rows -> tconv k64/s16 -> 320 samples -> int16 PCM
 //
 // Transposed convs run in polyphase form: output block b (s rows) = [x[b-taps+1] .. x[b]] (K = taps*Cin,
@@ -25,8 +25,9 @@ extern "C" int lyra_hip_debug_wgtrace_d0(long long* out) {
 namespace lyra {
 
 // =============================================================================================
-// stage 0 -- like encoder stage 2 a long chain of small dependent phases: small tile (S = 8 streams,
-// ~47 KB LDS), three workgroups per CU.  Rows of [2][S] matrices are t*S + s (one 16-row MFMA tile).
+// stage 0 -- like encoder stage 2 a long chain of small dependent phases: small tile (S = 8 streams, 512 threads,
+// ~68 KB LDS), two workgroups per CU.  Rows of [2][S] matrices are t*S + s (one 16-row MFMA tile); GEMMs whose
+// rows are just the 8 streams fold two N tiles into the idle upper lanes before their epilogue (fold_rows8).
 // =============================================================================================
 namespace {
 constexpr int SD0 = 8;

@@ -6,9 +6,9 @@
 //
 // Every fp32 dot product runs on v_mfma_f32_16x16x4_f32 in ascending-k order (== the oracle's fmaf chain);
 // everything between two GEMMs (LeakyReLU, depthwise dilated conv, residual add, history update) is fused
-// around them in LDS/registers.  Tiles are small (256 threads, ~50 KB LDS) so three workgroups share a CU:
-// the MFMA phases of one overlap the VALU/LDS/HBM phases of the others.  Per stream and step the only HBM
-// traffic is PCM in, history read/write and one small inter-stage activation.
+// around them in LDS/registers.  Tiles are small (stage 0: 256 threads, 29 KB LDS, four per CU; stage 1: 512
+// threads, 35 KB, two per CU) so that the MFMA phases of one tile overlap the VALU/LDS/HBM phases of the others.
+// Per stream and step the only HBM traffic is PCM in, history read/write and one small inter-stage activation.
 #include "resblocks.h"
 
 #ifdef LYRA_TIMING

@@ -2,10 +2,11 @@
 // pointwise and an int8 tail, two int8 resblocks, int8 conv k4/s2 g4 -> [1][512], int8 bottleneck conv k3 g4
 // -> 64 int8 codes -> features (graph ops 94-151 of soundstream_encoder.tflite).
 //
-// The stage is a long chain of small dependent phases (25 barriers), so it is latency- not throughput-bound:
-// the tile is kept small (S = 8 streams, ~53 KB LDS) so that three workgroups share a CU and cover each
-// other's global-memory latencies.  Rows are (t, s) -> t*S + s; with S = 8 the two time steps fill exactly
-// one 16-row MFMA tile.
+// The stage is a long chain of small dependent phases, latency- and VALU-bound rather than MFMA- or HBM-bound:
+// the tile is kept small (S = 8 streams, 512 threads, ~54 KB LDS) so that two workgroups share a CU; int8
+// LeakyReLU / ADD rescalings are LDS table lookups, the int8 residual blocks keep LeakyReLU -> depthwise ->
+// history thread-local, and everything a block loads from global memory is requested one phase early
+// (resblock_q.h).  Rows are (t, s) -> t*S + s; with S = 8 the two time steps fill exactly one 16-row MFMA tile.
 #include "resblock_q.h"
 
 #ifdef LYRA_TIMING
