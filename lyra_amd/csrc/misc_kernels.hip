@@ -9,10 +9,12 @@ namespace lyra {
 // (lyra/packet.h:91-122).  16 lanes = the 16 codewords of a stage; each lane runs the 64-term
 // squared-distance sum in the oracle's order (separate multiply and add, d ascending), then a
 // 16-lane shuffle argmin with lowest-index tie break (ARG_MIN = first minimum).  The residual lives
-// in registers, replicated across the 16 lanes, and is updated with the graph's three fp32 ops
-// r - (r + (q - r)).  4 frames per wavefront, 16 per workgroup.  The 4 KB codebook of the current
-// stage sits in LDS (rows padded to 68 floats: conflict-free ds_read_b128 across the 16 code lanes),
-// double-buffered: the next stage's rows are fetched from L2 while this stage computes.
+// in LDS, shared by the 16 lanes of its frame (broadcast reads), and is updated once per dimension with the
+// graph's three fp32 ops r - (r + (q - r)).  4 frames per wavefront, 16 per workgroup.  The 4 KB codebook of
+// the current stage sits in LDS (rows padded to 68 floats: conflict-free ds_read_b128 across the 16 code lanes),
+// double-buffered: the next stages' rows are fetched from L2 while this window computes.  63 VGPRs: the kernel
+// is a 46-step dependent chain at one wavefront per SIMD, so what matters is how little it takes away from the
+// decode-side kernels running next to it.
 // =============================================================================================
 __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ cb,
                                                           const float* __restrict__ feats, int B, int num_stages,
@@ -32,13 +34,13 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
 #pragma unroll
   for (int u = 0; u < W; ++u)
     nxt[u] = *reinterpret_cast<const f32x4*>(&cb[((size_t)min(u, 45) * 16 + ldrow) * 64 + ldc4 * 4]);
-  f32x2 r[32];  // the residual, replicated in the 16 code lanes of a frame (packed pairs -> v_pk_* math)
-#pragma unroll
-  for (int d4 = 0; d4 < 16; ++d4) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + d4 * 4]);
-    r[d4 * 2] = (f32x2){v[0], v[1]};
-    r[d4 * 2 + 1] = (f32x2){v[2], v[3]};
-  }
+  // The residual of each frame lives in LDS (rs), not replicated in the registers of its 16 code lanes: the
+  // distance pass reads it with broadcast ds_read_b128 next to the code rows, and the update r - (r + (q - r))
+  // is done once per dimension (lane j owns dims 4j..4j+3) instead of sixteen times.  All 16 lanes of a frame sit
+  // in one wavefront and LDS operations of a wavefront execute in order, so the write-back needs no barrier.
+  __shared__ __attribute__((aligned(16))) float rs[16][64];
+  float* rme = rs[tid >> 4];
+  *reinterpret_cast<f32x4*>(&rme[j * 4]) = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + j * 4]);
   const int nbytes = (num_stages + 1) >> 1;
   int cur = 0;
 #pragma unroll 1
@@ -56,12 +58,14 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
                         //  it was last read two windows ago, and every thread passed the barrier in between)
     }
     const float* c = cbs[win & 1] + u * 16 * 68;
+    asm volatile("" ::: "memory");   // rs is rewritten by the other lanes of the frame: never carry it in registers
     float sum = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < 16; ++d4) {
       f32x4 cv = *reinterpret_cast<const f32x4*>(&c[j * 68 + d4 * 4]);
-      f32x2 df0 = r[d4 * 2] - (f32x2){cv[0], cv[1]};
-      f32x2 df1 = r[d4 * 2 + 1] - (f32x2){cv[2], cv[3]};
+      f32x4 rv = *reinterpret_cast<const f32x4*>(&rme[d4 * 4]);
+      f32x2 df0 = (f32x2){rv[0], rv[1]} - (f32x2){cv[0], cv[1]};
+      f32x2 df1 = (f32x2){rv[2], rv[3]} - (f32x2){cv[2], cv[3]};
       f32x2 sq0 = df0 * df0, sq1 = df1 * df1;
       sum = sum + sq0[0];
       sum = sum + sq0[1];
@@ -81,14 +85,12 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
   }
     LYRA_ROR_STEP(8) LYRA_ROR_STEP(4) LYRA_ROR_STEP(2) LYRA_ROR_STEP(1)
 #undef LYRA_ROR_STEP
-#pragma unroll
-    for (int d4 = 0; d4 < 16; ++d4) {
-      f32x4 qv = *reinterpret_cast<const f32x4*>(&c[best * 68 + d4 * 4]);
-      f32x2 q0 = {qv[0], qv[1]}, q1 = {qv[2], qv[3]};
-      f32x2 t10 = q0 - r[d4 * 2], t11 = q1 - r[d4 * 2 + 1];       // the graph's three separate fp32 ops
-      f32x2 t20 = r[d4 * 2] + t10, t21 = r[d4 * 2 + 1] + t11;
-      r[d4 * 2] = r[d4 * 2] - t20;
-      r[d4 * 2 + 1] = r[d4 * 2 + 1] - t21;
+    {  // r <- r - (r + (q - r)), the graph's three separate fp32 ops, on this lane's four dimensions
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(&c[best * 68 + j * 4]);
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(&rme[j * 4]);
+      const f32x4 t1 = qv - rv;
+      const f32x4 t2 = rv + t1;
+      *reinterpret_cast<f32x4*>(&rme[j * 4]) = rv - t2;
     }
     if (j == 0 && frame < B) {
       if (indices) indices[(size_t)frame * 46 + k] = best;
