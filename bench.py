@@ -1,26 +1,45 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X-native Lyra encode+decode hot path.
+"""bench.py -- throughput of the MI355X-native Lyra encode/decode hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--with-logmel]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric, configs[2]): per GPU 4096 independent 16 kHz streams, each advancing one
-20 ms frame (320 samples) per step, encode at 9200 bps (184 bits = 46 RVQ stages) + decode.  A "step" =
-lyra_hip_encode_dev (PCM -> packets) followed by lyra_hip_decode_dev (packets -> PCM) over the whole batch,
-inputs already resident in HBM, state carried from step to step (frames of a stream are NOT independent).
-Streams are sharded across GPUs with no data-path collective (weak scaling: 4096 streams per GPU); the
-only collectives are the timing barrier and the max-over-ranks reduction.
+Workloads (BASELINE.json `configs`; a "step" advances every stream by one 20 ms frame, state carried
+from step to step -- frames of a stream are NOT independent):
 
-One JSON line on rank 0.  `roofline` is for the kernel with the largest share of the step, its duration
-measured live with HIP events recorded on the library's own stream around every launch of the timed region
-(lyra_hip_profile_*); `cpu_baseline` times the CPU oracle (a port, not the TFLite binary) on this box's host
-cores on a bounded sample of the same kind of input.
+  --config 3 (default; the configuration BASELINE.json's metric is quoted on)
+        4096 streams per GPU, 9200 bps (184 bits = 46 RVQ stages), step = lyra_hip_encode_dev (PCM -> packets)
+        + lyra_hip_decode_dev (packets -> PCM).  Weak scaling: 4096 streams per GPU.
+  --config 2   1024 streams per GPU, 3200 bps (64 bits = 16 stages), encode + decode.
+  --config 4   decode only, 8192 streams per GPU: lossy features / packets are produced ONCE by the encoder + RVQ on
+        the same synthetic PCM (lyra_benchmark_lib.cc:121-160); the timed step is lyra_hip_generate_dev (features ->
+        PCM, the pure lyra_gan_model path, primary = `value`) and, in a second timed region, lyra_hip_decode_dev
+        (packets -> PCM, adds the RVQ decode; reported as `secondary`).
+  --config 5   32768 streams IN TOTAL at 6000 bps (120 bits), encode + decode, split over the GPUs of the job
+        (strong scaling: N = 1 runs all 32768 streams on one GPU).  Same as --total-streams 32768 --bits 120.
+  --streams / --bits / --total-streams override the above.
+
+Streams are sharded across GPUs with no data-path collective; the only collectives are the timing barrier and the
+max / sum reductions of the result (plus, with --bcast-weights, one RCCL broadcast of the packed weights at init).
+Launched WITHOUT torch.distributed but with --gpus N > 1, one process drives N contexts from N threads.
+
+One JSON line on rank 0:
+  * `value` = whole-job frames/s with inputs resident in HBM;
+  * `roofline` = the WHOLE STEP against its binding bound (fp32 MFMA for encode+decode: 5.43 MFLOP of fp32 MFMA work
+    per stream-frame = 34.5 ns at 157.3 TFLOP/s, vs 13.4 ns of HBM time for the bytes the kernels move);
+  * `kernels` = per-kernel durations measured live with HIP events on the library's own streams in a SERIALISED pass
+    (lyra_hip_set_serial: the two library streams strictly in call order, so no cross-stream contention), each with
+    its own binding bound computed from the bytes it actually moves (lyra_amd/csrc/state_layout.h);
+  * `dominant_kernel` = the kernel with the largest serialised duration, bracketed by HIP events inside the timed
+    region (i.e. under the two-stream overlap the step really runs with);
+  * `cpu_baseline` = the CPU oracle (a port, not the TFLite binary) on this box's host cores, bounded sample.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -28,38 +47,94 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STREAMS_PER_GPU = 4096
-NUM_BITS = 184
 SEED = 0x4C797261  # "Lyra"
-
-# Algorithmic work per stream-frame of each kernel (DESIGN.md "Kernels"): fp32 MACs, int8 MACs, HBM bytes
-# (inputs + outputs + per-stream state read and written, at the reference's fp32 state representation).
-KERNEL_WORK = {
-    "enc_s0_kernel": dict(f32=912640, i8=0, bytes=640 + 2 * (48 + 26 * 64 + 5 * 64) * 4 + 4 * 128 * 4),
-    "enc_s1_kernel": dict(f32=430592, i8=0, bytes=4 * 128 * 4 + 2 * (26 * 128 + 2 * 128) * 4 + 2 * 256 * 4),
-    "enc_s2_kernel": dict(f32=132608, i8=519168, bytes=2 * 256 * 4 + 2 * (26 * 256 + 2 * 256 + 2 * 512) * 4 + 256),
-    "rvq_encode_kernel": dict(f32=0, i8=0, bytes=256 + 23, flops=3 * 16 * 64 * 46 + 3 * 64 * 46),
-    "rvq_decode_kernel": dict(f32=0, i8=0, bytes=23 + 256, flops=64 * 46),
-    "dec_s0_kernel": dict(f32=24576, i8=758272, bytes=256 + 2 * (2 * 64 + 8 * 64 + 26 * 256 + 4 * 64) * 4 + 4 * 128 * 4),
-    "dec_s1_kernel": dict(f32=627200, i8=0, bytes=4 * 128 * 4 + 2 * (26 * 128 + 5 * 64) * 4 + 20 * 64 * 4),
-    "dec_s2_kernel": dict(f32=584960, i8=0, bytes=20 * 64 * 4 + 2 * (26 * 64 + 48) * 4 + 640),
+CONFIGS = {
+    2: dict(streams=1024, bits=64, mode="encdec", scaling="weak"),
+    3: dict(streams=4096, bits=184, mode="encdec", scaling="weak"),
+    4: dict(streams=8192, bits=184, mode="decode", scaling="weak"),
+    5: dict(total_streams=32768, bits=120, mode="encdec", scaling="strong"),
 }
+
+# Work per stream-frame of each kernel (DESIGN.md "Kernels"):
+#   f32 / i8 : MACs on the fp32 / int8 MFMA path;  flops: fp32 VALU FLOP (RVQ, log-mel);
+#   moved    : HBM bytes the kernel itself reads + writes per stream-frame: inputs + outputs + per-stream state at
+#              the representation of lyra_amd/csrc/state_layout.h (int8 histories as int8, dilated-conv histories
+#              as rings that are read where tapped and written T rows per step);
+#   ref_bytes: the same at the reference's fp32 TFLite-variable representation (215 KB/frame whole path).
+KERNEL_WORK = {
+    "enc_s0_kernel": dict(f32=912640, i8=0, moved=640 + 2 * (48 + 26 * 64 + 5 * 64) * 4 + 4 * 128 * 4,
+                          ref_bytes=640 + 2 * (48 + 26 * 64 + 5 * 64) * 4 + 4 * 128 * 4),
+    "enc_s1_kernel": dict(f32=430592, i8=0,
+                          moved=2048 + (1024 + 1024) + (3072 + 2048) + (4096 + 2048) + (1024 + 1024) + 2048,
+                          ref_bytes=4 * 128 * 4 + 2 * (26 * 128 + 2 * 128) * 4 + 2 * 256 * 4),
+    "enc_s2_kernel": dict(f32=132608, i8=519168,
+                          moved=2048 + (2048 + 2048) + (1024 + 512) + (1024 + 512) + (512 + 512) + (1024 + 512) + 512 + 8,
+                          ref_bytes=2 * 256 * 4 + 2 * (26 * 256 + 2 * 256 + 2 * 512) * 4 + 256),
+    "rvq_encode_kernel": dict(f32=0, i8=0, moved=256 + 23, ref_bytes=256 + 23, flops=3 * 16 * 64 * 46 + 3 * 64 * 46),
+    "rvq_decode_kernel": dict(f32=0, i8=0, moved=23 + 256, ref_bytes=23 + 256, flops=64 * 46),
+    "dec_s0_kernel": dict(f32=24576, i8=758272,
+                          moved=23 + (512 + 256) + (2048 + 2048) + (512 + 512) + (1024 + 512) + (1024 + 512)
+                          + (1024 + 1024) + 2048 + 4,
+                          ref_bytes=256 + 2 * (2 * 64 + 8 * 64 + 26 * 256 + 4 * 64) * 4 + 4 * 128 * 4),
+    "dec_s1_kernel": dict(f32=627200, i8=0,
+                          moved=2048 + (1024 + 1024) + (3072 + 2048) + (4096 + 2048) + (1280 + 1280) + 5120,
+                          ref_bytes=4 * 128 * 4 + 2 * (26 * 128 + 5 * 64) * 4 + 20 * 64 * 4),
+    "dec_s2_kernel": dict(f32=584960, i8=0, moved=5120 + 2 * (26 * 64) * 4 + 2 * 48 * 4 + 640 + 8,
+                          ref_bytes=20 * 64 * 4 + 2 * (26 * 64 + 48) * 4 + 640),
+    "logmel_kernel": dict(f32=0, i8=0, moved=640 + 640 + 640 + 640, ref_bytes=640 + 2 * 640 + 640,
+                          flops64=10 * 512 * 10 + 513 * 5 + 1024 * 3),   # fp64: radix-2 FFT-1024 + |X| + mel
+}
+ENCODE_KERNELS = ("enc_s0_kernel", "enc_s1_kernel", "enc_s2_kernel", "rvq_encode_kernel")
+DECODE_KERNELS = ("dec_s0_kernel", "dec_s1_kernel", "dec_s2_kernel")
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_I8_MFMA_TOPS = 3944.0      # same guide: v_mfma_i32_16x16x64_i8, dense
+PEAK_F32_VALU_TFLOPS = 157.3    # same guide: FP32 vector
+PEAK_F64_VALU_TFLOPS = 78.6     # CDNA4 FP64 vector (half the fp32 rate)
 PEAK_HBM_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
-    ap.add_argument("--bits", type=int, default=NUM_BITS)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (weak scaling)")
+    ap.add_argument("--total-streams", type=int, default=None, help="streams in the whole job (strong scaling)")
+    ap.add_argument("--bits", type=int, default=None)
+    ap.add_argument("--with-logmel", action="store_true",
+                    help="run the log-mel front end on every decoded hop (lyra_decoder.cc:304-311) inside the step")
+    ap.add_argument("--bcast-weights", action="store_true",
+                    help="rank 0 reads the weight container, RCCL-broadcasts it, every rank builds from the image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise the multi-rank plumbing (gloo) without touching a GPU")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def resolve_workload(args, world):
+    """-> dict(B per rank, total, bits, mode, scaling) from --config and the overrides."""
+    cfg = dict(CONFIGS[args.config])
+    if args.bits is not None:
+        cfg["bits"] = args.bits
+    if args.total_streams is not None:
+        cfg.pop("streams", None)
+        cfg["total_streams"] = args.total_streams
+        cfg["scaling"] = "strong"
+    elif args.streams is not None:
+        cfg.pop("total_streams", None)
+        cfg["streams"] = args.streams
+        cfg["scaling"] = "weak"
+    if "total_streams" in cfg:
+        total = cfg["total_streams"]
+        if total % world:
+            raise SystemExit(f"--total-streams {total} is not divisible by the {world} GPUs of the job")
+        per = total // world
+    else:
+        per = cfg["streams"]
+        total = per * world
+    return dict(B=per, total=total, bits=cfg["bits"], mode=cfg["mode"], scaling=cfg["scaling"], config=args.config)
 
 
 def dist_env():
@@ -88,23 +163,6 @@ def shard_ids(total_streams, rank, world):
     return rank * per, per
 
 
-def selftest_dist(args):
-    import torch
-    import torch.distributed as dist
-    rank, world, _ = dist_env()
-    if world > 1:
-        dist.init_process_group("gloo", init_method="env://")
-        dist.barrier()
-    lo, per = shard_ids(args.streams * world, rank, world)
-    secs, units = reduce_job(0.5 + 0.25 * rank, per * args.steps, world, torch.device("cpu"))
-    if rank == 0:
-        print(json.dumps({"selftest": "dist", "world": world, "seconds": secs, "units": units,
-                          "first_id": lo, "per_rank": per}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -117,7 +175,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(bits):
+def cpu_baseline(bits, mode):
     """Oracle (CPU port of the same arithmetic) on the host cores, bounded to ~12 s."""
     from oracle import lyra_oracle
     lyra_oracle.build()
@@ -134,151 +192,402 @@ def cpu_baseline(bits):
     steps = int(max(16, min(4000, 12.0 * rate / streams)))
     rate, r = run(steps)
     split = r["stage_seconds"] / (streams * steps) * 1e3
-    return {"value": round(rate, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{streams} streams x {steps} frames, uniform full-scale int16 PCM, {bits} bits, "
-                      f"oracle/lyra_oracle.c one stream per thread",
-            "ms_per_frame_per_core": {"extract": round(float(split[0]), 4), "quantize": round(float(split[1]), 4),
-                                      "dequantize": round(float(split[2]), 4), "generate": round(float(split[3]), 4)}}
+    out = {"value": round(rate, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{streams} streams x {steps} frames, uniform full-scale int16 PCM, {bits} bits, encode+decode, "
+                     f"oracle/lyra_oracle.c one stream per thread",
+           "ms_per_frame_per_core": {"extract": round(float(split[0]), 4), "quantize": round(float(split[1]), 4),
+                                     "dequantize": round(float(split[2]), 4), "generate": round(float(split[3]), 4)}}
+    if mode == "decode":   # the decode-only share of the same run (dequantize + generate stages)
+        dec_ms = float(split[2] + split[3])
+        out["decode_only_value"] = round(cores / (dec_ms * 1e-3), 1) if dec_ms > 0 else None
+    return out
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------------------
+# per-kernel and whole-step roofline arithmetic (pure functions: covered by the CPU tests)
+# ------------------------------------------------------------------------------------------------------------
+def kernel_bound(name):
+    """(bound name, ns per stream-frame at that peak, dict of all candidate times in ns)."""
+    w = KERNEL_WORK[name]
+    t = {"mfma": (2 * w["f32"] / (PEAK_F32_MFMA_TFLOPS * 1e12) + 2 * w["i8"] / (PEAK_I8_MFMA_TOPS * 1e12)) * 1e9,
+         "hbm": w["moved"] / (PEAK_HBM_GBS * 1e9) * 1e9,
+         "valu": (w.get("flops", 0) / (PEAK_F32_VALU_TFLOPS * 1e12) + w.get("flops64", 0) / (PEAK_F64_VALU_TFLOPS * 1e12)) * 1e9}
+    b = max(t, key=lambda k: t[k])
+    return b, t[b], t
+
+
+def kernel_row(name, total_ms, launches, B):
+    w = KERNEL_WORK[name]
+    dur = total_ms / launches * 1e-3
+    bound, t_ns, _ = kernel_bound(name)
+    return {"avg_us": round(dur * 1e6, 2), "launches": launches,
+            "f32_tflops": round(2 * w["f32"] * B / dur / 1e12, 3),
+            "i8_tops": round(2 * w["i8"] * B / dur / 1e12, 3),
+            "moved_gbs": round(w["moved"] * B / dur / 1e9, 1),
+            "moved_bytes_per_launch": w["moved"] * B,
+            "bound": bound, "floor_us": round(t_ns * B * 1e-3, 2),
+            "frac": round(t_ns * 1e-9 * B / dur, 4)}
+
+
+def step_work(mode, with_logmel):
+    names = list(DECODE_KERNELS) if mode == "decode" else list(ENCODE_KERNELS + DECODE_KERNELS)
+    if with_logmel:
+        names.append("logmel_kernel")
+    f32 = sum(KERNEL_WORK[k]["f32"] for k in names)
+    i8 = sum(KERNEL_WORK[k]["i8"] for k in names)
+    moved = sum(KERNEL_WORK[k]["moved"] for k in names)
+    ref_bytes = sum(KERNEL_WORK[k]["ref_bytes"] for k in names)
+    return names, f32, i8, moved, ref_bytes
+
+
+def step_roofline(mode, with_logmel, frames_per_s_per_gpu, traffic_table):
+    """The whole step against its binding bound."""
+    names, f32, i8, moved, ref_bytes = step_work(mode, with_logmel)
+    t_mfma = 2 * f32 / (PEAK_F32_MFMA_TFLOPS * 1e12) + 2 * i8 / (PEAK_I8_MFMA_TOPS * 1e12)
+    t_hbm = moved / (PEAK_HBM_GBS * 1e9)
+    traffic = None
+    if traffic_table:
+        vals = [traffic_table.get(k, {}).get("hbm_bytes_per_frame") for k in names]
+        if all(v is not None for v in vals):
+            traffic = round(sum(vals), 1)
+    common = {"kernel": "whole step: " + " + ".join(n.replace("_kernel", "") for n in names),
+              "fp32_mfma_ns_per_frame": round(2 * f32 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e9, 2),
+              "int8_mfma_ns_per_frame": round(2 * i8 / (PEAK_I8_MFMA_TOPS * 1e12) * 1e9, 2),
+              "hbm_ns_per_frame": round(t_hbm * 1e9, 2),
+              "algorithmic_flops_per_frame": 2 * f32, "moved_bytes_per_frame": moved,
+              "reference_representation_bytes_per_frame": ref_bytes,
+              "traffic": traffic, "traffic_unit": "HBM bytes per stream-frame",
+              "traffic_source": "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json), "
+                                "2*FETCH_SIZE + WRITE_SIZE per the gfx950 note in MI355X_MICROARCH.md"}
+    if t_mfma >= t_hbm:
+        ach = 2 * f32 * frames_per_s_per_gpu / 1e12
+        return dict(common, bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    hbm_frac=round(moved * frames_per_s_per_gpu / 1e9 / PEAK_HBM_GBS, 4))
+    ach = moved * frames_per_s_per_gpu / 1e9
+    return dict(common, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                frac=round(ach / PEAK_HBM_GBS, 4),
+                mfma_frac=round(2 * f32 * frames_per_s_per_gpu / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+
+
+def load_traffic():
+    """profiles/traffic.json: per kernel HBM bytes per launch at the batch it was profiled with (4096)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        batch = float(t.get("_batch", 4096))
+        for k, v in t.items():
+            if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+                v["hbm_bytes_per_frame"] = v["hbm_bytes_per_launch"] / batch
+        return t
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# one GPU's share of the job
+# ------------------------------------------------------------------------------------------------------------
+class Shard:
+    """All device buffers and the step function of ONE GPU (one rank, or one thread of the single-process mode)."""
+
+    RING = 32   # distinct synthetic input frames kept in HBM and cycled (bounds memory at B = 32768)
+
+    def __init__(self, device, first_id, wl, args, weights_image=None):
+        import torch
+        import lyra_amd
+        self.torch, self.lyra = torch, lyra_amd
+        self.dev = torch.device("cuda", device)
+        self.wl, self.args = wl, args
+        B, bits = wl["B"], wl["bits"]
+        self.ctx = lyra_amd.LyraHip(device=device, max_streams=B, requant="exact", weights_image=weights_image)
+        self.ctx.torch_order = False   # this harness synchronises explicitly around every region it times
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(SEED + first_id)
+        n = min(self.RING, args.warmup + args.steps)
+        # UnitToInt16Scalar(U(-1,1)) i.i.d. (lyra_benchmark_lib.cc:233-239): full-scale uniform int16
+        self.pcm_in = torch.randint(-32768, 32768, (n, B, 320), generator=gen, device=self.dev,
+                                    dtype=torch.int32).to(torch.int16)
+        self.ids = torch.arange(B, device=self.dev, dtype=torch.int32)  # local stream slots of this shard
+        nb = lyra_amd.packet_size(bits)
+        # two packet / PCM buffer sets, alternated (include/lyra_hip.h "Streams": the two-buffer rule)
+        self.packets = [torch.empty((B, nb), device=self.dev, dtype=torch.uint8) for _ in range(2)]
+        self.pcm_out = [torch.empty((B, 320), device=self.dev, dtype=torch.int16) for _ in range(2)]
+        self.mel = torch.empty((B, 160), device=self.dev, dtype=torch.float32) if args.with_logmel else None
+        self.feats = self.pk_seq = None
+        if wl["mode"] == "decode":
+            self._prepare_decode_inputs(n)
+        torch.cuda.synchronize(self.dev)
+
+    def _prepare_decode_inputs(self, n):
+        """Config #4: Extract -> Quantize -> DecodeToLossyFeatures once over the synthetic PCM
+        (lyra_benchmark_lib.cc:85-137); keep the lossy features and the packets of every step."""
+        torch, ctx, B, bits = self.torch, self.ctx, self.wl["B"], self.wl["bits"]
+        ns = bits // 4
+        self.feats = torch.empty((n, B, 64), device=self.dev, dtype=torch.float32)
+        self.pk_seq = torch.zeros((n, B, self.lyra.packet_size(bits)), device=self.dev, dtype=torch.uint8)
+        feat = torch.empty((B, 64), device=self.dev, dtype=torch.float32)
+        idx = torch.empty((B, 46), device=self.dev, dtype=torch.int32)
+        for i in range(n):
+            ctx.extract_dev(self.ids, self.pcm_in[i], feat)
+            ctx.rvq_encode_dev(feat, bits, idx)
+            ctx.rvq_decode_dev(idx, self.feats[i])      # decode side: ordered after the encode side by the library
+            ctx.synchronize()
+            nib = torch.zeros((B, 2 * self.pk_seq.shape[2]), device=self.dev, dtype=torch.int32)
+            nib[:, :ns] = idx[:, :ns]
+            self.pk_seq[i] = ((nib[:, 0::2] << 4) | nib[:, 1::2]).to(torch.uint8)   # packet.h:91-122, no header
+            torch.cuda.synchronize(self.dev)
+        ctx.reset()
+
+    # -- steps --------------------------------------------------------------------------------------------------
+    def step_encdec(self, i):
+        ctx, bits, j = self.ctx, self.wl["bits"], i % self.pcm_in.shape[0]
+        ctx.encode_dev(self.ids, self.pcm_in[j], bits, self.packets[i & 1])
+        ctx.decode_dev(self.ids, self.packets[i & 1], bits, self.pcm_out[i & 1])
+        if self.mel is not None:
+            ctx.logmel_dev(self.ids, self.pcm_out[i & 1], self.mel)
+
+    def step_generate(self, i):
+        self.ctx.generate_dev(self.ids, self.feats[i % self.feats.shape[0]], self.pcm_out[i & 1])
+        if self.mel is not None:
+            self.ctx.logmel_dev(self.ids, self.pcm_out[i & 1], self.mel)
+
+    def step_decode(self, i):
+        self.ctx.decode_dev(self.ids, self.pk_seq[i % self.pk_seq.shape[0]], self.wl["bits"], self.pcm_out[i & 1])
+        if self.mel is not None:
+            self.ctx.logmel_dev(self.ids, self.pcm_out[i & 1], self.mel)
+
+    def sync(self):
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize(self.dev)
+
+    def kernel_table(self, step, first, nsteps):
+        """Serialised pass: every kernel bracketed by HIP events, the two library streams strictly in call order."""
+        ctx = self.ctx
+        ctx.set_serial(True)
+        ctx.profile_enable(True)
+        for i in range(first, first + 2):   # first launches after the mode switch: not representative
+            step(i)
+        ctx.synchronize()
+        ctx.profile_read()
+        for i in range(first + 2, first + 2 + nsteps):
+            step(i)
+        ctx.synchronize()
+        prof = ctx.profile_read()
+        ctx.profile_enable(False)
+        ctx.set_serial(False)
+        B = self.wl["B"]
+        return {k: kernel_row(k, ms, n, B) for k, (ms, n) in prof.items() if n and k in KERNEL_WORK}
+
+    def timed(self, step, first, K, barrier, only=None):
+        """K steps between barriers + synchronises -> (seconds, dominant-kernel profile)."""
+        ctx = self.ctx
+        if only:
+            ctx.profile_enable(True, only=only)
+        barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for i in range(first, first + K):
+            step(i)
+        self.sync()
+        barrier()
+        t1 = time.perf_counter()
+        prof = ctx.profile_read() if only else {}
+        ctx.profile_enable(False)
+        return t1 - t0, prof
+
+
+def run_shard(sh, args, wl, barrier):
+    """Warm-up, serialised kernel table, timed region(s) of one shard -> dict of raw results."""
+    K, W = args.steps, args.warmup
+    step = sh.step_encdec if wl["mode"] == "encdec" else sh.step_generate
+    for i in range(W):
+        step(i)
+    sh.sync()
+    table = None
+    cursor = W
+    if not args.no_kernel_table:
+        table = sh.kernel_table(step, cursor, 8)
+        cursor += 10
+        for i in range(cursor, cursor + 2):   # back to the overlapped regime before timing
+            step(i)
+        cursor += 2
+        sh.sync()
+    dom = max(table, key=lambda k: table[k]["avg_us"]) if table else None
+    secs, prof = sh.timed(step, cursor, K, barrier, only=dom)
+    res = {"seconds": secs, "table": table, "dom": dom, "dom_prof": prof.get(dom) if dom else None}
+    if wl["mode"] == "decode":
+        cursor += K
+        for i in range(cursor, cursor + 3):
+            sh.step_decode(i)
+        sh.sync()
+        table2 = None
+        if not args.no_kernel_table:
+            table2 = sh.kernel_table(sh.step_decode, cursor + 3, 8)
+            sh.sync()
+        secs2, _ = sh.timed(sh.step_decode, cursor + 13, K, barrier)
+        res["secondary_seconds"] = secs2
+        res["secondary_table"] = table2
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------
+# result line
+# ------------------------------------------------------------------------------------------------------------
+def result_line(args, wl, world, secs, frames, res, launcher):
+    K, W, B, bits, mode = args.steps, args.warmup, wl["B"], wl["bits"], wl["mode"]
+    value = frames / secs
+    per_gpu = value / world
+    traffic_table = load_traffic()
+    roof = step_roofline(mode, args.with_logmel, per_gpu, traffic_table)
+    names, f32, i8, moved, _ = step_work(mode, args.with_logmel)
+    what = "encode+decode" if mode == "encdec" else "decode only (lyra_hip_generate_dev: features -> PCM)"
+    out = {
+        "metric": "20ms 16kHz frames/sec encode+decode (whole node) at batch 4096; xRT/stream",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(secs / K * 1e3, 4), "higher_is_better": True, "scaling": wl["scaling"],
+        "vs_baseline": None, "dtype": "f32+i8 (fp32 and int8 layers exactly as the reference graphs)",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE config #{wl['config']}: batch={B} streams/GPU x 1 frame(20 ms, 320 samples)"
+                               f"/step, {bits} bits ({bits // 4}-stage RVQ, {bits * 50} bps), {what}"
+                               + (", log-mel front end on every decoded hop" if args.with_logmel else "")
+                               + ", state carried across steps",
+                   "baseline_config": wl["config"], "streams_per_gpu": B, "total_streams": wl["total"],
+                   "num_bits": bits,
+                   "parallelism": f"streams sharded over {world} GPU(s), no data-path collective ({launcher})",
+                   "requant_mode": "exact"},
+        "xrt_per_stream": round(value / 50.0 / wl["total"], 3),
+        "xrt_aggregate": round(value / 50.0, 1),
+        "roofline": roof,
+    }
+    if res.get("table"):
+        out["kernels"] = res["table"]
+        out["kernels_note"] = ("serialised pass (lyra_hip_set_serial): HIP events on the library's streams, no "
+                               "cross-stream contention; 8 steps; frac = floor_us / avg_us at the kernel's binding bound")
+        out["serial_sum_us"] = round(sum(r["avg_us"] for r in res["table"].values()), 2)
+    if res.get("dom") and res.get("dom_prof") and res["dom_prof"][1]:
+        ms, n = res["dom_prof"]
+        row = kernel_row(res["dom"], ms, n, B)
+        row.update(kernel=res["dom"], measured_in="timed region (two library streams overlapping)")
+        if traffic_table and res["dom"] in traffic_table:
+            row["traffic_bytes_per_launch_at_B4096"] = traffic_table[res["dom"]].get("hbm_bytes_per_launch")
+        out["dominant_kernel"] = row
+    if mode == "decode":
+        s2 = res["secondary_seconds"]
+        v2 = frames / s2
+        out["secondary"] = {"what": "lyra_hip_decode_dev: packets -> PCM (RVQ decode fused into decoder stage 0)",
+                            "value": round(v2, 1), "unit": "frames/s", "ms_per_step": round(s2 / K * 1e3, 4)}
+        if res.get("secondary_table"):
+            out["secondary"]["kernels"] = res["secondary_table"]
+    return out
+
+
+def selftest_dist(args):
+    import torch
+    import torch.distributed as dist
+    rank, world, _ = dist_env()
+    if world > 1:
+        dist.init_process_group("gloo", init_method="env://")
+        dist.barrier()
+    wl = resolve_workload(args, world)
+    lo, per = shard_ids(wl["total"], rank, world)
+    assert per == wl["B"]
+    secs, units = reduce_job(0.5 + 0.25 * rank, per * args.steps, world, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"selftest": "dist", "world": world, "seconds": secs, "units": units,
+                          "first_id": lo, "per_rank": per, "scaling": wl["scaling"], "total": wl["total"]}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def broadcast_weights(rank, dev):
+    """RCCL broadcast of the packed weight container (3.2 MB) from rank 0: the one collective with a
+    payload in the whole job, at init, outside the timed region."""
+    import torch
+    import torch.distributed as dist
+    import lyra_amd
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        raw = np.fromfile(os.path.join(lyra_amd.default_model_dir(), "lyra_v1.lyrapack"), dtype=np.uint8)
+        n[0] = raw.size
+    dist.broadcast(n, src=0)
+    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    if rank == 0:
+        buf.copy_(torch.from_numpy(raw))
+    dist.broadcast(buf, src=0)
+    return buf.cpu().numpy().tobytes()
+
+
+def main_single_process(args, ngpu):
+    """--gpus N without torch.distributed: one process, one thread and one context per GPU.  ctypes releases the GIL
+    around every library call, so the N host threads enqueue concurrently."""
+    import torch
+    if torch.cuda.device_count() < ngpu:
+        raise SystemExit(f"--gpus {ngpu} but only {torch.cuda.device_count()} device(s) visible")
+    wl = resolve_workload(args, ngpu)
+    shards = [None] * ngpu
+    results = [None] * ngpu
+    bar = threading.Barrier(ngpu)
+
+    def worker(r):
+        torch.cuda.set_device(r)
+        first, _ = shard_ids(wl["total"], r, ngpu)
+        shards[r] = Shard(r, first, wl, args)
+        bar.wait()
+        results[r] = run_shard(shards[r], args, wl, bar.wait)
+
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(ngpu)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    secs = max(r["seconds"] for r in results)
+    res = dict(results[0])
+    if wl["mode"] == "decode":
+        res["secondary_seconds"] = max(r["secondary_seconds"] for r in results)
+    out = result_line(args, wl, ngpu, secs, wl["B"] * ngpu * args.steps, res, "one process, one host thread per GPU")
+    print(json.dumps(out))
+
+
+def main(argv=None):
+    args = parse(argv)
     if args.selftest_dist:
         return selftest_dist(args)
     import torch
-    import lyra_amd
     rank, world, local = dist_env()
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback); use --selftest-dist for the plumbing test")
+    if world == 1 and args.gpus > 1:
+        return main_single_process(args, args.gpus)
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
-
-    B, K, W, bits = args.streams, args.steps, args.warmup, args.bits
-    first_id, _ = shard_ids(B * world, rank, world)
-    ctx = lyra_amd.LyraHip(device=local, max_streams=B, requant="exact")
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(SEED + first_id)
-    # UnitToInt16Scalar(U(-1,1)) i.i.d. (lyra_benchmark_lib.cc:233-239): full-scale uniform int16
-    pcm_in = torch.randint(-32768, 32768, (W + K, B, 320), generator=gen, device=dev, dtype=torch.int32).to(torch.int16)
-    ids = torch.arange(B, device=dev, dtype=torch.int32)  # local stream slots of this rank's shard
-    # two packet / PCM buffers, alternated: the library runs decode of step i (decode-side stream) concurrently with
-    # encode of step i+1 (encode-side stream); a packet buffer is rewritten only two steps later, after a
-    # stream-ordered decode has consumed it (include/lyra_hip.h "Streams").
-    packets = [torch.empty((B, lyra_amd.packet_size(bits)), device=dev, dtype=torch.uint8) for _ in range(2)]
-    pcm_out = [torch.empty((B, 320), device=dev, dtype=torch.int16) for _ in range(2)]
-    torch.cuda.synchronize()
-
-    def step(i):
-        # (the library orders encode(i) after decode(i-2): alternating two buffers is all the caller has to do)
-        ctx.encode_dev(ids, pcm_in[i], bits, packets[i & 1])
-        ctx.decode_dev(ids, packets[i & 1], bits, pcm_out[i & 1])
-
-    # warm-up: every kernel bracketed by HIP events -> per-kernel share and the dominant kernel
-    ctx.profile_enable(True)
-    cold = min(2, max(W - 1, 0))
-    for i in range(cold):           # first launches carry one-off costs (code upload, lazy init): not representative
-        step(i)
-    ctx.synchronize()
-    ctx.profile_read()
-    for i in range(cold, W):
-        step(i)
-    ctx.synchronize()
-    warm = ctx.profile_read()
-    dom = max((k for k in warm if k in KERNEL_WORK and warm[k][1]), key=lambda k: warm[k][0] / warm[k][1])
-    # timed region: only the dominant kernel is bracketed (two event records per step instead of sixteen)
-    ctx.profile_enable(True, only=dom)
+    wl = resolve_workload(args, world)
+    first_id, _ = shard_ids(wl["total"], rank, world)
+    image = broadcast_weights(rank, dev) if (args.bcast_weights and world > 1) else None
+    sh = Shard(local, first_id, wl, args, weights_image=image)
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-    barrier()
-    torch.cuda.synchronize()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
-    for k, val in warm.items():  # other kernels: warm-up averages (reported for context only)
-        if k != dom:
-            prof[k] = val
 
-    secs, frames = reduce_job(t1 - t0, B * K, world, dev)
-    if rank != 0:
-        if world > 1:
-            import torch.distributed as dist
-            dist.destroy_process_group()
-        return
-
-    value = frames / secs
-    kern = {}
-    for name, (ms, n) in prof.items():
-        if n == 0 or name not in KERNEL_WORK:
-            continue
-        w = KERNEL_WORK[name]
-        dur = ms / n * 1e-3
-        kern[name] = {"avg_us": round(dur * 1e6, 2), "launches": n,
-                      "f32_tflops": round(2 * w["f32"] * B / dur / 1e12, 3),
-                      "i8_tops": round(2 * w["i8"] * B / dur / 1e12, 3),
-                      "alg_gbs": round(w["bytes"] * B / dur / 1e9, 1)}
-    kern[dom]["measured_in"] = "timed region"
-    w = KERNEL_WORK[dom]
-    dur = kern[dom]["avg_us"] * 1e-6
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from rocprofv3 --pmc passes (offline)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    # the binding bound of this kernel: whichever of (fp32 MFMA + int8 MFMA time) and HBM time is longer at peak
-    t_mfma = 2 * w["f32"] * B / (PEAK_F32_MFMA_TFLOPS * 1e12) + 2 * w["i8"] * B / (PEAK_I8_MFMA_TOPS * 1e12)
-    t_hbm = w["bytes"] * B / (PEAK_HBM_GBS * 1e9)
-    if t_mfma >= t_hbm:
-        ach = 2 * w["f32"] * B / dur / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "algorithmic_flops_per_launch": 2 * w["f32"] * B, "algorithmic_bytes_per_launch": w["bytes"] * B,
-                "avg_launch_us": kern[dom]["avg_us"]}
-    else:
-        ach = w["bytes"] * B / dur / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": w["bytes"] * B, "avg_launch_us": kern[dom]["avg_us"]}
-    out = {
-        "metric": "20ms 16kHz frames/sec encode+decode (whole node) at batch 4096; xRT/stream",
-        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(secs / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32+i8 (fp32 and int8 layers exactly as the reference graphs)",
-        "data": "synthetic",
-        "config": {"workload": f"batch={B} streams/GPU x 1 frame(20 ms, 320 samples)/step, {bits} bits "
-                               f"({bits // 4}-stage RVQ, {bits * 50} bps), encode+decode, state carried across steps",
-                   "streams_per_gpu": B, "total_streams": B * world, "num_bits": bits,
-                   "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
-                   "requant_mode": "exact"},
-        "xrt_per_stream": round(value / 50.0 / (B * world), 3),
-        "xrt_aggregate": round(value / 50.0, 1),
-        "path_f32_tflops": round(value * 5.425152e6 / 1e12 / world, 3),
-        "path_frac_of_f32_mfma_peak": round(value * 5.425152e6 / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
-        "roofline": roof,
-        "kernels": kern,
-    }
-    if world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(bits)
-        except Exception as e:  # the baseline leg must never take the GPU number down with it
-            out["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(out))
+    res = run_shard(sh, args, wl, barrier)
+    secs, frames = reduce_job(res["seconds"], wl["B"] * args.steps, world, dev)
+    if wl["mode"] == "decode":
+        res["secondary_seconds"], _ = reduce_job(res["secondary_seconds"], 0, world, dev)
+    if rank == 0:
+        out = result_line(args, wl, world, secs, frames, res, "one process per GPU, torch.distributed/RCCL for the "
+                          "timing barrier and the result reduction only")
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl["bits"], wl["mode"])
+            except Exception as e:  # the baseline leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

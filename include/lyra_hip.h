@@ -9,8 +9,9 @@
  * callers of these functions; INTEGRATION.md shows the binding a reference
  * maintainer would add in lyra/lyra_components.cc:42-65.
  *
- * Model: one context = one GPU + one HIP stream + per-stream codec state for
- * `max_streams` independent audio streams.  A "frame" is one 20 ms hop of
+ * Model: one context = one GPU + two HIP streams (encode side / decode side,
+ * see "Streams") + per-stream codec state for `max_streams` independent audio
+ * streams.  A "frame" is one 20 ms hop of
  * 16 kHz audio (320 samples); the codec is streaming/causal, so stream `id`
  * must be fed its frames in order (the reference keeps this state inside the
  * TFLite interpreter's resource variables: lyra/tflite_model_wrapper.cc:36-121).
@@ -30,13 +31,27 @@
  *
  * Streams: a context runs two HIP streams -- the ENCODE side (extract,
  * rvq_encode, encode) and the DECODE side (rvq_decode, generate, decode,
- * logmel); encoder and decoder state are disjoint.  A decode-side call is
- * ordered (on the GPU) after every earlier encode-side call, so
- * encode_dev -> decode_dev on the produced packets needs no caller sync.
- * Encode-side calls are NOT ordered after earlier decode-side calls: encode of
- * frame i+1 overlaps decode of frame i.  With `_dev` variants, do not let an
- * encode-side call overwrite a buffer that a pending decode-side call still
- * reads (alternate two buffers, or lyra_hip_synchronize()).
+ * logmel, and the stateless helpers rvq_decode_dev / logmel_dev count as
+ * decode-side calls too); encoder and decoder state are disjoint.  What the
+ * library guarantees on the GPU, without any caller synchronisation:
+ *   (1) a decode-side call is ordered after EVERY earlier encode-side call, so
+ *       encode_dev -> decode_dev on the produced packets just works;
+ *   (2) an encode-side call is ordered after every earlier decode-side call
+ *       EXCEPT THE MOST RECENT ONE: encode of frame i+1 overlaps decode of
+ *       frame i, but not decode of frame i-1.
+ * Two-buffer rule for `_dev` callers: alternate two packet/PCM buffer sets
+ * (step i uses set i & 1).  By (2) the encode that rewrites set i & 1 at step
+ * i+2 is ordered after the decode that read it at step i.  A caller that
+ * reuses ONE buffer set must lyra_hip_synchronize() (or lyra_hip_set_serial)
+ * between steps.
+ * Both library streams are hipStreamNonBlocking: they do NOT order against the
+ * null stream or any stream of the caller.  A `_dev` caller that produces
+ * inputs or consumes outputs on its own stream brackets the calls with
+ * lyra_hip_wait_for_stream(ctx, s) (library work enqueued afterwards waits
+ * for what is already enqueued on s) and lyra_hip_stream_wait(ctx, s) (work
+ * enqueued on s afterwards waits for the library work enqueued so far), or
+ * synchronises.  `_dev` calls run on the context's device regardless of the
+ * caller's current device (which is restored on return).
  */
 #ifndef LYRA_HIP_H_
 #define LYRA_HIP_H_
@@ -67,10 +82,19 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
 
 /* Replaces CreateFeatureExtractor / CreateQuantizer / CreateGenerativeModel
  * (lyra/lyra_components.cc:42-55) + TfLiteModelWrapper::Create
- * (lyra/tflite_model_wrapper.cc:36-95).  `model_dir` must contain
- * lyra_v1.lyrapack (tools/pack_weights.py output for the reference's
- * model_coeffs directory; version identifier 3 as lyra_config.h:145-166). */
+ * (lyra/tflite_model_wrapper.cc:36-95).  `model_dir` is either the reference's
+ * own model directory (soundstream_encoder.tflite, quantizer.tflite,
+ * lyragan.tflite, lyra_config.binarypb -- converted in memory) or a directory
+ * holding the pre-packed lyra_v1.lyrapack (tools/pack_weights.py / pack_tool
+ * output for that directory; used first if present).  Version identifier 3 as
+ * lyra_config.h:145-166.  The container is validated (bounds, dtypes, the
+ * layer shapes the kernels are specialised to): a truncated or foreign file
+ * gives LYRA_HIP_EMODEL. */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
+/* The same from an in-memory lyra_v1.lyrapack image (e.g. read once by rank 0 and broadcast to the other GPUs' ranks
+ * over RCCL); the image is copied, the caller keeps ownership. */
+int lyra_hip_create_from_image(const void* image, size_t image_bytes, int device, int max_streams, int requant_mode,
+                               lyra_hip_ctx** out);
 void lyra_hip_destroy(lyra_hip_ctx* ctx);
 const char* lyra_hip_last_error(const lyra_hip_ctx* ctx); /* ctx may be NULL: last create() error */
 
@@ -134,6 +158,12 @@ int lyra_hip_decode_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, c
 void* lyra_hip_stream(lyra_hip_ctx* ctx);
 void* lyra_hip_stream_decode(lyra_hip_ctx* ctx);
 int lyra_hip_synchronize(lyra_hip_ctx* ctx);
+/* Ordering against a caller-owned HIP stream (hipStream_t as void*, NULL = the null stream); see "Streams". */
+int lyra_hip_wait_for_stream(lyra_hip_ctx* ctx, void* caller_stream);
+int lyra_hip_stream_wait(lyra_hip_ctx* ctx, void* caller_stream);
+/* on != 0: encode-side calls also wait for the MOST RECENT decode-side call, i.e. the two library streams run
+ * strictly in call order (one buffer set suffices; per-kernel timings are free of cross-stream contention). */
+int lyra_hip_set_serial(lyra_hip_ctx* ctx, int on);
 
 /* Per-stream state footprint in HBM (bytes) and the context's stream capacity. */
 size_t lyra_hip_state_bytes_per_stream(void);

@@ -80,6 +80,7 @@ def _load():
     L = C.CDLL(path)
     vp, ci, cp = C.c_void_p, C.c_int, C.c_char_p
     L.lyra_hip_create.argtypes = [cp, ci, ci, ci, C.POINTER(vp)]
+    L.lyra_hip_create_from_image.argtypes = [cp, C.c_size_t, ci, ci, ci, C.POINTER(vp)]
     L.lyra_hip_destroy.argtypes = [vp]
     L.lyra_hip_last_error.restype = cp
     L.lyra_hip_last_error.argtypes = [vp]
@@ -97,6 +98,9 @@ def _load():
     L.lyra_hip_stream_decode.restype = vp
     L.lyra_hip_stream_decode.argtypes = [vp]
     L.lyra_hip_synchronize.argtypes = [vp]
+    L.lyra_hip_wait_for_stream.argtypes = [vp, vp]
+    L.lyra_hip_stream_wait.argtypes = [vp, vp]
+    L.lyra_hip_set_serial.argtypes = [vp, ci]
     L.lyra_hip_state_bytes_per_stream.restype = C.c_size_t
     L.lyra_hip_max_streams.argtypes = [vp]
     L.lyra_hip_profile_enable.argtypes = [vp, C.c_uint]
@@ -109,10 +113,6 @@ def _load():
     return L
 
 
-def _is_torch(x):
-    return type(x).__module__.startswith("torch")
-
-
 def _np(a, dtype, shape):
     a = np.ascontiguousarray(a, dtype)
     return a.reshape(shape)
@@ -121,11 +121,17 @@ def _np(a, dtype, shape):
 class LyraHip:
     """One GPU context: weights + per-stream state for `max_streams` streams."""
 
-    def __init__(self, model_dir=None, device=0, max_streams=4096, requant="exact"):
+    def __init__(self, model_dir=None, device=0, max_streams=4096, requant="exact", weights_image=None):
         self.L = _load()
         h = C.c_void_p()
         mode = {"exact": 0, "gemmlowp_double": 1}[requant]
-        rc = self.L.lyra_hip_create((model_dir or default_model_dir()).encode(), device, max_streams, mode, C.byref(h))
+        if weights_image is not None:   # bytes of a lyra_v1.lyrapack (lyra_hip_create_from_image)
+            weights_image = bytes(weights_image)
+            rc = self.L.lyra_hip_create_from_image(weights_image, len(weights_image), device, max_streams, mode,
+                                                   C.byref(h))
+        else:
+            rc = self.L.lyra_hip_create((model_dir or default_model_dir()).encode(), device, max_streams, mode,
+                                        C.byref(h))
         if rc != 0:
             raise LyraHipError(f"lyra_hip_create failed ({rc}): {self.L.lyra_hip_last_error(None).decode()}")
         self.h = h
@@ -266,35 +272,83 @@ class LyraHip:
             raise LyraHipError(self.last_error())
         return out[:got]
 
-    # -- torch (device pointer) API: tensors must live on this context's device ------------------------------
+    # -- torch (device pointer) API ---------------------------------------------------------------------------
+    # The library's streams are non-blocking: they do not order against torch's streams by themselves.  With
+    # `torch_order=True` (default) every `_dev` call is bracketed by lyra_hip_wait_for_stream /
+    # lyra_hip_stream_wait on torch's CURRENT stream, so tensors produced or consumed by torch kernels on that
+    # stream are safe without a synchronize.  bench.py turns it off (it synchronises explicitly around the timed
+    # region and wants no extra event traffic inside it).
+    torch_order = True
+
+    def set_serial(self, on=True):
+        """Run the two library streams strictly in call order (lyra_hip_set_serial)."""
+        self._chk(self.L.lyra_hip_set_serial(self.h, 1 if on else 0))
+
+    def _dev_ptr(self, t, dtype_name, shape, what):
+        import torch
+        want = getattr(torch, dtype_name)
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device.index != self.device:
+            raise LyraHipError(f"{what}: expected a CUDA tensor on device {self.device}")
+        if t.dtype != want:
+            raise LyraHipError(f"{what}: dtype {t.dtype}, expected {want}")
+        if not t.is_contiguous():
+            raise LyraHipError(f"{what}: tensor is not contiguous")
+        if tuple(t.shape) != tuple(shape):
+            raise LyraHipError(f"{what}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+        return t.data_ptr()
+
+    def _torch_stream(self):
+        import torch
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _dev_call(self, fn, *args):
+        if self.torch_order:
+            st = self._torch_stream()
+            self._chk(self.L.lyra_hip_wait_for_stream(self.h, st))
+            self._chk(fn(self.h, *args))
+            self._chk(self.L.lyra_hip_stream_wait(self.h, st))
+        else:
+            self._chk(fn(self.h, *args))
+
     def encode_dev(self, d_ids, d_pcm, num_bits, d_packets):
         B = d_pcm.shape[0]
-        self._chk(self.L.lyra_hip_encode_dev(self.h, d_ids.data_ptr(), B, d_pcm.data_ptr(), num_bits,
-                                             d_packets.data_ptr()))
+        self._dev_call(self.L.lyra_hip_encode_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"), num_bits,
+                       self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"))
 
     def decode_dev(self, d_ids, d_packets, num_bits, d_pcm):
         B = d_pcm.shape[0]
-        self._chk(self.L.lyra_hip_decode_dev(self.h, d_ids.data_ptr(), B, d_packets.data_ptr(), num_bits,
-                                             d_pcm.data_ptr()))
+        self._dev_call(self.L.lyra_hip_decode_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"), num_bits,
+                       self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"))
 
     def extract_dev(self, d_ids, d_pcm, d_feat):
-        self._chk(self.L.lyra_hip_extract_dev(self.h, d_ids.data_ptr(), d_pcm.shape[0], d_pcm.data_ptr(),
-                                              d_feat.data_ptr()))
+        B = d_pcm.shape[0]
+        self._dev_call(self.L.lyra_hip_extract_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"),
+                       self._dev_ptr(d_feat, "float32", (B, NUM_FEATURES), "features"))
 
     def generate_dev(self, d_ids, d_feat, d_pcm):
-        self._chk(self.L.lyra_hip_generate_dev(self.h, d_ids.data_ptr(), d_feat.shape[0], d_feat.data_ptr(),
-                                               d_pcm.data_ptr()))
+        B = d_feat.shape[0]
+        self._dev_call(self.L.lyra_hip_generate_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_feat, "float32", (B, NUM_FEATURES), "features"),
+                       self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"))
 
     def logmel_dev(self, d_ids, d_pcm, d_mel):
-        self._chk(self.L.lyra_hip_logmel_dev(self.h, d_ids.data_ptr(), d_pcm.shape[0], d_pcm.data_ptr(),
-                                             d_mel.data_ptr()))
+        B = d_pcm.shape[0]
+        self._dev_call(self.L.lyra_hip_logmel_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"),
+                       self._dev_ptr(d_mel, "float32", (B, NUM_MEL), "mel"))
 
     def rvq_encode_dev(self, d_feat, num_bits, d_idx):
-        self._chk(self.L.lyra_hip_rvq_encode_dev(self.h, d_feat.shape[0], d_feat.data_ptr(), num_bits,
-                                                 d_idx.data_ptr()))
+        B = d_feat.shape[0]
+        self._dev_call(self.L.lyra_hip_rvq_encode_dev, B, self._dev_ptr(d_feat, "float32", (B, NUM_FEATURES), "features"),
+                       num_bits, self._dev_ptr(d_idx, "int32", (B, 46), "indices"))
 
     def rvq_decode_dev(self, d_idx, d_feat):
-        self._chk(self.L.lyra_hip_rvq_decode_dev(self.h, d_idx.shape[0], d_idx.data_ptr(), d_feat.data_ptr()))
+        B = d_idx.shape[0]
+        self._dev_call(self.L.lyra_hip_rvq_decode_dev, B, self._dev_ptr(d_idx, "int32", (B, 46), "indices"),
+                       self._dev_ptr(d_feat, "float32", (B, NUM_FEATURES), "features"))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -4,8 +4,8 @@
 // Two HIP streams per context: the ENCODE side (extract, rvq_encode, encode) and the DECODE side (rvq_decode,
 // generate, decode, logmel).  Encoder and decoder state are disjoint, so decode of step i can overlap encode of
 // step i+1; every stage kernel is a chain of short dependent phases, and two chains in flight fill each other's
-// bubbles.  Ordering: a decode-side call waits (on the GPU) for every earlier encode-side call; encode-side calls do
-// not wait for decode-side calls.
+// bubbles.  Ordering: a decode-side call waits (on the GPU) for every earlier encode-side call; an encode-side call
+// waits for every decode-side call except the most recent one (enc_side_begin; include/lyra_hip.h "Streams").
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -38,6 +38,8 @@ struct lyra_hip_ctx {
   hipEvent_t ev_enc[KMAX] = {};    // end of the latest encode-side work on se[k]
   hipEvent_t ev_dec[2][KMAX] = {}; // end of the two latest decode-side calls on sd[k]
   long n_dec_calls = 0;
+  bool serial = false;             // lyra_hip_set_serial: encode side also waits for the latest decode-side call
+  hipEvent_t ev_caller = nullptr;  // scratch event for lyra_hip_wait_for_stream / lyra_hip_stream_wait
   Model model;
   uint8_t* d_state = nullptr;
   // scratch, sized for `cap` frames
@@ -174,13 +176,21 @@ hipEvent_t take_event(lyra_hip_ctx* c) {
   (void)hipEventCreate(&e);
   return e;
 }
+// Timing only: a failed record here loses one sample (the span is dropped), never an ordering edge.
 struct ProfScope {
   lyra_hip_ctx* c; int kid; hipStream_t s; hipEvent_t a = nullptr;
   ProfScope(lyra_hip_ctx* c_, int kid_, hipStream_t s_) : c(c_), kid(kid_), s(s_) {
-    if (c->profiling & (1u << kid)) { a = take_event(c); (void)hipEventRecord(a, s); }
+    if (c->profiling & (1u << kid)) {
+      a = take_event(c);
+      if (a && hipEventRecord(a, s) != hipSuccess) { c->event_pool.push_back(a); a = nullptr; }
+    }
   }
   ~ProfScope() {
-    if (a) { hipEvent_t b = take_event(c); (void)hipEventRecord(b, s); c->spans.push_back({kid, a, b}); }
+    if (!a) return;
+    hipEvent_t b = take_event(c);
+    if (b && hipEventRecord(b, s) == hipSuccess) { c->spans.push_back({kid, a, b}); return; }
+    c->event_pool.push_back(a);
+    if (b) c->event_pool.push_back(b);
   }
 };
 
@@ -189,21 +199,43 @@ struct ProfScope {
 //  * decode-side work on chunk k waits for all encode-side work enqueued so far;
 //  * encode-side work on chunk k waits for every decode-side call except the most recent one, so a caller that
 //    alternates two buffers never has a buffer rewritten while a pending decode still reads it.
-void enc_side_begin(lyra_hip_ctx* c, int k) {
-  if (c->n_dec_calls >= 2) (void)hipStreamWaitEvent(c->se[k], c->ev_dec[c->n_dec_calls & 1][k], 0);
+// These edges ARE the encode -> decode dependency: every record / wait is checked, a failure fails the call.
+int enc_side_begin(lyra_hip_ctx* c, int k) {
+  if (c->n_dec_calls >= 2) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_dec[c->n_dec_calls & 1][k], 0));
+  if (c->serial && c->n_dec_calls >= 1)
+    HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_dec[(c->n_dec_calls - 1) & 1][k], 0));
+  return 0;
 }
-void enc_side_done(lyra_hip_ctx* c, int k) { (void)hipEventRecord(c->ev_enc[k], c->se[k]); }
-void dec_side_begin(lyra_hip_ctx* c, int k) {
-  for (int j = 0; j < c->nsub; ++j) (void)hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0);
+int enc_side_done(lyra_hip_ctx* c, int k) {
+  HIPCHK(c, hipEventRecord(c->ev_enc[k], c->se[k]));
+  return 0;
 }
-void dec_side_done(lyra_hip_ctx* c, int k, int nk = 0) {
+int dec_side_begin(lyra_hip_ctx* c, int k) {
+  for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0));
+  return 0;
+}
+int dec_side_done(lyra_hip_ctx* c, int k, int nk = 0) {
   const int slot = (int)(c->n_dec_calls & 1);
   if (nk == 1) {  // an unsplit call stands for every chunk
-    for (int j = 0; j < c->nsub; ++j) (void)hipEventRecord(c->ev_dec[slot][j], c->sd[0]);
+    for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipEventRecord(c->ev_dec[slot][j], c->sd[0]));
   } else {
-    (void)hipEventRecord(c->ev_dec[slot][k], c->sd[k]);
+    HIPCHK(c, hipEventRecord(c->ev_dec[slot][k], c->sd[k]));
   }
+  return 0;
 }
+// `_dev` entry points run on the context's device whatever the caller's current device is (a process may hold
+// contexts on several GPUs); the caller's device is restored on return.
+struct DeviceScope {
+  int prev = -1; bool ok = true;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define DEVSCOPE(c)                   \
+  DeviceScope devscope_((c)->device); \
+  if (!devscope_.ok) return fail(c, LYRA_HIP_EHIP, "hipSetDevice(%d) failed", (c)->device)
 
 // chunk k of a batch of B frames: [lo, lo + n), multiples of 16 streams so tiles stay whole
 void chunk_of(const lyra_hip_ctx* c, int B, int k, int* lo, int* n) {
@@ -293,8 +325,36 @@ hipError_t set_lds(K kernel, size_t bytes) {
 
 extern "C" {
 
+static int create_impl(const char* model_dir, const void* image, size_t image_bytes, int device, int max_streams,
+                       int requant_mode, lyra_hip_ctx** out);
+
+static int create_guarded(const char* model_dir, const void* image, size_t image_bytes, int device, int max_streams,
+                          int requant_mode, lyra_hip_ctx** out) {
+  try {
+    return create_impl(model_dir, image, image_bytes, device, max_streams, requant_mode, out);
+  } catch (const std::bad_alloc&) {      // no exception may cross the C boundary
+    if (out) *out = nullptr;
+    return fail(nullptr, LYRA_HIP_ENOMEM, "out of host memory while loading the model");
+  } catch (const std::exception& e) {
+    if (out) *out = nullptr;
+    return fail(nullptr, LYRA_HIP_EMODEL, "model load failed: %s", e.what());
+  }
+}
+
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out) {
-  if (!out || !model_dir || max_streams <= 0 || (requant_mode != 0 && requant_mode != 1))
+  if (!model_dir) return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create: bad argument");
+  return create_guarded(model_dir, nullptr, 0, device, max_streams, requant_mode, out);
+}
+
+int lyra_hip_create_from_image(const void* image, size_t image_bytes, int device, int max_streams, int requant_mode,
+                               lyra_hip_ctx** out) {
+  if (!image || image_bytes == 0) return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create_from_image: bad argument");
+  return create_guarded(nullptr, image, image_bytes, device, max_streams, requant_mode, out);
+}
+
+static int create_impl(const char* model_dir, const void* image, size_t image_bytes, int device, int max_streams,
+                       int requant_mode, lyra_hip_ctx** out) {
+  if (!out || max_streams <= 0 || (requant_mode != 0 && requant_mode != 1))
     return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create: bad argument");
   *out = nullptr;
   int ndev = 0;
@@ -310,12 +370,17 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
   std::string err;
   // Either the pre-packed container or -- as the reference's factories get it -- a model directory with the three
   // .tflite graphs and lyra_config.binarypb (lyra_components.cc:42-55, lyra_config.cc:55-58), converted in memory.
-  std::string path = std::string(model_dir) + "/lyra_v1.lyrapack";
-  if (!pk.open(path, &err)) {
-    std::vector<uint8_t> image;
-    std::string err2;
-    if (!pack_from_tflite_dir(model_dir, &image, &err2) || !pk.adopt(std::move(image), &err2))
-      return fail(nullptr, LYRA_HIP_EMODEL, "%s; %s", err.c_str(), err2.c_str());
+  if (image) {   // an in-memory LYRAPK01 image (e.g. received over an RCCL broadcast)
+    const uint8_t* p = static_cast<const uint8_t*>(image);
+    if (!pk.adopt(std::vector<uint8_t>(p, p + image_bytes), &err)) return fail(nullptr, LYRA_HIP_EMODEL, "%s", err.c_str());
+  } else {
+    std::string path = std::string(model_dir) + "/lyra_v1.lyrapack";
+    if (!pk.open(path, &err)) {
+      std::vector<uint8_t> conv;
+      std::string err2;
+      if (!pack_from_tflite_dir(model_dir, &conv, &err2) || !pk.adopt(std::move(conv), &err2))
+        return fail(nullptr, LYRA_HIP_EMODEL, "%s; %s", err.c_str(), err2.c_str());
+    }
   }
   lyra_hip_ctx* c = new lyra_hip_ctx();
   c->device = device;
@@ -349,7 +414,8 @@ int lyra_hip_create(const char* model_dir, int device, int max_streams, int requ
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
-  for (int k = 0; k < c->nsub; ++k) enc_side_done(c, k);
+  for (int k = 0; k < c->nsub; ++k)
+    if (enc_side_done(c, k) != 0) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
   *out = c;
   int rc = lyra_hip_reset_streams(c, nullptr, 0);
   if (rc == 0) rc = sync_all(c);
@@ -364,6 +430,7 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   free_scratch(c);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->ev_caller) (void)hipEventDestroy(c->ev_caller);
   for (int k = 0; k < lyra_hip_ctx::KMAX; ++k) {
     if (c->ev_enc[k]) (void)hipEventDestroy(c->ev_enc[k]);
     if (c->ev_dec[0][k]) (void)hipEventDestroy(c->ev_dec[0][k]);
@@ -417,15 +484,16 @@ int lyra_hip_extract_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int
   int rc = check_batch(c, B);
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  DEVSCOPE(c);
   if ((rc = ensure_scratch(c, B))) return rc;
   const int nk = chunks_for(c, B);
   for (int k = 0; k < nk && !rc; ++k) {
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    enc_side_begin(c, k);
+    if ((rc = enc_side_begin(c, k))) break;
     rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, d_feat + (size_t)lo * 64);
-    enc_side_done(c, k);
+    if (!rc) rc = enc_side_done(c, k);
   }
   return rc;
 }
@@ -435,18 +503,21 @@ int lyra_hip_rvq_encode_dev(lyra_hip_ctx* c, int B, const float* d_feat, int num
   int rc = check_bits(c, num_bits);
   if (rc) return rc;
   if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
-  enc_side_begin(c, 0);
+  DEVSCOPE(c);
+  if ((rc = enc_side_begin(c, 0))) return rc;
   rc = launch_rvq_encode(c, 0, B, d_feat, num_bits / 4, d_idx, nullptr);
-  enc_side_done(c, 0);
+  if (!rc) rc = enc_side_done(c, 0);
   return rc;
 }
 
 int lyra_hip_rvq_decode_dev(lyra_hip_ctx* c, int B, const int32_t* d_idx, float* d_feat) {
   if (!c) return LYRA_HIP_EINVAL;
   if (B <= 0 || !d_feat || !d_idx) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
-  dec_side_begin(c, 0);
-  int rc = launch_rvq_decode(c, 0, B, d_idx, nullptr, 46, d_feat);
-  dec_side_done(c, 0, 1);
+  DEVSCOPE(c);
+  int rc = dec_side_begin(c, 0);
+  if (rc) return rc;
+  rc = launch_rvq_decode(c, 0, B, d_idx, nullptr, 46, d_feat);
+  if (!rc) rc = dec_side_done(c, 0, 1);
   c->n_dec_calls++;
   return rc;
 }
@@ -455,15 +526,16 @@ int lyra_hip_generate_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const fl
   int rc = check_batch(c, B);
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_feat) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  DEVSCOPE(c);
   if ((rc = ensure_scratch(c, B))) return rc;
   const int nk = chunks_for(c, B);
   for (int k = 0; k < nk && !rc; ++k) {
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    dec_side_begin(c, k);
+    if ((rc = dec_side_begin(c, k))) break;
     rc = launch_generate(c, k, lo, d_ids + lo, n, d_feat + (size_t)lo * 64, d_pcm + (size_t)lo * 320);
-    dec_side_done(c, k, nk);
+    if (!rc) rc = dec_side_done(c, k, nk);
   }
   c->n_dec_calls++;
   return rc;
@@ -473,9 +545,10 @@ int lyra_hip_logmel_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
   int rc = check_batch(c, B);
   if (rc) return rc;
   if (!d_ids || !d_pcm || !d_mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
-  dec_side_begin(c, 0);
+  DEVSCOPE(c);
+  if ((rc = dec_side_begin(c, 0))) return rc;
   rc = launch_logmel(c, d_ids, B, d_pcm, d_mel);
-  dec_side_done(c, 0, 1);
+  if (!rc) rc = dec_side_done(c, 0, 1);
   c->n_dec_calls++;
   return rc;
 }
@@ -486,6 +559,7 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
   if (rc) return rc;
   if ((rc = check_bits(c, num_bits))) return rc;
   if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  DEVSCOPE(c);
   if ((rc = ensure_scratch(c, B))) return rc;
   const int nbytes = (num_bits + 7) / 8;
   const int nk = chunks_for(c, B);
@@ -493,11 +567,11 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    enc_side_begin(c, k);
+    if ((rc = enc_side_begin(c, k))) break;
     float* feat = c->d_feat + (size_t)lo * 64;
     rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, feat);
     if (!rc) rc = launch_rvq_encode(c, k, n, feat, num_bits / 4, nullptr, d_packets + (size_t)lo * nbytes);
-    enc_side_done(c, k);
+    if (!rc) rc = enc_side_done(c, k);
   }
   return rc;
 }
@@ -508,6 +582,7 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
   if (rc) return rc;
   if ((rc = check_bits(c, num_bits))) return rc;
   if (!d_ids || !d_pcm || !d_packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  DEVSCOPE(c);
   if ((rc = ensure_scratch(c, B))) return rc;
   const int nbytes = (num_bits + 7) / 8;
   const int nk = chunks_for(c, B);
@@ -515,13 +590,47 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    dec_side_begin(c, k);
+    if ((rc = dec_side_begin(c, k))) break;
     rc = launch_generate(c, k, lo, d_ids + lo, n, nullptr, d_pcm + (size_t)lo * 320,
                          d_packets + (size_t)lo * nbytes, num_bits / 4);
-    dec_side_done(c, k, nk);
+    if (!rc) rc = dec_side_done(c, k, nk);
   }
   c->n_dec_calls++;
   return rc;
+}
+
+// ---- ordering against a caller-owned stream (all library streams are non-blocking: they do NOT order
+//      against the null stream or any other stream by themselves) -----------------------------------------------
+int lyra_hip_wait_for_stream(lyra_hip_ctx* c, void* caller_stream) {
+  if (!c) return LYRA_HIP_EINVAL;
+  DEVSCOPE(c);
+  if (!c->ev_caller) HIPCHK(c, hipEventCreateWithFlags(&c->ev_caller, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_caller, (hipStream_t)caller_stream));
+  for (int k = 0; k < c->nsub; ++k) {
+    HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_caller, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_caller, 0));
+  }
+  return 0;
+}
+
+int lyra_hip_stream_wait(lyra_hip_ctx* c, void* caller_stream) {
+  if (!c) return LYRA_HIP_EINVAL;
+  DEVSCOPE(c);
+  if (!c->ev_caller) HIPCHK(c, hipEventCreateWithFlags(&c->ev_caller, hipEventDisableTiming));
+  for (int k = 0; k < c->nsub; ++k) {
+    // an event may be re-recorded once the wait that used it has been enqueued
+    HIPCHK(c, hipEventRecord(c->ev_caller, c->se[k]));
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)caller_stream, c->ev_caller, 0));
+    HIPCHK(c, hipEventRecord(c->ev_caller, c->sd[k]));
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)caller_stream, c->ev_caller, 0));
+  }
+  return 0;
+}
+
+int lyra_hip_set_serial(lyra_hip_ctx* c, int on) {
+  if (!c) return LYRA_HIP_EINVAL;
+  c->serial = on != 0;
+  return 0;
 }
 
 // ---- host-pointer variants (synchronous) --------------------------------------------------------------------
@@ -540,7 +649,7 @@ int lyra_hip_extract(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* 
   HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se[0]));
   if ((rc = launch_extract(c, 0, 0, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
   HIPCHK(c, hipMemcpyAsync(features, c->d_feat, (size_t)B * 256, hipMemcpyDeviceToHost, c->se[0]));
-  enc_side_done(c, 0);
+  if ((rc = enc_side_done(c, 0))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->se[0]));
   return 0;
 }
@@ -555,7 +664,7 @@ int lyra_hip_rvq_encode(lyra_hip_ctx* c, int B, const float* features, int num_b
   HIPCHK(c, hipMemcpyAsync(c->d_feat, features, (size_t)B * 256, hipMemcpyHostToDevice, c->se[0]));
   if ((rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, c->d_idx, nullptr))) return rc;
   HIPCHK(c, hipMemcpyAsync(indices, c->d_idx, (size_t)B * 46 * 4, hipMemcpyDeviceToHost, c->se[0]));
-  enc_side_done(c, 0);
+  if ((rc = enc_side_done(c, 0))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->se[0]));
   return 0;
 }
@@ -566,7 +675,7 @@ int lyra_hip_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* indices, float* f
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = ensure_scratch(c, B))) return rc;
-  dec_side_begin(c, 0);
+  if ((rc = dec_side_begin(c, 0))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_idx, indices, (size_t)B * 46 * 4, hipMemcpyHostToDevice, c->sd[0]));
   if ((rc = launch_rvq_decode(c, 0, B, c->d_idx, nullptr, 46, c->d_lossy))) return rc;
   HIPCHK(c, hipMemcpyAsync(features, c->d_lossy, (size_t)B * 256, hipMemcpyDeviceToHost, c->sd[0]));
@@ -578,7 +687,7 @@ int lyra_hip_generate(lyra_hip_ctx* c, const int32_t* ids, int B, const float* f
   PROLOGUE(c, B);
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  dec_side_begin(c, 0);
+  if ((rc = dec_side_begin(c, 0))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd[0]));
   HIPCHK(c, hipMemcpyAsync(c->d_lossy, features, (size_t)B * 256, hipMemcpyHostToDevice, c->sd[0]));
   if ((rc = launch_generate(c, 0, 0, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
@@ -591,7 +700,7 @@ int lyra_hip_logmel(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* p
   PROLOGUE(c, B);
   if (!pcm || !mel) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
-  dec_side_begin(c, 0);
+  if ((rc = dec_side_begin(c, 0))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd[0]));
   HIPCHK(c, hipMemcpyAsync(c->d_pcm_out, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->sd[0]));
   if ((rc = launch_logmel(c, c->d_ids_dec, B, c->d_pcm_out, c->d_mel))) return rc;
@@ -611,7 +720,7 @@ int lyra_hip_encode(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* p
   if ((rc = launch_extract(c, 0, 0, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
   if ((rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, nullptr, c->d_pkt))) return rc;
   HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->se[0]));
-  enc_side_done(c, 0);
+  if ((rc = enc_side_done(c, 0))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->se[0]));
   return 0;
 }
@@ -622,7 +731,7 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
   if (!pcm || !packets) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
   const int nbytes = (num_bits + 7) / 8;
-  dec_side_begin(c, 0);
+  if ((rc = dec_side_begin(c, 0))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd[0]));
   // decode-side packet staging reuses the idx scratch (the encode side owns d_pkt)
   uint8_t* d_pk = reinterpret_cast<uint8_t*>(c->d_idx);

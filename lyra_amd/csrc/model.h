@@ -3,6 +3,7 @@
 // over the flatbuffers, the coefficients are re-laid once at context creation for the hand-written kernels.
 #pragma once
 #include <cstdint>
+#include <initializer_list>
 #include <string>
 #include <vector>
 
@@ -16,16 +17,25 @@ class Pack {
   bool open(const std::string& path, std::string* err);
   bool adopt(std::vector<uint8_t>&& image, std::string* err);   // an in-memory LYRAPK01 image (tflite_pack.h)
   const PackEntry* find(const std::string& name) const;
-  template <class T>
-  const T* data(const std::string& name) const {
-    const PackEntry* e = find(name);
-    return e ? reinterpret_cast<const T*>(blob_.data() + e->offset) : nullptr;
+  // Payload of `name` iff it has exactly this dtype (0 f32, 1 i8, 2 i32) and shape; otherwise nullptr and the
+  // first such failure is remembered (ok() / missing()).  The kernels are specialised to fixed layer shapes, so a
+  // container with different ones is rejected here rather than over-read on the device.
+  const void* get(const std::string& name, uint32_t dtype, std::initializer_list<uint32_t> shape) const;
+  const float* f32(const std::string& name, std::initializer_list<uint32_t> shape) const {
+    return static_cast<const float*>(get(name, 0, shape));
+  }
+  const int8_t* i8(const std::string& name, std::initializer_list<uint32_t> shape) const {
+    return static_cast<const int8_t*>(get(name, 1, shape));
+  }
+  const int32_t* i32(const std::string& name, std::initializer_list<uint32_t> shape) const {
+    return static_cast<const int32_t*>(get(name, 2, shape));
   }
   bool ok() const { return missing_.empty(); }
   const std::string& missing() const { return missing_; }
 
  private:
   std::vector<uint8_t> blob_;
+  uint32_t n_ = 0;                 // validated entry count
   mutable std::string missing_;
 };
 

@@ -15,33 +15,68 @@ namespace lyra {
 bool Pack::open(const std::string& path, std::string* err) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { *err = "cannot open " + path; return false; }
-  fseek(f, 0, SEEK_END);
-  long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  blob_.resize((size_t)sz);
-  size_t got = fread(blob_.data(), 1, (size_t)sz, f);
-  fclose(f);
-  if (got != (size_t)sz || sz < 16 || memcmp(blob_.data(), "LYRAPK01", 8) != 0) {
+  long sz = -1;
+  if (fseek(f, 0, SEEK_END) == 0) sz = ftell(f);
+  if (sz < 16 || sz > (1l << 30) || fseek(f, 0, SEEK_SET) != 0) {   // a directory, a pipe, an empty or absurd file
+    fclose(f);
     *err = path + " is not a LYRAPK01 container";
     return false;
   }
-  return true;
+  std::vector<uint8_t> image((size_t)sz);
+  size_t got = fread(image.data(), 1, (size_t)sz, f);
+  fclose(f);
+  if (got != (size_t)sz) { *err = "short read on " + path; return false; }
+  return adopt(std::move(image), err);
 }
 
+// The container is untrusted input: every header field is checked against the image size before anything
+// dereferences it, so a truncated or corrupt file yields LYRA_HIP_EMODEL instead of an out-of-bounds read.
 bool Pack::adopt(std::vector<uint8_t>&& image, std::string* err) {
   blob_ = std::move(image);
+  n_ = 0;
   if (blob_.size() < 16 || memcmp(blob_.data(), "LYRAPK01", 8) != 0) { *err = "not a LYRAPK01 image"; return false; }
+  uint32_t n;
+  memcpy(&n, blob_.data() + 8, 4);
+  if (n > 65536 || 16 + (uint64_t)n * sizeof(PackEntry) > blob_.size()) { *err = "LYRAPK01: entry table exceeds the image"; return false; }
+  const PackEntry* e = reinterpret_cast<const PackEntry*>(blob_.data() + 16);
+  static const uint32_t kElem[3] = {4, 1, 4};
+  for (uint32_t i = 0; i < n; ++i) {
+    if (memchr(e[i].name, 0, sizeof e[i].name) == nullptr) { *err = "LYRAPK01: unterminated tensor name"; return false; }
+    if (e[i].dtype > 2 || e[i].ndim < 1 || e[i].ndim > 4) { *err = std::string("LYRAPK01: bad dtype/rank for ") + e[i].name; return false; }
+    uint64_t count = 1;
+    for (uint32_t d = 0; d < e[i].ndim; ++d) {
+      count *= e[i].shape[d];
+      if (count > (1ull << 31)) { *err = std::string("LYRAPK01: absurd shape for ") + e[i].name; return false; }
+    }
+    if (e[i].nbytes != count * kElem[e[i].dtype] || e[i].offset % 4 != 0 || e[i].offset > blob_.size() ||
+        e[i].nbytes > blob_.size() - e[i].offset) {
+      *err = std::string("LYRAPK01: payload of ") + e[i].name + " does not fit the image";
+      return false;
+    }
+  }
+  n_ = n;
   return true;
 }
 
 const PackEntry* Pack::find(const std::string& name) const {
-  uint32_t n;
-  memcpy(&n, blob_.data() + 8, 4);
   const PackEntry* e = reinterpret_cast<const PackEntry*>(blob_.data() + 16);
-  for (uint32_t i = 0; i < n; ++i)
+  for (uint32_t i = 0; i < n_; ++i)
     if (strncmp(e[i].name, name.c_str(), 56) == 0) return &e[i];
-  if (missing_.empty()) missing_ = name;
+  if (missing_.empty()) missing_ = "tensor " + name + " is missing";
   return nullptr;
+}
+
+const void* Pack::get(const std::string& name, uint32_t dtype, std::initializer_list<uint32_t> shape) const {
+  const PackEntry* e = find(name);
+  if (!e) return nullptr;
+  bool ok = e->dtype == dtype && e->ndim == shape.size();
+  uint32_t d = 0;
+  for (uint32_t want : shape) { ok = ok && e->shape[d] == want; ++d; }
+  if (!ok) {
+    if (missing_.empty()) missing_ = "tensor " + name + " has an unexpected dtype or shape";
+    return nullptr;
+  }
+  return blob_.data() + e->offset;
 }
 
 namespace {
@@ -109,6 +144,7 @@ struct Builder {
   const Pack& pk;
   Arena arena;
   std::vector<std::pair<void*, size_t>> fixups;  // (address of a device-pointer field, arena offset)
+  std::string stride_mismatch;                   // first transposed conv whose stride is not the kernels'
 
   template <class P, class T>
   void put(P* field, const std::vector<T>& v) {
@@ -125,12 +161,11 @@ struct Builder {
   }
 
   // ---- fp32 conv [cout][k][cig] -> B fragments [cout/16][K/16][64 lanes][4] --------------------
-  void conv_f(const char* pre, int idx, ConvF* out) {
-    const PackEntry* e = pk.find(key(pre, "conv", idx, "w"));
-    const float* w = pk.data<float>(key(pre, "conv", idx, "w"));
-    const float* b = pk.data<float>(key(pre, "conv", idx, "b"));
-    if (!e || !w || !b) return;
-    int cout = e->shape[0], k = e->shape[1], cig = e->shape[2];
+  // Every loader names the shape the kernels are specialised to; Pack::get refuses anything else.
+  void conv_f(const char* pre, int idx, ConvF* out, uint32_t cout, uint32_t k, uint32_t cig) {
+    const float* w = pk.f32(key(pre, "conv", idx, "w"), {cout, k, cig});
+    const float* b = pk.f32(key(pre, "conv", idx, "b"), {cout});
+    if (!w || !b) return;
     int K = k * cig, KC = K / 16, NT = cout / 16;
     std::vector<float> frag((size_t)NT * KC * 64 * 4);
     for (int nt = 0; nt < NT; ++nt)
@@ -148,13 +183,12 @@ struct Builder {
 
   // ---- fp32 transposed conv [cout][k][cin], stride s -> polyphase B fragments ---------------------
   //   K = (k/s)*cin with the OLDEST input block first, N = s*cout (n = phase*cout + co)
-  void tconv_f(const char* pre, int idx, ConvF* out, int* cout_out) {
-    const PackEntry* e = pk.find(key(pre, "tconv", idx, "w"));
-    const float* w = pk.data<float>(key(pre, "tconv", idx, "w"));
-    const float* b = pk.data<float>(key(pre, "tconv", idx, "b"));
-    const int32_t* opt = pk.data<int32_t>(key(pre, "tconv", idx, "opt"));
-    if (!e || !w || !b || !opt) return;
-    int cout = e->shape[0], k = e->shape[1], cin = e->shape[2], s = opt[0];
+  void tconv_f(const char* pre, int idx, ConvF* out, uint32_t cout, uint32_t k, uint32_t cin, int s) {
+    const float* w = pk.f32(key(pre, "tconv", idx, "w"), {cout, k, cin});
+    const float* b = pk.f32(key(pre, "tconv", idx, "b"), {cout});
+    const int32_t* opt = pk.i32(key(pre, "tconv", idx, "opt"), {4});
+    if (!w || !b || !opt) return;
+    if (opt[0] != s) { stride_mismatch = key(pre, "tconv", idx, "opt"); return; }
     int taps = k / s, K = taps * cin, KC = K / 16, N = s * cout, NT = N / 16;
     std::vector<float> frag((size_t)NT * KC * 64 * 4);
     for (int nt = 0; nt < NT; ++nt)
@@ -170,33 +204,29 @@ struct Builder {
           }
     put(&out->w, frag);
     put(&out->b, std::vector<float>(b, b + cout));
-    if (cout_out) *cout_out = cout;
   }
 
   // ---- fp32 depthwise [k][C] -> AT16 channel order -------------------------------------------------
-  void dw_f(const char* pre, int idx, DwF* out) {
-    const PackEntry* e = pk.find(key(pre, "dw", idx, "w"));
-    const float* w = pk.data<float>(key(pre, "dw", idx, "w"));
-    const float* b = pk.data<float>(key(pre, "dw", idx, "b"));
-    if (!e || !w || !b) return;
-    int k = e->shape[0], C = e->shape[1];
+  void dw_f(const char* pre, int idx, DwF* out, uint32_t C) {
+    const uint32_t k = 3;
+    const float* w = pk.f32(key(pre, "dw", idx, "w"), {k, C});
+    const float* b = pk.f32(key(pre, "dw", idx, "b"), {C});
+    if (!w || !b) return;
     std::vector<float> wp((size_t)k * C), bp(C);
-    for (int j = 0; j < k; ++j)
-      for (int c = 0; c < C; ++c) wp[(size_t)j * C + at16(c)] = w[(size_t)j * C + c];
-    for (int c = 0; c < C; ++c) bp[at16(c)] = b[c];
+    for (int j = 0; j < (int)k; ++j)
+      for (int c = 0; c < (int)C; ++c) wp[(size_t)j * C + at16(c)] = w[(size_t)j * C + c];
+    for (int c = 0; c < (int)C; ++c) bp[at16(c)] = b[c];
     put(&out->w, wp);
     put(&out->b, bp);
   }
 
   // ---- int8 conv [cout][k][cig] -> B fragments [cout/16][K/64][64 lanes][16 bytes] ----------------
-  void conv_q(const char* pre, int idx, ConvQ* out) {
-    const PackEntry* e = pk.find(key(pre, "conv", idx, "w"));
-    const int8_t* w = pk.data<int8_t>(key(pre, "conv", idx, "w"));
-    const int32_t* b = pk.data<int32_t>(key(pre, "conv", idx, "b"));
-    const float* q = pk.data<float>(key(pre, "conv", idx, "q"));
-    const float* ws = pk.data<float>(key(pre, "conv", idx, "wscale"));
-    if (!e || !w || !b || !q || !ws) return;
-    int cout = e->shape[0], k = e->shape[1], cig = e->shape[2];
+  void conv_q(const char* pre, int idx, ConvQ* out, uint32_t cout, uint32_t k, uint32_t cig) {
+    const int8_t* w = pk.i8(key(pre, "conv", idx, "w"), {cout, k, cig});
+    const int32_t* b = pk.i32(key(pre, "conv", idx, "b"), {cout});
+    const float* q = pk.f32(key(pre, "conv", idx, "q"), {4});
+    const float* ws = pk.f32(key(pre, "conv", idx, "wscale"), {cout});
+    if (!w || !b || !q || !ws) return;
     int K = k * cig, KC = K / 64, NT = cout / 16;
     int zin = (int)q[1];
     std::vector<int8_t> frag((size_t)NT * KC * 64 * 16);
@@ -209,7 +239,7 @@ struct Builder {
             frag[(((size_t)nt * KC + c) * 64 + lane) * 16 + j] = w[(size_t)n * K + kidx];
           }
     std::vector<int32_t> bf(cout), M(cout), sh(cout);
-    for (int n = 0; n < cout; ++n) {
+    for (int n = 0; n < (int)cout; ++n) {
       long long sum = 0;
       for (int kk = 0; kk < K; ++kk) sum += w[(size_t)n * K + kk];
       bf[n] = (int32_t)(b[n] - (long long)zin * sum);
@@ -225,20 +255,19 @@ struct Builder {
 
   // ---- int8 depthwise [k][C] --------------------------------------------------------------------------
   void dw_q(const char* pre, int idx, DwQ* out) {
-    const PackEntry* e = pk.find(key(pre, "dw", idx, "w"));
-    const int8_t* w = pk.data<int8_t>(key(pre, "dw", idx, "w"));
-    const int32_t* b = pk.data<int32_t>(key(pre, "dw", idx, "b"));
-    const float* q = pk.data<float>(key(pre, "dw", idx, "q"));
-    const float* ws = pk.data<float>(key(pre, "dw", idx, "wscale"));
-    if (!e || !w || !b || !q || !ws) return;
-    int k = e->shape[0], C = e->shape[1];
+    const uint32_t k = 3, C = 256;
+    const int8_t* w = pk.i8(key(pre, "dw", idx, "w"), {k, C});
+    const int32_t* b = pk.i32(key(pre, "dw", idx, "b"), {C});
+    const float* q = pk.f32(key(pre, "dw", idx, "q"), {4});
+    const float* ws = pk.f32(key(pre, "dw", idx, "wscale"), {C});
+    if (!w || !b || !q || !ws) return;
     const int zin = (int)q[1];
     std::vector<int32_t> M(C), sh(C), bf(C);
-    for (int c = 0; c < C; ++c) {
+    for (int c = 0; c < (int)C; ++c) {
       QM m = quantize_multiplier((double)q[0] * (double)ws[c] / (double)q[2]);
       M[c] = m.m; sh[c] = m.shift;
       long long sum = 0;
-      for (int j = 0; j < k; ++j) sum += w[(size_t)j * C + c];
+      for (int j = 0; j < (int)k; ++j) sum += w[(size_t)j * C + c];
       bf[c] = (int32_t)(b[c] - (long long)zin * sum);  // the kernel accumulates raw codes
     }
     put(&out->w, std::vector<int8_t>(w, w + (size_t)k * C));
@@ -251,14 +280,15 @@ struct Builder {
 
   // ---- int8 transposed conv [64][4][128] -> GEMM fragments, N tiles ordered [co tile][tap] ----------------
   void tconv_q(const char* pre, int idx, TconvQ* out, QP* dq, const float** sub, int sub_idx) {
-    const PackEntry* e = pk.find(key(pre, "tconv", idx, "w"));
-    const int8_t* w = pk.data<int8_t>(key(pre, "tconv", idx, "w"));
-    const int32_t* b = pk.data<int32_t>(key(pre, "tconv", idx, "b"));
-    const float* q = pk.data<float>(key(pre, "tconv", idx, "q"));
-    const float* ws = pk.data<float>(key(pre, "tconv", idx, "wscale"));
-    const float* sc = pk.data<float>(key(pre, "sub", sub_idx, "c"));
-    if (!e || !w || !b || !q || !ws || !sc) return;
-    int cout = e->shape[0], k = e->shape[1], cin = e->shape[2];  // 64, 4, 128
+    const int cout = 64, k = 4, cin = 128;
+    const int8_t* w = pk.i8(key(pre, "tconv", idx, "w"), {64, 4, 128});
+    const int32_t* b = pk.i32(key(pre, "tconv", idx, "b"), {64});
+    const float* q = pk.f32(key(pre, "tconv", idx, "q"), {4});
+    const float* ws = pk.f32(key(pre, "tconv", idx, "wscale"), {1});
+    const float* sc = pk.f32(key(pre, "sub", sub_idx, "c"), {64});
+    const int32_t* opt = pk.i32(key(pre, "tconv", idx, "opt"), {4});
+    if (!w || !b || !q || !ws || !sc || !opt) return;
+    if (opt[0] != 2) { stride_mismatch = key(pre, "tconv", idx, "opt"); return; }
     int KC = cin / 64, NT = (cout / 16) * k;
     int zin = (int)q[1];
     std::vector<int8_t> frag((size_t)NT * KC * 64 * 16);
@@ -289,7 +319,7 @@ struct Builder {
   }
 
   void lrelu_q(const char* pre, int idx, LreluQ* out) {
-    const float* q = pk.data<float>(key(pre, "lrelu8", idx, "q"));
+    const float* q = pk.f32(key(pre, "lrelu8", idx, "q"), {4});
     if (!q) return;
     QM p = quantize_multiplier((double)q[0] / (double)q[2]);
     QM n = quantize_multiplier((double)q[0] * (double)LYRA_LRELU_ALPHA / (double)q[2]);
@@ -297,7 +327,7 @@ struct Builder {
     out->mpos = p.m; out->spos = p.shift; out->mneg = n.m; out->sneg = n.shift;
   }
   void add_q(const char* pre, int idx, AddQ* out) {
-    const float* q = pk.data<float>(key(pre, "add8", idx, "q"));
+    const float* q = pk.f32(key(pre, "add8", idx, "q"), {6});
     if (!q) return;
     double s1 = q[0], s2 = q[2], so = q[4];
     double twice = 2.0 * (s1 > s2 ? s1 : s2);
@@ -328,7 +358,7 @@ struct Builder {
     put(out, lut);
   }
   QP qp(const char* pre, const char* kind, int idx) {
-    const float* q = pk.data<float>(key(pre, kind, idx, "q"));
+    const float* q = pk.f32(key(pre, kind, idx, "q"), {2});
     QP r{1.f, 0};
     if (q) { r.s = q[0]; r.z = (int)q[1]; }
     return r;
@@ -340,72 +370,72 @@ double hz_to_mel(double f) { return 1127.0 * std::log1p(f / 700.0); }
 }  // namespace
 
 bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
-  const int32_t* ver = pk.data<int32_t>("meta.version");
+  const int32_t* ver = pk.i32("meta.version", {1});
   if (!ver || ver[0] != 3) { *err = "weight container version identifier is not 3 (lyra_config.h:145-166)"; return false; }
   Builder B{pk};
   // Each kernel's weights are packed contiguously so that the kernel can warm its XCD's L2 / TLBs with one
   // pass over [warm.base, warm.base + warm.bytes) (l2_warm in lyra_dev.h).
   // ---- encoder (op numbering: tools/pack_weights.py) ----------------------------------
   size_t mark = B.mark();
-  B.conv_f("enc", 0, &M->enc0.first);
+  B.conv_f("enc", 0, &M->enc0.first, 64, 64, 1);
   for (int r = 0; r < 3; ++r) {
-    B.dw_f("enc", r, &M->enc0.dw[r]);
-    B.conv_f("enc", 1 + 2 * r, &M->enc0.pw[r]);
-    B.conv_f("enc", 2 + 2 * r, &M->enc0.cv[r]);
+    B.dw_f("enc", r, &M->enc0.dw[r], 64);
+    B.conv_f("enc", 1 + 2 * r, &M->enc0.pw[r], 64, 1, 64);
+    B.conv_f("enc", 2 + 2 * r, &M->enc0.cv[r], 64, 1, 64);
   }
-  B.conv_f("enc", 7, &M->enc0.down);
+  B.conv_f("enc", 7, &M->enc0.down, 128, 10, 64);
   const size_t p_enc0 = B.arena.reserve(sizeof(EncS0P));   // the kernel's parameter block rides in its warm range
   B.range(&M->enc0.warm, mark);
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
-    B.dw_f("enc", 3 + r, &M->enc1.dw[r]);
-    B.conv_f("enc", 8 + 2 * r, &M->enc1.pw[r]);
-    B.conv_f("enc", 9 + 2 * r, &M->enc1.cv[r]);
+    B.dw_f("enc", 3 + r, &M->enc1.dw[r], 128);
+    B.conv_f("enc", 8 + 2 * r, &M->enc1.pw[r], 128, 1, 128);
+    B.conv_f("enc", 9 + 2 * r, &M->enc1.cv[r], 128, 1, 64);
   }
-  B.conv_f("enc", 14, &M->enc1.down);
+  B.conv_f("enc", 14, &M->enc1.down, 256, 4, 64);
   const size_t p_enc1 = B.arena.reserve(sizeof(EncS1P));
   B.range(&M->enc1.warm, mark);
   mark = B.mark();
   EncS2P& E2 = M->enc2;
-  B.dw_f("enc", 6, &E2.dw0);
-  B.conv_f("enc", 15, &E2.pw0);
+  B.dw_f("enc", 6, &E2.dw0, 256);
+  B.conv_f("enc", 15, &E2.pw0, 256, 1, 256);
   E2.q_r0 = B.qp("enc", "quant", 0);
   E2.dq_r0 = B.qp("enc", "dequant", 0);
   E2.q_x1 = B.qp("enc", "quant", 1);
   E2.out = B.qp("enc", "dequant", 9);
   for (int i = 0; i < 7; ++i) B.lrelu_q("enc", i, &E2.lr[i]);
   B.lrelu_luts(E2.lr, 7, &E2.lr_lut);
-  B.conv_q("enc", 16, &E2.r0b);
+  B.conv_q("enc", 16, &E2.r0b, 256, 1, 64);
   for (int r = 0; r < 2; ++r) {
     B.dw_q("enc", 7 + r, &E2.dwq[r]);
-    B.conv_q("enc", 17 + 2 * r, &E2.pwq[r]);
-    B.conv_q("enc", 18 + 2 * r, &E2.cvq[r]);
+    B.conv_q("enc", 17 + 2 * r, &E2.pwq[r], 256, 1, 256);
+    B.conv_q("enc", 18 + 2 * r, &E2.cvq[r], 256, 1, 64);
     B.add_q("enc", r, &E2.add[r]);
   }
   B.add_luts(E2.add, 2, &E2.add_lut);
-  B.conv_q("enc", 21, &E2.down2);
-  B.conv_q("enc", 22, &E2.bott);
+  B.conv_q("enc", 21, &E2.down2, 512, 4, 64);
+  B.conv_q("enc", 22, &E2.bott, 64, 3, 128);
   E2.mode = requant_mode;
   const size_t p_enc2 = B.arena.reserve(sizeof(EncS2P));
   B.range(&E2.warm, mark);
   // ---- decoder -----------------------------------------------------------------------------
   mark = B.mark();
   DecS0P& D0 = M->dec0;
-  B.conv_f("dec", 0, &D0.head);
+  B.conv_f("dec", 0, &D0.head, 512, 3, 16);
   D0.q0 = B.qp("dec", "quant", 0);
   for (int g = 0; g < 4; ++g) B.tconv_q("dec", g, &D0.up0[g], &D0.up0_dq[g], &D0.up0_sub[g], g);
   D0.q1 = B.qp("dec", "quant", 1);
   for (int r = 0; r < 3; ++r) {
     B.dw_q("dec", r, &D0.dwq[r]);
-    B.conv_q("dec", 1 + 2 * r, &D0.pwq[r]);
-    B.conv_q("dec", 2 + 2 * r, &D0.cvq[r]);
+    B.conv_q("dec", 1 + 2 * r, &D0.pwq[r], 256, 1, 256);
+    B.conv_q("dec", 2 + 2 * r, &D0.cvq[r], 256, 1, 64);
   }
   for (int i = 0; i < 6; ++i) B.lrelu_q("dec", i, &D0.lr[i]);
   for (int i = 0; i < 2; ++i) B.add_q("dec", i, &D0.add[i]);
   B.lrelu_luts(D0.lr, 6, &D0.lr_lut);
   B.add_luts(D0.add, 2, &D0.add_lut);
   {
-    const float* q = pk.data<float>("dec.conv.2.q");  // output quantisation of resblock-0's grouped conv
+    const float* q = pk.f32("dec.conv.2.q", {4});  // output quantisation of resblock-0's grouped conv
     if (q) { D0.dq_r0.s = q[2]; D0.dq_r0.z = (int)q[3]; }
   }
   D0.q3 = B.qp("dec", "quant", 3);
@@ -415,33 +445,33 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   B.range(&D0.warm, mark);
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
-    B.dw_f("dec", 3 + r, &M->dec1.dw[r]);
-    B.conv_f("dec", 7 + 2 * r, &M->dec1.pw[r]);
-    B.conv_f("dec", 8 + 2 * r, &M->dec1.cv[r]);
+    B.dw_f("dec", 3 + r, &M->dec1.dw[r], 128);
+    B.conv_f("dec", 7 + 2 * r, &M->dec1.pw[r], 128, 1, 128);
+    B.conv_f("dec", 8 + 2 * r, &M->dec1.cv[r], 128, 1, 64);
   }
-  B.tconv_f("dec", 6, &M->dec1.up, nullptr);
+  B.tconv_f("dec", 6, &M->dec1.up, 64, 10, 128, 5);
   {
-    const float* sc = pk.data<float>("dec.sub.6.c");
+    const float* sc = pk.f32("dec.sub.6.c", {64});
     if (sc) B.put(&M->dec1.up_sub, std::vector<float>(sc, sc + 64));
   }
   const size_t p_dec1 = B.arena.reserve(sizeof(DecS1P));
   B.range(&M->dec1.warm, mark);
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
-    B.dw_f("dec", 6 + r, &M->dec2.dw[r]);
-    B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r]);
-    B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r]);
+    B.dw_f("dec", 6 + r, &M->dec2.dw[r], 64);
+    B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r], 64, 1, 64);
+    B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r], 64, 1, 64);
   }
-  B.tconv_f("dec", 7, &M->dec2.up, nullptr);
+  B.tconv_f("dec", 7, &M->dec2.up, 1, 64, 64, 16);
   {
-    const float* sc = pk.data<float>("dec.sub.7.c");
+    const float* sc = pk.f32("dec.sub.7.c", {1});
     if (sc) M->dec2.up_sub = sc[0];
   }
   const size_t p_dec2 = B.arena.reserve(sizeof(DecS2P));
   B.range(&M->dec2.warm, mark);
   // ---- RVQ codebooks -------------------------------------------------------------------------------------
   {
-    const float* cb = pk.data<float>("rvq.codebooks");
+    const float* cb = pk.f32("rvq.codebooks", {46, 16, 64});
     if (cb) {
       std::vector<float> nat(cb, cb + 46 * 16 * 64), tr((size_t)46 * 64 * 16);
       for (int k = 0; k < 46; ++k)
@@ -505,7 +535,23 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   M->reset.d_r0_1 = (int8_t)D0.dwq[1].zin;
   M->reset.d_r0_2 = (int8_t)D0.dwq[2].zin;
 
-  if (!pk.ok()) { *err = "weight container lacks tensor " + pk.missing(); return false; }
+  {  // strides / dilations the kernels hard-code (opt = stride, dilation, groups, kernel)
+    struct Opt { const char* name; int stride, dil; };
+    static const Opt kOpts[] = {
+        {"enc.conv.0.opt", 16, 1}, {"enc.conv.7.opt", 5, 1}, {"enc.conv.14.opt", 2, 1}, {"enc.conv.21.opt", 2, 1},
+        {"enc.conv.22.opt", 1, 1}, {"dec.conv.0.opt", 1, 1},
+        {"enc.dw.0.opt", 1, 1}, {"enc.dw.1.opt", 1, 3}, {"enc.dw.2.opt", 1, 9}, {"enc.dw.3.opt", 1, 1},
+        {"enc.dw.4.opt", 1, 3}, {"enc.dw.5.opt", 1, 9}, {"enc.dw.6.opt", 1, 1}, {"enc.dw.7.opt", 1, 3},
+        {"enc.dw.8.opt", 1, 9}, {"dec.dw.0.opt", 1, 1}, {"dec.dw.1.opt", 1, 3}, {"dec.dw.2.opt", 1, 9},
+        {"dec.dw.3.opt", 1, 1}, {"dec.dw.4.opt", 1, 3}, {"dec.dw.5.opt", 1, 9}, {"dec.dw.6.opt", 1, 1},
+        {"dec.dw.7.opt", 1, 3}, {"dec.dw.8.opt", 1, 9}};
+    for (const Opt& o : kOpts) {
+      const int32_t* v = pk.i32(o.name, {4});
+      if (v && (v[0] != o.stride || v[1] != o.dil) && B.stride_mismatch.empty()) B.stride_mismatch = o.name;
+    }
+  }
+  if (!pk.ok()) { *err = "weight container: " + pk.missing(); return false; }
+  if (!B.stride_mismatch.empty()) { *err = "weight container: unexpected stride in " + B.stride_mismatch; return false; }
 
   const std::vector<uint8_t>& bytes = B.arena.bytes();
   if (hipMalloc((void**)&M->d_arena, bytes.size()) != hipSuccess) { *err = "hipMalloc(weights) failed"; return false; }

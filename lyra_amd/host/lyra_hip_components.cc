@@ -34,17 +34,31 @@ class SharedContext {
       for (int i = max_streams - 1; i >= 0; --i) free_.push_back(i);
     }
     if (free_.empty()) { LOG(ERROR) << "No free stream slot (SetMaxStreams)."; return nullptr; }
-    *stream_id = free_.back();
+    const int32_t id = free_.back();
+    {
+      // The C ABI wants every call on a context serialised, and the reset touches the same staging buffers
+      // and id-stamp table as Extract / Generate running on other threads' objects: take the call mutex.
+      std::lock_guard<std::mutex> lc(call_mu_);
+      if (lyra_hip_reset_streams(ctx_, &id, 1) != 0) {
+        LOG(ERROR) << "lyra_hip_reset_streams failed: " << lyra_hip_last_error(ctx_);
+        if (users_ == 0) { lyra_hip_destroy(ctx_); ctx_ = nullptr; free_.clear(); }
+        return nullptr;   // the slot stays on the free list
+      }
+    }
     free_.pop_back();
     ++users_;
-    int32_t id = *stream_id;
-    lyra_hip_reset_streams(ctx_, &id, 1);
+    *stream_id = id;
     return ctx_;
   }
   void Release(int stream_id) {
     std::lock_guard<std::mutex> l(mu_);
     free_.push_back(stream_id);
-    if (--users_ == 0) { lyra_hip_destroy(ctx_); ctx_ = nullptr; free_.clear(); }
+    if (--users_ == 0) {
+      std::lock_guard<std::mutex> lc(call_mu_);   // no call of another thread may still be inside the context
+      lyra_hip_destroy(ctx_);
+      ctx_ = nullptr;
+      free_.clear();
+    }
   }
   std::mutex& call_mutex() { return call_mu_; }  // the C ABI wants calls on one context serialised
 
