@@ -41,7 +41,9 @@ struct lyra_hip_ctx {
   bool serial = false;             // lyra_hip_set_serial: encode side also waits for the latest decode-side call
   hipEvent_t ev_caller = nullptr;  // scratch event for lyra_hip_wait_for_stream / lyra_hip_stream_wait
   Model model;
-  uint8_t* d_state = nullptr;
+  uint8_t* d_state = nullptr;       // one allocation, carved into per-kernel regions (state_layout.h)
+  StateMap sm = {};
+  int cw[16] = {};                  // code_warm_bytes per kernel id
   // scratch, sized for `cap` frames
   int cap = 0;
   int32_t* d_ids = nullptr;      // encode-side staging of host ids
@@ -165,6 +167,21 @@ int check_ids_host(lyra_hip_ctx* c, const int32_t* ids, int B) {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// machine-code size of each kernel (generated at build time by code_sizes.sh from the kernel objects)
+struct CodeSize { const char* name; int bytes; };
+const CodeSize kCodeSizes[] = {
+#include "code_sizes.inc"
+    {"", 0}};
+// what a kernel is told to warm: its size minus a margin (s_getpc at the first statement is not byte 0 of the function,
+// and the range must not run past the end of the code object); disabled with LYRA_HIP_NO_CODE_WARM=1
+int code_warm_bytes(const char* kernel) {
+  static const bool off = getenv("LYRA_HIP_NO_CODE_WARM") != nullptr;
+  if (off) return 0;
+  for (const CodeSize& c : kCodeSizes)
+    if (strcmp(c.name, kernel) == 0) return c.bytes > 2048 ? c.bytes - 1024 : 0;
+  return 0;
+}
+
 enum { K_ENC_S0, K_ENC_S1, K_ENC_S2, K_RVQ_ENC, K_RVQ_DEC, K_DEC_S0, K_DEC_S1, K_DEC_S2, K_LOGMEL, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"enc_s0_kernel", "enc_s1_kernel", "enc_s2_kernel", "rvq_encode_kernel",
                                            "rvq_decode_kernel", "dec_s0_kernel", "dec_s1_kernel", "dec_s2_kernel",
@@ -256,13 +273,13 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   float* codes = c->d_codes + (size_t)lo * 64;
   { ProfScope ps(c, K_ENC_S0, st_);
     hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), st_,
-                       M.d_enc0, d_pcm, d_ids, B, c->d_state, e0); }
+                       M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0]); }
   { ProfScope ps(c, K_ENC_S1, st_);
     hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes(), st_,
-                       M.d_enc1, e0, d_ids, B, c->d_state, e1); }
+                       M.d_enc1, e0, d_ids, B, c->sm.base[st::R_E1], e1, c->cw[K_ENC_S1]); }
   { ProfScope ps(c, K_ENC_S2, st_);
     hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), st_,
-                       M.d_enc2, e1, d_ids, B, c->d_state, d_feat, codes); }
+                       M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes, c->cw[K_ENC_S2]); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
   return 0;
@@ -295,13 +312,14 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
   float* d1 = c->d_d1 + (size_t)lo * 1280;
   { ProfScope ps(c, K_DEC_S0, st_);
     hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), st_,
-                       M.d_dec0, d_feat, d_ids, B, c->d_state, d0, d_pkt, num_stages, M.cb); }
+                       M.d_dec0, d_feat, d_ids, B, c->sm.base[st::R_D0], d0, d_pkt, num_stages, M.cb,
+                       c->cw[K_DEC_S0]); }
   { ProfScope ps(c, K_DEC_S1, st_);
     hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(dec_s1_threads()), dec_s1_lds_bytes(), st_,
-                       M.d_dec1, d0, d_ids, B, c->d_state, d1); }
+                       M.d_dec1, d0, d_ids, B, c->sm.base[st::R_D1], d1, c->cw[K_DEC_S1]); }
   { ProfScope ps(c, K_DEC_S2, st_);
     hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), st_,
-                       M.d_dec2, d1, d_ids, B, c->d_state, d_pcm); }
+                       M.d_dec2, d1, d_ids, B, c->sm.base[st::R_D2], d_pcm, c->cw[K_DEC_S2]); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
   return 0;
@@ -310,7 +328,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
 int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
   { ProfScope ps(c, K_LOGMEL, c->sd[0]);
     hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, d_pcm, d_ids, B,
-                       c->d_state, d_mel); }
+                       c->sm.base[st::R_MEL], d_mel); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -409,11 +427,20 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
+  {
+    size_t off = 0;
+    for (int r = 0; r < st::R_COUNT; ++r) {   // region sizes are multiples of 256 bytes: every base stays aligned
+      c->sm.base[r] = c->d_state + off;
+      c->sm.bytes[r] = st::REGION_BYTES[r];
+      off += (size_t)max_streams * st::REGION_BYTES[r];
+    }
+  }
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
       set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
+  for (int i = 0; i < K_COUNT; ++i) c->cw[i] = code_warm_bytes(kKernelNames[i]);
   for (int k = 0; k < c->nsub; ++k)
     if (enc_side_done(c, k) != 0) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
   *out = c;
@@ -465,7 +492,7 @@ int lyra_hip_reset_streams(lyra_hip_ctx* c, const int32_t* ids, int n) {
   if (rc) return rc;
   if (!ids) {
     hipLaunchKernelGGL(reset_kernel, dim3(c->max_streams), dim3(256), 0, c->se[0], c->model.d_reset,
-                       (const int32_t*)nullptr, c->max_streams, 1, c->d_state);
+                       (const int32_t*)nullptr, c->max_streams, 1, c->sm);
     HIPCHK(c, hipGetLastError());
     return sync_all(c);
   }
@@ -474,7 +501,7 @@ int lyra_hip_reset_streams(lyra_hip_ctx* c, const int32_t* ids, int n) {
   if ((rc = ensure_scratch(c, n))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->se[0]));
   hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, c->se[0], c->model.d_reset, (const int32_t*)c->d_ids, n, 0,
-                     c->d_state);
+                     c->sm);
   HIPCHK(c, hipGetLastError());
   return sync_all(c);
 }

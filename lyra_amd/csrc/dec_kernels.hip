@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
                                                        const int32_t* __restrict__ ids, int B,
                                                        uint8_t* __restrict__ state, float* __restrict__ out0,
                                                        const uint8_t* __restrict__ packets, int num_stages,
-                                                       const float* __restrict__ cb) {
+                                                       const float* __restrict__ cb, int code_bytes) {
   const DecS0P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* FB = smem;                                   // [3][16][72]: two history rows + new features (rows s < S used)
@@ -83,13 +83,14 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   if (tid < SD0) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::D0_BYTES + st::PHASE);
   }
   load_luts<NTD0>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NTD0, 1>(P.warm);
+  const auto warm_code = code_warm<NTD0>(code_bytes);
   const auto warm_cb = l2_warm<NTD0, 1>(feats ? WarmRange{nullptr, 0} : WarmRange{reinterpret_cast<const uint8_t*>(cb), 46 * 16 * 64 * 4});
   __syncthreads();
-  TileCtx cx{state, sids, sphase, B - b0};
+  TileCtx cx{state, sids, sphase, B - b0, st::D0_BYTES};
 
   // ---- feature window [f-2, f-1, f] (history ring R=2, T=1); GEMM rows = streams, 16-row tile ----------
   {
@@ -334,8 +335,13 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   LYRA_TSTAMP(48);
   LYRA_WSTAMP(101);
   LYRA_WG_END();
+  if (tid < SD0 && cx.valid(tid)) {   // this region's ring phase
+    int ph = sphase[tid] + 1;
+    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+  }
   l2_warm_sink(warm_cb, state, B);
   l2_warm_sink(warm, state, B);
+  l2_warm_sink(warm_code, state, B);
 }
 
 // =============================================================================================
@@ -414,7 +420,8 @@ int dec_s1_threads() { return NTD1; }
 
 __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
                                                           const int32_t* __restrict__ ids, int B,
-                                                          uint8_t* __restrict__ state, float* __restrict__ out1) {
+                                                          uint8_t* __restrict__ state, float* __restrict__ out1,
+                                                          int code_bytes) {
   const DecS1P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [4][S][136]: X[t]
@@ -427,11 +434,12 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
   if (tid < SD1) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::D1_BYTES + st::PHASE);
   }
   const auto warm = l2_warm<NTD1, 2>(P.warm);
+  const auto warm_code = code_warm<NTD1>(code_bytes);
   __syncthreads();
-  TileCtx cx{state, sids, sphase, B - b0};
+  TileCtx cx{state, sids, sphase, B - b0, st::D1_BYTES};
   const auto H0 = hist128_prefetch<SD1, NTD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
@@ -456,7 +464,12 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
   if (NTD1 == 256) dec_s1_tconv<5>(XB, SB, P, cx, b0, out1, wave * 5);
   else if (wave < 4) dec_s1_tconv<3>(XB, SB, P, cx, b0, out1, wave * 3);
   else dec_s1_tconv<2>(XB, SB, P, cx, b0, out1, 12 + (wave - 4) * 2);
+  if (tid < SD1 && cx.valid(tid)) {   // this region's ring phase
+    int ph = sphase[tid] + 1;
+    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+  }
   l2_warm_sink(warm, state, B);
+  l2_warm_sink(warm_code, state, B);
 }
 
 // =============================================================================================
@@ -473,24 +486,21 @@ int dec_s2_streams_per_wg() { return SD2; }
 
 __global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                           const int32_t* __restrict__ ids, int B,
-                                                          uint8_t* __restrict__ state, int16_t* __restrict__ pcm) {
+                                                          uint8_t* __restrict__ state, int16_t* __restrict__ pcm,
+                                                          int code_bytes) {
   const DecS2P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [27][S][72]: rows 0-2 zeros, rows 3-22 activations, rows 23-26 zeros
   float* SB = XB + 27 * SD2 * CS0;      // old overlap tail [S][48]
   int* sids = reinterpret_cast<int*>(SB + SD2 * 48);
-  int* sphase = sids + SD2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * SD2;
-  if (tid < SD2) {
-    int id = ids[min(b0 + tid, B - 1)];
-    sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::DEC_PHASE);
-  }
+  if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NTD2, 1>(P.warm);
+  const auto warm_code = code_warm<NTD2>(code_bytes);
   __syncthreads();
-  TileCtx cx{state, sids, sphase, B - b0};
+  TileCtx cx{state, sids, nullptr, B - b0, st::D2_BYTES};   // T = 20 >= every 2*dilation: no ring, no phase
   const int wn = wave & 3, wm = wave >> 2;
   const int pcol = at16(wn * 16 + (lane & 15));
   f32x4 xr[5][1];  // residual stream in registers (MFMA C layout)
@@ -550,11 +560,8 @@ __global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restric
         }
       }
   }
-  if (tid < SD2 && cx.valid(tid)) {
-    int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(cx.sbase(tid) + st::DEC_PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
-  }
   l2_warm_sink(warm, state, B);
+  l2_warm_sink(warm_code, state, B);
 }
 
 }  // namespace lyra

@@ -38,7 +38,8 @@ int enc_s0_streams_per_wg() { return S0; }
 
 __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                          const int32_t* __restrict__ ids, int B,
-                                                         uint8_t* __restrict__ state, float* __restrict__ out0) {
+                                                         uint8_t* __restrict__ state, float* __restrict__ out0,
+                                                         int code_bytes) {
   const EncS0P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [25][S0][CS0]: rows 0-4 strided-conv history, rows 5-24 the one
@@ -52,8 +53,9 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   LYRA_TSTAMP(0);
   if (tid < S0) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NT0, 1>(P.warm);
+  const auto warm_code = code_warm<NT0>(code_bytes);
   __syncthreads();
-  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::BYTES; };
+  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::E0_BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B; };
 
   // The 5 history rows of the strided conv (needed only in phase D/E) are requested together with the PCM so
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   LYRA_TSTAMP(2);
 
   // ---- C. three residual blocks, dilation 1 / 3 / 9 --------------------------------------------
-  TileCtx cx{state, sids, nullptr, B - b0};
+  TileCtx cx{state, sids, nullptr, B - b0, st::E0_BYTES};
   resblocks64r<S0, NT0>(xr, XB + 5 * S0 * CS0, cx, P.dw, P.pw, P.cv, st::E_R0_0, st::E_R0_1, st::E_R0_2);
   LYRA_TSTAMP(3);
 
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   LYRA_WG_END();
   LYRA_TSTAMP(6);
   l2_warm_sink(warm, state, B);
+  l2_warm_sink(warm_code, state, B);
 }
 
 // =============================================================================================
@@ -191,7 +194,8 @@ int enc_s1_threads() { return NT1; }
 
 __global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const EncS1P* __restrict__ Pp, const float* __restrict__ in0,
                                                          const int32_t* __restrict__ ids, int B,
-                                                         uint8_t* __restrict__ state, float* __restrict__ out1) {
+                                                         uint8_t* __restrict__ state, float* __restrict__ out1,
+                                                         int code_bytes) {
   const EncS1P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                    // [6][S1][CS1]: rows 0-1 strided-conv history, rows 2-5 X[t]
@@ -206,14 +210,15 @@ __global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const E
   if (tid < S1) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::ENC_PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::E1_BYTES + st::PHASE);
   }
   const auto warm = l2_warm<NT1, 2>(P.warm);
+  const auto warm_code = code_warm<NT1>(code_bytes);
   __syncthreads();
-  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::BYTES; };
+  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::E1_BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B; };
 
-  TileCtx cx{state, sids, sphase, B - b0};
+  TileCtx cx{state, sids, sphase, B - b0, st::E1_BYTES};
   const auto H0 = hist128_prefetch<S1, NT1>(cx, 1, st::E_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
@@ -271,7 +276,12 @@ __global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const E
   }
   LYRA_TSTAMP(73);
   LYRA_WSTAMP(103);
+  if (tid < S1 && valid(tid)) {   // this region's ring phase (every thread read it into LDS before the first barrier)
+    int ph = sphase[tid] + 1;
+    *reinterpret_cast<int*>(sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+  }
   l2_warm_sink(warm, state, B);
+  l2_warm_sink(warm_code, state, B);
 }
 
 }  // namespace lyra

@@ -41,7 +41,7 @@ int enc_s2_streams_per_wg() { return S2; }
 __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, float* __restrict__ feats,
-                                                      float* __restrict__ codes_dbg) {
+                                                      float* __restrict__ codes_dbg, int code_bytes) {
   const EncS2P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* DF = smem;                                  // [2][S][CS2] depthwise out; later int8 staging QB4
@@ -65,12 +65,13 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
   if (tid < S2) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::BYTES + st::ENC_PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::E2_BYTES + st::PHASE);
   }
   load_luts<NT2>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NT2, 1>(P.warm);
+  const auto warm_code = code_warm<NT2>(code_bytes);
   __syncthreads();
-  TileCtx cx{state, sids, sphase, B - b0};
+  TileCtx cx{state, sids, sphase, B - b0, st::E2_BYTES};
   const RbqPre pre1 = resblock_q_prefetch<S2>(cx, 3, st::E_R2_1, P.dwq[0], P.pwq[0], P.cvq[0]);
 
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
@@ -232,9 +233,10 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
   LYRA_WG_END();
   if (tid < S2 && cx.valid(tid)) {
     int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(cx.sbase(tid) + st::ENC_PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
   }
   l2_warm_sink(warm, state, B);
+  l2_warm_sink(warm_code, state, B);
 }
 
 }  // namespace lyra

@@ -21,10 +21,13 @@ struct EncS2P {
   WarmRange warm;
 };
 
-__global__ void enc_s0_kernel(const EncS0P* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* out0);
-__global__ void enc_s1_kernel(const EncS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
+// code_bytes: size of the kernel's own machine code to pull into L2 at start (lyra_dev.h code_warm; 0 = skip)
+__global__ void enc_s0_kernel(const EncS0P* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* out0,
+                              int code_bytes);
+__global__ void enc_s1_kernel(const EncS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1,
+                              int code_bytes);
 __global__ void enc_s2_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, float* feats,
-                              float* codes_dbg);
+                              float* codes_dbg, int code_bytes);
 size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg();
 size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg(); int enc_s1_threads();
 size_t enc_s2_lds_bytes(); int enc_s2_streams_per_wg();
@@ -51,9 +54,11 @@ struct DecS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; const float* up_s
 struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; WarmRange warm; };
 
 __global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0,
-                              const uint8_t* packets, int num_stages, const float* cb);
-__global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1);
-__global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm);
+                              const uint8_t* packets, int num_stages, const float* cb, int code_bytes);
+__global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1,
+                              int code_bytes);
+__global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm,
+                              int code_bytes);
 size_t dec_s0_lds_bytes(); int dec_s0_streams_per_wg();
 size_t dec_s1_lds_bytes(); int dec_s1_streams_per_wg(); int dec_s1_threads();
 size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg();
@@ -69,6 +74,8 @@ struct MelP { const double* hann; const double* tw_re; const double* tw_im; cons
 __global__ void logmel_kernel(const MelP* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* mel);
 size_t logmel_lds_bytes();
 struct ResetP { int8_t e_r2_1, e_r2_2, e_d2, e_bott, d_r0_0, d_r0_1, d_r0_2; };
-__global__ void reset_kernel(const ResetP* P, const int32_t* ids, int n, int all, uint8_t* state);
+// region base pointers and per-stream slot sizes (state_layout.h), filled on the host, passed by value
+struct StateMap { uint8_t* base[st::R_COUNT]; int bytes[st::R_COUNT]; };
+__global__ void reset_kernel(const ResetP* P, const int32_t* ids, int n, int all, StateMap sm);
 
 }  // namespace lyra

@@ -277,6 +277,20 @@ __device__ __forceinline__ WarmTok<MAXIT> l2_warm(const WarmRange& w) {
   }
   return tok;
 }
+// The kernel's OWN machine code, same idea.  The stage kernels are tens of KB of straight-line code executed once
+// per workgroup; instruction-cache misses are served by the XCD's L2, which is cold at a kernel boundary, so each
+// line's first fetch goes to the Infinity Cache -- or, when the step's working set (265 MB of per-stream state at
+// B = 4096, more than the 256 MB cache) has pushed the code out of it, to HBM, in the middle of the dependent phase
+// chain.  Measured (tools/pipeline_probe.py): inside the sustained encode+decode pipeline the two largest kernels
+// (enc_s2 29 KB, dec_s0 42 KB of code) ran 64 / 82 us instead of 40 / 45 us on most boxes of the pool; pulling
+// the code into L2 with data loads at kernel start brings them back to 51 / 61 us.
+// `code_bytes` comes from the host (symbol size of this kernel, minus a margin: s_getpc is not byte 0 of the function).
+template <int NT>
+__device__ __forceinline__ WarmTok<1> code_warm(int code_bytes) {
+  const uint64_t pc = __builtin_amdgcn_s_getpc();
+  return l2_warm<NT, 1>(WarmRange{reinterpret_cast<const uint8_t*>(pc & ~127ull), (uint32_t)(code_bytes > 0 ? code_bytes : 0)});
+}
+
 // never true in practice; keeps the warm-up loads alive without waiting for them early
 template <int MAXIT>
 __device__ __forceinline__ void l2_warm_sink(const WarmTok<MAXIT>& tok, uint8_t* state, int B) {

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
   double* mag = dsm + 2048;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  int16_t* prev = reinterpret_cast<int16_t*>(state + (size_t)ids[b] * st::BYTES + st::M_PREV);
+  int16_t* prev = reinterpret_cast<int16_t*>(state + (size_t)ids[b] * st::MEL_BYTES + st::M_PREV);
   for (int i = tid; i < 1024; i += 256) {
     double v = 0.0;
     if (i < 320) v = (double)prev[i] * P.hann[i];
@@ -193,26 +193,36 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
 
 // =============================================================================================
 // state reset: zeros everywhere (the graphs' CALL_ONCE init subgraph assigns zero constants), int8
-// histories hold the zero point of their tensor (== quantize(0.0f)).
+// histories hold the zero point of their tensor (== quantize(0.0f)); NoiseEstimator: is_noise_ = true
+// (lyra/noise_estimator.cc:131).  One workgroup per stream walks that stream's slot in every region.
 // =============================================================================================
 __global__ __launch_bounds__(256) void reset_kernel(const ResetP* __restrict__ Pp, const int32_t* __restrict__ ids, int n, int all,
-                                                     uint8_t* __restrict__ state) {
+                                                     StateMap sm) {
   const ResetP& P = *Pp;
   const int sidx = blockIdx.x;
   if (sidx >= n) return;
   const int id = all ? sidx : ids[sidx];
-  uint8_t* base = state + (size_t)id * st::BYTES;
-  for (int o = threadIdx.x * 16; o < st::BYTES; o += 256 * 16) {
-    int v = 0;
-    if (o >= st::E_R2_1 && o < st::E_R2_2) v = P.e_r2_1;
-    else if (o >= st::E_R2_2 && o < st::E_D2) v = P.e_r2_2;
-    else if (o >= st::E_D2 && o < st::E_BOTT) v = P.e_d2;
-    else if (o >= st::E_BOTT && o < st::E_END) v = P.e_bott;
-    else if (o >= st::D_R0_0 && o < st::D_R0_1) v = P.d_r0_0;
-    else if (o >= st::D_R0_1 && o < st::D_R0_2) v = P.d_r0_1;
-    else if (o >= st::D_R0_2 && o < st::D_UP1) v = P.d_r0_2;
-    int w = (v & 255) * 0x01010101;
-    *reinterpret_cast<i32x4*>(base + o) = (i32x4){w, w, w, w};
+#pragma unroll 1
+  for (int r = 0; r < st::R_COUNT; ++r) {
+    const int bytes = sm.bytes[r];   // (st::REGION_BYTES is a host-side table: no runtime indexing of it here)
+    uint8_t* base = sm.base[r] + (size_t)id * bytes;
+    for (int o = threadIdx.x * 16; o < bytes; o += 256 * 16) {
+      int v = 0;
+      if (r == st::R_E2) {
+        if (o >= st::E_R2_1 && o < st::E_R2_2) v = P.e_r2_1;
+        else if (o >= st::E_R2_2 && o < st::E_D2) v = P.e_r2_2;
+        else if (o >= st::E_D2 && o < st::E_BOTT) v = P.e_d2;
+        else if (o >= st::E_BOTT && o < st::E_BOTT + 2 * 512) v = P.e_bott;
+      } else if (r == st::R_D0) {
+        if (o >= st::D_R0_0 && o < st::D_R0_1) v = P.d_r0_0;
+        else if (o >= st::D_R0_1 && o < st::D_R0_2) v = P.d_r0_1;
+        else if (o >= st::D_R0_2 && o < st::D_UP1) v = P.d_r0_2;
+      }
+      const int w = (v & 255) * 0x01010101;
+      i32x4 q = (i32x4){w, w, w, w};
+      if ((r == st::R_NOISE_E || r == st::R_NOISE_D) && o == 0) q[st::N_IS_NOISE / 4] = 1;
+      *reinterpret_cast<i32x4*>(base + o) = q;
+    }
   }
 }
 

@@ -11,11 +11,12 @@
 namespace lyra {
 
 struct TileCtx {
-  uint8_t* state;
+  uint8_t* state;      // the kernel's own state region: [stream][stride] (state_layout.h)
   const int* sids;     // LDS: stream id of each tile slot
   const int* sphase;   // LDS: frame phase of each tile slot (may be null when no ring is used)
   int nvalid;          // slots < nvalid are real streams
-  __device__ __forceinline__ uint8_t* sbase(int s) const { return state + (size_t)sids[s] * st::BYTES; }
+  int stride;          // bytes per stream in this region
+  __device__ __forceinline__ uint8_t* sbase(int s) const { return state + (size_t)sids[s] * stride; }
   __device__ __forceinline__ bool valid(int s) const { return s < nvalid; }
 };
 
