@@ -8,89 +8,107 @@ namespace lyra {
 // ResidualVectorQuantizer::Quantize (lyra/residual_vector_quantizer.cc:77-110) + Packet<>::Pack
 // (lyra/packet.h:91-122).  16 lanes = the 16 codewords of a stage; each lane runs the 64-term
 // squared-distance sum in the oracle's order (separate multiply and add, d ascending), then a
-// 16-lane shuffle argmin with lowest-index tie break (ARG_MIN = first minimum).  The residual lives
-// in LDS, shared by the 16 lanes of its frame (broadcast reads), and is updated once per dimension with the
-// graph's three fp32 ops r - (r + (q - r)).  4 frames per wavefront, 16 per workgroup.  The 4 KB codebook of
-// the current stage sits in LDS (rows padded to 68 floats: conflict-free ds_read_b128 across the 16 code lanes),
-// double-buffered: the next stages' rows are fetched from L2 while this window computes.  63 VGPRs: the kernel
-// is a 46-step dependent chain at one wavefront per SIMD, so what matters is how little it takes away from the
-// decode-side kernels running next to it.
+// 16-lane DPP argmin with lowest-index tie break (ARG_MIN = first minimum).  4 frames per wavefront,
+// 16 per workgroup.
+//
+// With 4096 frames there is exactly one 64-term chain per lane of the chip and one wavefront per SIMD: the kernel
+// is a 46-step dependent chain and nothing but its own latency matters.  Per stage the critical path is
+//   residual broadcast reads (LDS) -> 64 dependent adds -> 4 DPP steps -> winner row read (LDS) -> 3 ops -> LDS write,
+// so everything that does not depend on the residual is taken off it:
+//  * the lane's codeword row of stage k+1 (16 x ds_read_b128) is fetched into registers while stage k reduces and
+//    updates (two register sets, the stage loop is unrolled by two);
+//  * the residual lives in LDS (rs, row stride 68 floats so the four frames of a wavefront hit different banks),
+//    shared by the 16 lanes of its frame with broadcast reads; lane j owns dims 4j..4j+3, keeps them in registers
+//    and applies the graph's three fp32 ops r - (r + (q - r)) to them once per stage.  All 16 lanes of a frame sit
+//    in one wavefront and LDS operations of a wavefront execute in order: the write-back needs no barrier;
+//  * codebooks go global -> registers -> LDS in windows of W = 8 stages (rows padded to 68 floats: conflict-free
+//    ds_read_b128 across the 16 code lanes), three buffers deep, one barrier per window: window w+1 is already in
+//    LDS while window w computes (the cross-window prefetch needs it), window w+2 is in flight from L2.
 // =============================================================================================
 __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ cb,
                                                           const float* __restrict__ feats, int B, int num_stages,
                                                           int32_t* __restrict__ indices,
                                                           uint8_t* __restrict__ packets) {
-  // Codebooks are staged through LDS in windows of W stages, double-buffered: window w+1 is fetched from L2
-  // while window w computes (a whole window of compute hides the load latency; one barrier per window).
-  constexpr int W = 4, WFLOATS = W * 16 * 68;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) float cbs[2][WFLOATS];
+  constexpr int W = 8, ROW = 68, WFLOATS = W * 16 * ROW;   // 3 x 34 KB of LDS: one workgroup per CU anyway
+  __shared__ __attribute__((aligned(16))) float cbs[3][WFLOATS];
+  __shared__ __attribute__((aligned(16))) float rs[16][ROW];
   const int tid = threadIdx.x;
   const int j = tid & 15;
   const int frame = blockIdx.x * 16 + (tid >> 4);
   const int f = min(frame, B - 1);
   const int ldrow = tid >> 4, ldc4 = tid & 15;  // this thread's float4 of each stage's [16][64] codebook
-  f32x4 nxt[W];
+  const f32x4 LYRA_GLOBAL* cbg = reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(cb)) + ldrow * 16 + ldc4;
+  f32x4 stage_in[W];
+  auto gload = [&](int win) {
 #pragma unroll
-  for (int u = 0; u < W; ++u)
-    nxt[u] = *reinterpret_cast<const f32x4*>(&cb[((size_t)min(u, 45) * 16 + ldrow) * 64 + ldc4 * 4]);
-  // The residual of each frame lives in LDS (rs), not replicated in the registers of its 16 code lanes: the
-  // distance pass reads it with broadcast ds_read_b128 next to the code rows, and the update r - (r + (q - r))
-  // is done once per dimension (lane j owns dims 4j..4j+3) instead of sixteen times.  All 16 lanes of a frame sit
-  // in one wavefront and LDS operations of a wavefront execute in order, so the write-back needs no barrier.
-  __shared__ __attribute__((aligned(16))) float rs[16][64];
+    for (int v = 0; v < W; ++v) stage_in[v] = cbg[(size_t)min(win * W + v, 45) * 256];
+  };   // (windows past the last stage re-read stage 45: never used, keeps the loop free of tail cases)
+  auto lstore = [&](int win) {
+    float* dst = cbs[win % 3] + ldrow * ROW + ldc4 * 4;
+#pragma unroll
+    for (int v = 0; v < W; ++v) *reinterpret_cast<f32x4*>(dst + v * 16 * ROW) = stage_in[v];
+  };
+  gload(0);
   float* rme = rs[tid >> 4];
-  *reinterpret_cast<f32x4*>(&rme[j * 4]) = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + j * 4]);
+  f32x4 mine = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + j * 4]);   // this lane's four residual dims
+  *reinterpret_cast<f32x4*>(&rme[j * 4]) = mine;
+  lstore(0);
+  gload(1);
+  __syncthreads();
   const int nbytes = (num_stages + 1) >> 1;
   int cur = 0;
-#pragma unroll 1
-  for (int k = 0; k < num_stages; ++k) {
+  f32x4 rowa[16], rowb[16];
+  auto load_row = [&](f32x4 (&row)[16], int k) {
+    const float* c = cbs[(k / W) % 3] + (k & (W - 1)) * 16 * ROW + j * ROW;
+#pragma unroll
+    for (int d4 = 0; d4 < 16; ++d4) row[d4] = *reinterpret_cast<const f32x4*>(&c[d4 * 4]);
+  };
+  load_row(rowa, 0);
+  auto stage = [&](int k, const f32x4 (&row)[16], f32x4 (&next)[16]) {
     const int u = k & (W - 1), win = k / W;
     if (u == 0) {
-      // window `win` -> LDS (its loads were issued a window ago), then request window win+1
-#pragma unroll
-      for (int v = 0; v < W; ++v)
-        *reinterpret_cast<f32x4*>(&cbs[win & 1][v * 16 * 68 + ldrow * 68 + ldc4 * 4]) = nxt[v];
-#pragma unroll
-      for (int v = 0; v < W; ++v)
-        nxt[v] = *reinterpret_cast<const f32x4*>(&cb[((size_t)min((win + 1) * W + v, 45) * 16 + ldrow) * 64 + ldc4 * 4]);
-      __syncthreads();  // window visible; (the previous barrier already guarantees nobody still reads this buffer:
-                        //  it was last read two windows ago, and every thread passed the barrier in between)
+      // window win+1 -> LDS (fetched a window ago), request window win+2.  Buffer (win+1) % 3 last held window
+      // win-2, which nobody reads any more: every wave passed the previous window's barrier, i.e. finished
+      // window win-2, before any wave could get here.
+      lstore(win + 1);
+      gload(win + 2);
+      __syncthreads();
     }
-    const float* c = cbs[win & 1] + u * 16 * 68;
     asm volatile("" ::: "memory");   // rs is rewritten by the other lanes of the frame: never carry it in registers
     float sum = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < 16; ++d4) {
-      f32x4 cv = *reinterpret_cast<const f32x4*>(&c[j * 68 + d4 * 4]);
-      f32x4 rv = *reinterpret_cast<const f32x4*>(&rme[d4 * 4]);
-      f32x2 df0 = (f32x2){rv[0], rv[1]} - (f32x2){cv[0], cv[1]};
-      f32x2 df1 = (f32x2){rv[2], rv[3]} - (f32x2){cv[2], cv[3]};
-      f32x2 sq0 = df0 * df0, sq1 = df1 * df1;
-      sum = sum + sq0[0];
-      sum = sum + sq0[1];
-      sum = sum + sq1[0];
-      sum = sum + sq1[1];
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(&rme[d4 * 4]);
+      const f32x4 df = rv - row[d4];
+      const f32x4 sq = df * df;
+      sum = sum + sq[0];
+      sum = sum + sq[1];
+      sum = sum + sq[2];
+      sum = sum + sq[3];
     }
-    int best = j;
-    float bd = sum;
-    // all-reduce over the 16 code lanes with DPP row rotations (row_ror:8/4/2/1): register-only, no LDS crossbar.
-    // (distance, index) is totally ordered, so every lane ends with the same winner.
-#define LYRA_ROR_STEP(N)                                                                                  \
-  {                                                                                                       \
-    float od = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bd),      \
-                                                                       0x120 + (N), 0xf, 0xf, false));    \
-    int oi = __builtin_amdgcn_update_dpp(0, best, 0x120 + (N), 0xf, 0xf, false);                          \
-    if (od < bd || (od == bd && oi < best)) { bd = od; best = oi; }                                       \
-  }
-    LYRA_ROR_STEP(8) LYRA_ROR_STEP(4) LYRA_ROR_STEP(2) LYRA_ROR_STEP(1)
-#undef LYRA_ROR_STEP
+    // Off the critical path: issued after the chain (the residual reads above must not queue behind it) and before
+    // the reduction, so the 16 reads drain while the DPP steps run and the winner-row read below finds the LDS idle.
+    __builtin_amdgcn_sched_barrier(0);
+    if (k + 1 < num_stages) load_row(next, k + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ARG_MIN = first minimum, branch-free: the row minimum of the distance by a 16-lane all-reduce with DPP row
+    // rotations (register-only, no LDS crossbar), then the lowest lane of the frame's 16-lane field that holds it
+    // (ballot + find-first-set).  Distances are sums of squares (>= 0, finite for finite features); fminf returns
+    // one of its operands exactly.
+    float m = sum;
+#define LYRA_ROR_MINF(N) \
+    m = __builtin_fminf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + (N), 0xf, 0xf, false)));
+    LYRA_ROR_MINF(8) LYRA_ROR_MINF(4) LYRA_ROR_MINF(2) LYRA_ROR_MINF(1)
+#undef LYRA_ROR_MINF
+    const unsigned long long holders = __builtin_amdgcn_ballot_w64(sum == m);
+    const int best = __builtin_ctz((unsigned)(holders >> (tid & 48)) | 0x10000u) & 15;   // (& 15: NaN distances only)
     {  // r <- r - (r + (q - r)), the graph's three separate fp32 ops, on this lane's four dimensions
-      const f32x4 qv = *reinterpret_cast<const f32x4*>(&c[best * 68 + j * 4]);
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(&rme[j * 4]);
-      const f32x4 t1 = qv - rv;
-      const f32x4 t2 = rv + t1;
-      *reinterpret_cast<f32x4*>(&rme[j * 4]) = rv - t2;
+      const float* c = cbs[win % 3] + u * 16 * ROW;
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(&c[best * ROW + j * 4]);
+      const f32x4 t1 = qv - mine;
+      const f32x4 t2 = mine + t1;
+      mine = mine - t2;
+      *reinterpret_cast<f32x4*>(&rme[j * 4]) = mine;
     }
     if (j == 0 && frame < B) {
       if (indices) indices[(size_t)frame * 46 + k] = best;
@@ -99,6 +117,11 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
         else cur = best << 4;
       }
     }
+  };
+#pragma unroll 1
+  for (int k = 0; k < num_stages; k += 2) {
+    stage(k, rowa, rowb);
+    if (k + 1 < num_stages) stage(k + 1, rowb, rowa);
   }
   if (j == 0 && frame < B) {
     if (packets && (num_stages & 1)) packets[(size_t)frame * nbytes + (num_stages >> 1)] = (uint8_t)cur;

@@ -1028,3 +1028,27 @@ double lo_run_batch(const lo_model* m, lo_stream** streams, int B, int steps, in
   free(th); free(jobs);
   return dt;
 }
+
+/* ------------------------------------------------------------------------ */
+/* batch RVQ (tests: >= 10^6 vectors against the GPU kernel)                    */
+/* ------------------------------------------------------------------------ */
+typedef struct { const lo_model* m; const float* feats; long lo, hi; int num_stages; int32_t* idx; } rvq_job;
+static void* rvq_worker(void* p) {
+  rvq_job* j = (rvq_job*)p;
+  for (long i = j->lo; i < j->hi; ++i) lo_rvq_encode(j->m, j->feats + i * 64, j->num_stages, j->idx + i * RVQ_STAGES);
+  return NULL;
+}
+void lo_rvq_encode_batch(const lo_model* m, const float* feats, long n, int num_stages, int32_t* idx, int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pthread_t th[256];
+  rvq_job jobs[256];
+  long per = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; ++t) {
+    long lo = t * per, hi = lo + per > n ? n : lo + per;
+    if (lo > n) lo = n;
+    jobs[t] = (rvq_job){m, feats, lo, hi, num_stages, idx};
+    pthread_create(&th[t], NULL, rvq_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+}

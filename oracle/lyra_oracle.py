@@ -45,6 +45,7 @@ def lib():
         L.lo_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.lo_rvq_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.lo_rvq_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_rvq_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_int]
         L.lo_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.lo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.lo_decode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -81,6 +82,13 @@ class Oracle:
         idx = np.empty((feat.shape[0], 46), np.int32)
         for i in range(feat.shape[0]):
             self.L.lo_rvq_encode(self.h, _p(feat[i]), num_stages, _p(idx[i]))
+        return idx
+
+    def rvq_encode_batch(self, feat, num_stages, threads=8):
+        """Many vectors at once (threaded in C): float32 [n][64] -> int32 [n][46]."""
+        feat = np.ascontiguousarray(feat, np.float32).reshape(-1, 64)
+        idx = np.empty((feat.shape[0], 46), np.int32)
+        self.L.lo_rvq_encode_batch(self.h, _p(feat), feat.shape[0], num_stages, _p(idx), threads)
         return idx
 
     def rvq_decode(self, idx):

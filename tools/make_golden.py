@@ -127,6 +127,13 @@ def main():
     np.savez_compressed(os.path.join(OUT, "rvq.npz"), fixture=feat, fixture_idx=idx.astype(np.int32),
                         fixture_dec16=dec[16], fixture_dec30=dec[30], fixture_dec46=dec[46],
                         rnd=rnd, rnd_idx=ridx.astype(np.int32), rnd_dec=rdec)
+    # --- 4. the reference's 16 kHz test wavs as raw PCM (inputs of the whole-file known answers / LSD criterion) ---
+    wavs = {}
+    for name in ("sample1_16kHz", "sample2_16kHz"):
+        w = wave.open(REF + "/testdata/" + name + ".wav")
+        assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        wavs[name] = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+    np.savez_compressed(os.path.join(OUT, "sample_wavs.npz"), **wavs)
     print("rvq fixture idx", list(map(int, idx)))
     print("done ->", OUT)
 
