@@ -127,6 +127,34 @@ int lyra_hip_generate(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const
  * per-stream 320-sample history. */
 int lyra_hip_logmel(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, float* mel);
 
+/* NoiseEstimator (lyra/noise_estimator.h:45-60), one instance per stream and side: side LYRA_HIP_SIDE_ENCODER is the
+ * estimator LyraEncoder owns for DTX (lyra_encoder.cc:81-83), LYRA_HIP_SIDE_DECODER the one LyraDecoder feeds with every
+ * decoded hop of a received packet (lyra_decoder.cc:304-311).  noise_receive = ReceiveSamples for one full 320-sample
+ * hop per stream (its own log-mel front end + ComputeIsNoise + DecayBounds / UpdateNoiseEstimate,
+ * noise_estimator.cc:144-245) and returns is_noise() per stream (int32 0/1); noise_estimate = noise_estimate(),
+ * [B][160] log-mel bins. */
+#define LYRA_HIP_SIDE_ENCODER 0
+#define LYRA_HIP_SIDE_DECODER 1
+int lyra_hip_noise_receive(lyra_hip_ctx* ctx, int side, const int32_t* stream_ids, int B, const int16_t* pcm,
+                           int32_t* is_noise);
+int lyra_hip_noise_estimate(lyra_hip_ctx* ctx, int side, const int32_t* stream_ids, int B, float* estimate);
+
+/* Resampler::Resample (lyra/resampler.cc:57-62), one instance per stream and side: LYRA_HIP_SIDE_ENCODER is the
+ * resampler LyraEncoder applies to incoming audio (external rate -> 16 kHz, lyra_encoder.cc:59-66,119-122),
+ * LYRA_HIP_SIDE_DECODER the one behind LyraDecoder's BufferedResampler (16 kHz -> external, lyra_decoder.cc:107-113).
+ * in [B][n_in] int16 -> out [B][n_in * out_rate / in_rate]; rates from {8000, 16000, 32000, 48000}, one of them
+ * 16000; n_in <= 960 and a multiple of in_rate / gcd.  audio_dsp::QResampler is restated (Kaiser-windowed sinc,
+ * radius 17 input samples, primed: output delayed by 17 input samples); see oracle/lyra_oracle.c for the parity note. */
+int lyra_hip_resample(lyra_hip_ctx* ctx, int side, const int32_t* stream_ids, int B, const int16_t* in, int n_in,
+                      int in_rate, int out_rate, int16_t* out);
+
+/* ComfortNoiseGenerator::AddFeatures + GenerateSamples(320) (lyra/comfort_noise_generator.cc:74-119): one 20 ms hop
+ * of noise per stream whose 160-bin log-mel matches `features` [B][160]; features == NULL uses each stream's decoder-side
+ * noise estimate, as LyraDecoder::RunComfortNoiseGenerator does (lyra_decoder.cc:328-340).  Phases come from a
+ * counter-based generator (seed, stream id, hop, bin) instead of the reference's non-deterministic absl::BitGen. */
+int lyra_hip_comfort_noise(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const float* features, int16_t* pcm);
+int lyra_hip_set_cng_seed(lyra_hip_ctx* ctx, uint64_t seed);
+
 /* ---- fused paths -------------------------------------------------------------------------------- */
 
 /* LyraEncoder::Encode without resampling/DTX (lyra/lyra_encoder.cc:143-155): Extract -> Quantize ->
@@ -134,6 +162,13 @@ int lyra_hip_logmel(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const i
  * pcm [B][320] -> packets [B][num_bits/8 rounded up] (8 / 15 / 23 bytes for 64 / 120 / 184 bits). */
 int lyra_hip_encode(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, int num_bits,
                     uint8_t* packets);
+
+/* LyraEncoder::Encode with enable_dtx = true (lyra/lyra_encoder.cc:131-156): every hop updates the stream's
+ * encoder-side NoiseEstimator; a hop that is noise yields an EMPTY packet (packet_bytes[i] = 0, the packet row is left
+ * zero) and does not run the feature extractor, so the encoder state of that stream does not advance; any other hop
+ * is encoded as lyra_hip_encode does (packet_bytes[i] = num_bits / 8 rounded up). */
+int lyra_hip_encode_dtx(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, int num_bits,
+                        uint8_t* packets, int32_t* packet_bytes);
 
 /* LyraDecoder::SetEncodedPacket + DecodeSamples(320) steady state, no loss/PLC
  * (lyra/lyra_decoder.cc:172-226,284-326): unpack -> DecodeToLossyFeatures -> generative model. */
@@ -152,6 +187,15 @@ int lyra_hip_encode_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, c
                         uint8_t* d_packets);
 int lyra_hip_decode_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const uint8_t* d_packets,
                         int num_bits, int16_t* d_pcm);
+int lyra_hip_resample_dev(lyra_hip_ctx* ctx, int side, const int32_t* d_stream_ids, int B, const int16_t* d_in, int n_in,
+                          int in_rate, int out_rate, int16_t* d_out);
+int lyra_hip_comfort_noise_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const float* d_features,
+                               int16_t* d_pcm);
+int lyra_hip_noise_receive_dev(lyra_hip_ctx* ctx, int side, const int32_t* d_stream_ids, int B, const int16_t* d_pcm,
+                               int32_t* d_is_noise);
+/* (rows of d_packets that belong to noise hops are not written) */
+int lyra_hip_encode_dtx_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const int16_t* d_pcm, int num_bits,
+                            uint8_t* d_packets, int32_t* d_packet_bytes);
 
 /* The context's HIP streams (hipStream_t as void*), for event timing / ordering by the caller:
  * encode side and decode side.  lyra_hip_synchronize() waits for both. */

@@ -93,6 +93,14 @@ def _load():
         getattr(L, f"lyra_hip_rvq_decode{suf}").argtypes = [vp, ci, vp, vp]
         getattr(L, f"lyra_hip_encode{suf}").argtypes = [vp, vp, ci, vp, ci, vp]
         getattr(L, f"lyra_hip_decode{suf}").argtypes = [vp, vp, ci, vp, ci, vp]
+    for suf in ("", "_dev"):
+        getattr(L, f"lyra_hip_noise_receive{suf}").argtypes = [vp, ci, vp, ci, vp, vp]
+        getattr(L, f"lyra_hip_encode_dtx{suf}").argtypes = [vp, vp, ci, vp, ci, vp, vp]
+    L.lyra_hip_noise_estimate.argtypes = [vp, ci, vp, ci, vp]
+    for suf in ("", "_dev"):
+        getattr(L, f"lyra_hip_resample{suf}").argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
+        getattr(L, f"lyra_hip_comfort_noise{suf}").argtypes = [vp, vp, ci, vp, vp]
+    L.lyra_hip_set_cng_seed.argtypes = [vp, C.c_uint64]
     L.lyra_hip_stream.restype = vp
     L.lyra_hip_stream.argtypes = [vp]
     L.lyra_hip_stream_decode.restype = vp
@@ -244,6 +252,60 @@ class LyraHip:
         out = np.empty((B, HOP), np.int16)
         self._chk(self.L.lyra_hip_decode(self.h, ids.ctypes.data, B, packets.ctypes.data, num_bits, out.ctypes.data))
         return out
+
+    _SIDES = {"encoder": 0, "decoder": 1}
+
+    def noise_receive(self, pcm, stream_ids=None, side="decoder"):
+        """NoiseEstimator::ReceiveSamples, one full hop per stream -> is_noise int32 [B]."""
+        pcm = _np(pcm, np.int16, (-1, HOP))
+        B = pcm.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.empty(B, np.int32)
+        self._chk(self.L.lyra_hip_noise_receive(self.h, self._SIDES[side], ids.ctypes.data, B, pcm.ctypes.data,
+                                                out.ctypes.data))
+        return out
+
+    def noise_estimate(self, stream_ids, side="decoder"):
+        """NoiseEstimator::noise_estimate() -> float32 [B][160]."""
+        ids = _np(stream_ids, np.int32, (-1,))
+        out = np.empty((ids.size, NUM_MEL), np.float32)
+        self._chk(self.L.lyra_hip_noise_estimate(self.h, self._SIDES[side], ids.ctypes.data, ids.size, out.ctypes.data))
+        return out
+
+    def encode_dtx(self, pcm, num_bits, stream_ids=None):
+        """LyraEncoder::Encode with enable_dtx -> (packets uint8 [B][nbytes], packet_bytes int32 [B]; 0 = empty packet)."""
+        pcm = _np(pcm, np.int16, (-1, HOP))
+        B = pcm.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.zeros((B, packet_size(num_bits)), np.uint8)
+        nbytes = np.empty(B, np.int32)
+        self._chk(self.L.lyra_hip_encode_dtx(self.h, ids.ctypes.data, B, pcm.ctypes.data, num_bits, out.ctypes.data,
+                                             nbytes.ctypes.data))
+        return out, nbytes
+
+    def resample(self, audio, in_rate, out_rate, stream_ids=None, side="encoder"):
+        """Resampler::Resample per stream: int16 [B][n_in] -> int16 [B][n_in * out_rate / in_rate]."""
+        audio = np.ascontiguousarray(audio, np.int16)
+        B, n_in = audio.shape
+        ids = self._ids(stream_ids, B)
+        out = np.empty((B, n_in * out_rate // in_rate), np.int16)
+        self._chk(self.L.lyra_hip_resample(self.h, self._SIDES[side], ids.ctypes.data, B, audio.ctypes.data, n_in,
+                                           in_rate, out_rate, out.ctypes.data))
+        return out
+
+    def comfort_noise(self, features=None, stream_ids=None, B=None):
+        """ComfortNoiseGenerator: one hop per stream; features float32 [B][160] or None (= the decoder-side noise estimate)."""
+        if features is not None:
+            features = _np(features, np.float32, (-1, NUM_MEL))
+            B = features.shape[0]
+        ids = self._ids(stream_ids, B)
+        out = np.empty((B, HOP), np.int16)
+        self._chk(self.L.lyra_hip_comfort_noise(self.h, ids.ctypes.data, B,
+                                                features.ctypes.data if features is not None else None, out.ctypes.data))
+        return out
+
+    def set_cng_seed(self, seed):
+        self._chk(self.L.lyra_hip_set_cng_seed(self.h, seed))
 
     def profile_kernel_names(self):
         n = self.L.lyra_hip_profile_kernel_count()

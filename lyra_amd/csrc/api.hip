@@ -8,6 +8,7 @@
 // waits for every decode-side call except the most recent one (enc_side_begin; include/lyra_hip.h "Streams").
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -59,7 +60,15 @@ struct lyra_hip_ctx {
   float* d_d0 = nullptr;     // [cap][4][128]
   float* d_d1 = nullptr;     // [cap][20][64]
   int16_t* d_pcm_out = nullptr;
-  float* d_mel = nullptr;    // [cap][160]
+  float* d_mel = nullptr;    // [cap][160]  decode side / plugin-level log-mel
+  float* d_mel_enc = nullptr;  // [cap][160]  encode side (DTX noise estimator)
+  int32_t* d_flag_enc = nullptr;  // [cap] is_noise, encode side
+  int32_t* d_flag_dec = nullptr;  // [cap] is_noise, decode side
+  int32_t* d_live_ids = nullptr;  // [cap] stream ids with noise hops masked to -1 (DTX)
+  int32_t* d_pkt_bytes = nullptr; // [cap]
+  int16_t* d_rs_in = nullptr;     // [cap][960] resampler staging (host-pointer entry points)
+  int16_t* d_rs_out = nullptr;    // [cap][960]
+  unsigned long long cng_seed = 0x4C797261ull;   // comfort-noise phase generator seed (lyra_hip_set_cng_seed)
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
   unsigned profiling = 0;  // bit i set: bracket launches of kernel i
@@ -103,12 +112,15 @@ int sync_all(lyra_hip_ctx* c) {
 
 void free_scratch(lyra_hip_ctx* c) {
   void* ps[] = {c->d_ids, c->d_ids_dec, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_codes, c->d_idx, c->d_pkt,
-                c->d_lossy, c->d_d0, c->d_d1, c->d_pcm_out, c->d_mel};
+                c->d_lossy, c->d_d0, c->d_d1, c->d_pcm_out, c->d_mel, c->d_mel_enc, c->d_flag_enc, c->d_flag_dec,
+                c->d_live_ids, c->d_pkt_bytes, c->d_rs_in, c->d_rs_out};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   c->d_ids = nullptr; c->d_ids_dec = nullptr; c->d_pcm_in = nullptr; c->d_e0 = nullptr; c->d_e1 = nullptr;
   c->d_feat = nullptr; c->d_codes = nullptr; c->d_idx = nullptr; c->d_pkt = nullptr; c->d_lossy = nullptr;
-  c->d_d0 = nullptr; c->d_d1 = nullptr; c->d_pcm_out = nullptr; c->d_mel = nullptr;
+  c->d_d0 = nullptr; c->d_d1 = nullptr; c->d_pcm_out = nullptr; c->d_mel = nullptr; c->d_mel_enc = nullptr;
+  c->d_flag_enc = nullptr; c->d_flag_dec = nullptr; c->d_live_ids = nullptr; c->d_pkt_bytes = nullptr;
+  c->d_rs_in = nullptr; c->d_rs_out = nullptr;
   c->cap = 0;
 }
 
@@ -132,6 +144,13 @@ int ensure_scratch(lyra_hip_ctx* c, int B) {
   HIPCHK(c, dalloc(&c->d_d1, n * 20 * 64));
   HIPCHK(c, dalloc(&c->d_pcm_out, n * 320));
   HIPCHK(c, dalloc(&c->d_mel, n * 160));
+  HIPCHK(c, dalloc(&c->d_mel_enc, n * 160));
+  HIPCHK(c, dalloc(&c->d_flag_enc, n));
+  HIPCHK(c, dalloc(&c->d_flag_dec, n));
+  HIPCHK(c, dalloc(&c->d_live_ids, n));
+  HIPCHK(c, dalloc(&c->d_pkt_bytes, n));
+  HIPCHK(c, dalloc(&c->d_rs_in, n * 960));
+  HIPCHK(c, dalloc(&c->d_rs_out, n * 960));
   c->cap = B;
   return 0;
 }
@@ -182,10 +201,11 @@ int code_warm_bytes(const char* kernel) {
   return 0;
 }
 
-enum { K_ENC_S0, K_ENC_S1, K_ENC_S2, K_RVQ_ENC, K_RVQ_DEC, K_DEC_S0, K_DEC_S1, K_DEC_S2, K_LOGMEL, K_COUNT };
+enum { K_ENC_S0, K_ENC_S1, K_ENC_S2, K_RVQ_ENC, K_RVQ_DEC, K_DEC_S0, K_DEC_S1, K_DEC_S2, K_LOGMEL, K_NOISE, K_RESAMPLE,
+       K_CNG, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"enc_s0_kernel", "enc_s1_kernel", "enc_s2_kernel", "rvq_encode_kernel",
                                            "rvq_decode_kernel", "dec_s0_kernel", "dec_s1_kernel", "dec_s2_kernel",
-                                           "logmel_kernel"};
+                                           "logmel_kernel", "noise_update_kernel", "resample_kernel", "cng_kernel"};
 
 hipEvent_t take_event(lyra_hip_ctx* c) {
   if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
@@ -286,10 +306,10 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
 }
 
 int launch_rvq_encode(lyra_hip_ctx* c, int k, int B, const float* d_feat, int num_stages, int32_t* d_idx,
-                      uint8_t* d_pkt) {
+                      uint8_t* d_pkt, const int32_t* d_mask_ids = nullptr, int32_t* d_pkt_bytes = nullptr) {
   { ProfScope ps(c, K_RVQ_ENC, c->se[k]);
     hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->se[k], c->model.cb, d_feat, B,
-                       num_stages, d_idx, d_pkt); }
+                       num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -328,7 +348,32 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
 int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
   { ProfScope ps(c, K_LOGMEL, c->sd[0]);
     hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, d_pcm, d_ids, B,
-                       c->sm.base[st::R_MEL], d_mel); }
+                       c->sm.base[st::R_MEL], (int)st::MEL_BYTES, (int)st::M_PREV, d_mel); }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// NoiseEstimator::ReceiveSamples for one full hop of B streams (noise_estimator.cc:144-173): the estimator's own log-mel
+// front end, then the decision + recurrence.  side 0 = encoder (DTX) on the encode-side stream, 1 = decoder.
+NoiseP noise_params() {
+  const float secs_per_hop = 320.f / 16000.f;
+  NoiseP p;
+  p.hops_per_update = (int)roundf(1.f / secs_per_hop);
+  p.max_smoothing = powf(0.5f, secs_per_hop / 0.7f);
+  p.bound_decay = powf(0.5f, secs_per_hop / 1.f);
+  return p;
+}
+int launch_noise(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_pcm, int32_t* d_is_noise,
+                 int32_t* d_masked_ids) {
+  hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
+  uint8_t* region = c->sm.base[side == 0 ? st::R_NOISE_E : st::R_NOISE_D];
+  float* mel = side == 0 ? c->d_mel_enc : c->d_mel;
+  { ProfScope ps(c, K_LOGMEL, st_);
+    hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), st_, c->model.d_mel, d_pcm, d_ids, B,
+                       region, (int)st::NOISE_BYTES, (int)st::N_PREV, mel); }
+  { ProfScope ps(c, K_NOISE, st_);
+    hipLaunchKernelGGL(noise_update_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st_, noise_params(), d_ids, B, region,
+                       (const float*)mel, d_is_noise, d_masked_ids); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -438,7 +483,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
       set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
-      set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess)
+      set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
   for (int i = 0; i < K_COUNT; ++i) c->cw[i] = code_warm_bytes(kKernelNames[i]);
   for (int k = 0; k < c->nsub; ++k)
@@ -626,6 +671,237 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
   return rc;
 }
 
+// host-pointer entry points: validate, bind the device, size the scratch, drain both streams
+#define PROLOGUE(c, B)                      \
+  int rc = check_batch(c, B);               \
+  if (rc) return rc;                        \
+  HIPCHK(c, hipSetDevice(c->device));       \
+  if ((rc = ensure_scratch(c, B))) return rc; \
+  if ((rc = sync_all(c))) return rc
+
+// ---- Resampler / ComfortNoiseGenerator ------------------------------------------------------------------
+// Kaiser-windowed-sinc polyphase table; the same construction as oracle/lyra_oracle.c lo_resampler_design
+// (audio_dsp::QResampler restated: cutoff 0.9 x the lower Nyquist, Kaiser beta 6, radius 17 input samples, unit DC gain).
+static double bessel_i0(double x) {
+  double sum = 1.0, term = 1.0;
+  for (int k = 1; k < 64; ++k) { term *= (x / (2.0 * k)) * (x / (2.0 * k)); sum += term; if (term < 1e-18 * sum) break; }
+  return sum;
+}
+static bool resample_design(int in_rate, int out_rate, ResampleP* P) {
+  static const int kRates[] = {8000, 16000, 32000, 48000};   // kSupportedSampleRates (lyra_config.h)
+  bool ok_in = false, ok_out = false;
+  for (int r : kRates) { ok_in |= r == in_rate; ok_out |= r == out_rate; }
+  if (!ok_in || !ok_out || (in_rate != 16000 && out_rate != 16000)) return false;
+  int a = in_rate, b = out_rate;
+  while (b) { int t = a % b; a = b; b = t; }
+  P->up = out_rate / a; P->down = in_rate / a;
+  const double PI = 3.14159265358979323846;
+  const int radius = st::RS_RADIUS, taps = st::RS_TAPS;
+  const double cutoff = 0.9 * 0.5 * (in_rate < out_rate ? in_rate : out_rate);
+  const double wc = 2.0 * cutoff / in_rate, beta = 6.0, i0b = bessel_i0(beta);
+  memset(P->coef, 0, sizeof P->coef);
+  for (int p = 0; p < P->up; ++p) {
+    double h[64], sum = 0.0;
+    for (int j = 0; j < taps; ++j) {
+      const double x = (double)(radius - j) + (double)p / P->up;
+      double v = 0.0;
+      if (fabs(x) <= radius) {
+        const double arg = PI * wc * x;
+        const double sinc = fabs(arg) < 1e-12 ? 1.0 : sin(arg) / arg;
+        const double y = x / radius;
+        v = wc * sinc * bessel_i0(beta * sqrt(1.0 - y * y)) / i0b;
+      }
+      h[j] = v; sum += v;
+    }
+    for (int j = 0; j < taps; ++j) P->coef[p][j] = (float)(h[j] / sum);
+  }
+  return true;
+}
+
+// side 0: the encoder's resampler slot (external rate -> 16 kHz, encode-side stream); 1: the decoder's (16 kHz -> external)
+int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
+                    int out_rate, int16_t* d_out, int* n_out_p) {
+  ResampleP P;
+  if (!resample_design(in_rate, out_rate, &P))
+    return fail(c, LYRA_HIP_EINVAL, "unsupported resampling %d -> %d Hz (one side must be 16000; 8000/16000/32000/48000)", in_rate, out_rate);
+  if (n_in <= 0 || n_in > 960 || n_in % P.down != 0)
+    return fail(c, LYRA_HIP_EINVAL, "resample: %d input samples per stream (must be 1..960 and a multiple of %d)", n_in, P.down);
+  const int n_out = n_in * P.up / P.down;
+  if (n_out > 960) return fail(c, LYRA_HIP_EINVAL, "resample: %d output samples per stream exceed 960", n_out);
+  hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
+  { ProfScope ps(c, K_RESAMPLE, st_);
+    hipLaunchKernelGGL(resample_kernel, dim3(B), dim3(256), (size_t)(st::RS_TAPS - 1 + n_in) * 4, st_, P, d_ids, B,
+                       c->sm.base[side == 0 ? st::R_RS_E : st::R_RS_D], d_in, n_in, d_out, n_out); }
+  HIPCHK(c, hipGetLastError());
+  if (n_out_p) *n_out_p = n_out;
+  return 0;
+}
+
+int launch_cng(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_features, int16_t* d_pcm) {
+  { ProfScope ps(c, K_CNG, c->sd[0]);
+    hipLaunchKernelGGL(cng_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, c->cng_seed, d_ids, B,
+                       c->sm.base[st::R_CNG], (const uint8_t*)c->sm.base[st::R_NOISE_D], d_features, d_pcm); }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int lyra_hip_resample_dev(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_in, int n_in,
+                          int in_rate, int out_rate, int16_t* d_out) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if ((side != 0 && side != 1) || !d_ids || !d_in || !d_out) return fail(c, LYRA_HIP_EINVAL, "bad side or null pointer");
+  DEVSCOPE(c);
+  if (side == 0) {
+    if ((rc = enc_side_begin(c, 0))) return rc;
+    rc = launch_resample(c, 0, d_ids, B, d_in, n_in, in_rate, out_rate, d_out, nullptr);
+    if (!rc) rc = enc_side_done(c, 0);
+    return rc;
+  }
+  if ((rc = dec_side_begin(c, 0))) return rc;
+  rc = launch_resample(c, 1, d_ids, B, d_in, n_in, in_rate, out_rate, d_out, nullptr);
+  if (!rc) rc = dec_side_done(c, 0, 1);
+  c->n_dec_calls++;
+  return rc;
+}
+
+int lyra_hip_resample(lyra_hip_ctx* c, int side, const int32_t* ids, int B, const int16_t* in, int n_in, int in_rate,
+                      int out_rate, int16_t* out) {
+  PROLOGUE(c, B);
+  if ((side != 0 && side != 1) || !in || !out) return fail(c, LYRA_HIP_EINVAL, "bad side or null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  if (n_in <= 0 || n_in > 960) return fail(c, LYRA_HIP_EINVAL, "resample: %d input samples per stream (1..960)", n_in);
+  hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
+  int32_t* dids = side == 0 ? c->d_ids : c->d_ids_dec;
+  HIPCHK(c, hipMemcpyAsync(dids, ids, (size_t)B * 4, hipMemcpyHostToDevice, st_));
+  HIPCHK(c, hipMemcpyAsync(c->d_rs_in, in, (size_t)B * n_in * 2, hipMemcpyHostToDevice, st_));
+  int n_out = 0;
+  if ((rc = launch_resample(c, side, dids, B, c->d_rs_in, n_in, in_rate, out_rate, c->d_rs_out, &n_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(out, c->d_rs_out, (size_t)B * n_out * 2, hipMemcpyDeviceToHost, st_));
+  if (side == 0 && (rc = enc_side_done(c, 0))) return rc;
+  HIPCHK(c, hipStreamSynchronize(st_));
+  return 0;
+}
+
+int lyra_hip_comfort_noise_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_features, int16_t* d_pcm) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if (!d_ids || !d_pcm) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  DEVSCOPE(c);
+  if ((rc = dec_side_begin(c, 0))) return rc;
+  rc = launch_cng(c, d_ids, B, d_features, d_pcm);
+  if (!rc) rc = dec_side_done(c, 0, 1);
+  c->n_dec_calls++;
+  return rc;
+}
+
+int lyra_hip_comfort_noise(lyra_hip_ctx* c, const int32_t* ids, int B, const float* features, int16_t* pcm) {
+  PROLOGUE(c, B);
+  if (!pcm) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  hipStream_t st_ = c->sd[0];
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, st_));
+  if (features) HIPCHK(c, hipMemcpyAsync(c->d_mel, features, (size_t)B * 160 * 4, hipMemcpyHostToDevice, st_));
+  if ((rc = launch_cng(c, c->d_ids_dec, B, features ? c->d_mel : nullptr, c->d_pcm_out))) return rc;
+  HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, st_));
+  HIPCHK(c, hipStreamSynchronize(st_));
+  return 0;
+}
+
+int lyra_hip_set_cng_seed(lyra_hip_ctx* c, uint64_t seed) {
+  if (!c) return LYRA_HIP_EINVAL;
+  c->cng_seed = seed;
+  return 0;
+}
+
+// ---- NoiseEstimator / DTX ---------------------------------------------------------------------------
+int lyra_hip_noise_receive_dev(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_pcm,
+                               int32_t* d_is_noise) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if ((side != 0 && side != 1) || !d_ids || !d_pcm || !d_is_noise) return fail(c, LYRA_HIP_EINVAL, "bad side or null pointer");
+  DEVSCOPE(c);
+  if ((rc = ensure_scratch(c, B))) return rc;
+  if (side == 0) {
+    if ((rc = enc_side_begin(c, 0))) return rc;
+    rc = launch_noise(c, 0, d_ids, B, d_pcm, d_is_noise, nullptr);
+    if (!rc) rc = enc_side_done(c, 0);
+    return rc;
+  }
+  if ((rc = dec_side_begin(c, 0))) return rc;
+  rc = launch_noise(c, 1, d_ids, B, d_pcm, d_is_noise, nullptr);
+  if (!rc) rc = dec_side_done(c, 0, 1);
+  c->n_dec_calls++;
+  return rc;
+}
+
+int lyra_hip_encode_dtx_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, int num_bits,
+                            uint8_t* d_packets, int32_t* d_packet_bytes) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if ((rc = check_bits(c, num_bits))) return rc;
+  if (!d_ids || !d_pcm || !d_packets || !d_packet_bytes) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  DEVSCOPE(c);
+  if ((rc = ensure_scratch(c, B))) return rc;
+  if ((rc = enc_side_begin(c, 0))) return rc;
+  // lyra_encoder.cc:131-141: the noise estimator sees every hop; only non-noise hops reach the feature extractor
+  rc = launch_noise(c, 0, d_ids, B, d_pcm, c->d_flag_enc, c->d_live_ids);
+  if (!rc) rc = launch_extract(c, 0, 0, c->d_live_ids, B, d_pcm, c->d_feat);
+  if (!rc) rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, nullptr, d_packets, c->d_live_ids, d_packet_bytes);
+  if (!rc) rc = enc_side_done(c, 0);
+  return rc;
+}
+
+int lyra_hip_noise_receive(lyra_hip_ctx* c, int side, const int32_t* ids, int B, const int16_t* pcm, int32_t* is_noise) {
+  PROLOGUE(c, B);
+  if ((side != 0 && side != 1) || !pcm || !is_noise) return fail(c, LYRA_HIP_EINVAL, "bad side or null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
+  int32_t* dids = side == 0 ? c->d_ids : c->d_ids_dec;
+  int16_t* dpcm = side == 0 ? c->d_pcm_in : c->d_pcm_out;
+  int32_t* dflag = side == 0 ? c->d_flag_enc : c->d_flag_dec;
+  HIPCHK(c, hipMemcpyAsync(dids, ids, (size_t)B * 4, hipMemcpyHostToDevice, st_));
+  HIPCHK(c, hipMemcpyAsync(dpcm, pcm, (size_t)B * 640, hipMemcpyHostToDevice, st_));
+  if ((rc = launch_noise(c, side, dids, B, dpcm, dflag, nullptr))) return rc;
+  HIPCHK(c, hipMemcpyAsync(is_noise, dflag, (size_t)B * 4, hipMemcpyDeviceToHost, st_));
+  if (side == 0 && (rc = enc_side_done(c, 0))) return rc;
+  HIPCHK(c, hipStreamSynchronize(st_));
+  return 0;
+}
+
+int lyra_hip_noise_estimate(lyra_hip_ctx* c, int side, const int32_t* ids, int B, float* estimate) {
+  PROLOGUE(c, B);
+  if ((side != 0 && side != 1) || !estimate) return fail(c, LYRA_HIP_EINVAL, "bad side or null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  hipStream_t st_ = c->sd[0];
+  HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, st_));
+  hipLaunchKernelGGL(noise_read_kernel, dim3(cdiv(B * 160, 256)), dim3(256), 0, st_, (const int32_t*)c->d_ids_dec, B,
+                     (const uint8_t*)c->sm.base[side == 0 ? st::R_NOISE_E : st::R_NOISE_D], (int)st::N_EST, c->d_mel);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(estimate, c->d_mel, (size_t)B * 160 * 4, hipMemcpyDeviceToHost, st_));
+  HIPCHK(c, hipStreamSynchronize(st_));
+  return 0;
+}
+
+int lyra_hip_encode_dtx(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, int num_bits, uint8_t* packets,
+                        int32_t* packet_bytes) {
+  PROLOGUE(c, B);
+  if ((rc = check_bits(c, num_bits))) return rc;
+  if (!pcm || !packets || !packet_bytes) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = check_ids_host(c, ids, B))) return rc;
+  const int nbytes = (num_bits + 7) / 8;
+  HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se[0]));
+  HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se[0]));
+  HIPCHK(c, hipMemsetAsync(c->d_pkt, 0, (size_t)B * nbytes, c->se[0]));   // empty packets read back as zeros
+  if ((rc = launch_noise(c, 0, c->d_ids, B, c->d_pcm_in, c->d_flag_enc, c->d_live_ids))) return rc;
+  if ((rc = launch_extract(c, 0, 0, c->d_live_ids, B, c->d_pcm_in, c->d_feat))) return rc;
+  if ((rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, nullptr, c->d_pkt, c->d_live_ids, c->d_pkt_bytes))) return rc;
+  HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->se[0]));
+  HIPCHK(c, hipMemcpyAsync(packet_bytes, c->d_pkt_bytes, (size_t)B * 4, hipMemcpyDeviceToHost, c->se[0]));
+  if ((rc = enc_side_done(c, 0))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->se[0]));
+  return 0;
+}
+
 // ---- ordering against a caller-owned stream (all library streams are non-blocking: they do NOT order
 //      against the null stream or any other stream by themselves) -----------------------------------------------
 int lyra_hip_wait_for_stream(lyra_hip_ctx* c, void* caller_stream) {
@@ -661,13 +937,6 @@ int lyra_hip_set_serial(lyra_hip_ctx* c, int on) {
 }
 
 // ---- host-pointer variants (synchronous) --------------------------------------------------------------------
-#define PROLOGUE(c, B)                      \
-  int rc = check_batch(c, B);               \
-  if (rc) return rc;                        \
-  HIPCHK(c, hipSetDevice(c->device));       \
-  if ((rc = ensure_scratch(c, B))) return rc; \
-  if ((rc = sync_all(c))) return rc
-
 int lyra_hip_extract(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, float* features) {
   PROLOGUE(c, B);
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");

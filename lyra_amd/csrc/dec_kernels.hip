@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   if (tid < SD0) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::D0_BYTES + st::PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::D0_BYTES + st::PHASE);
   }
   load_luts<NTD0>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NTD0, 1>(P.warm);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
   if (tid < SD1) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::D1_BYTES + st::PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::D1_BYTES + st::PHASE);
   }
   const auto warm = l2_warm<NTD1, 2>(P.warm);
   const auto warm_code = code_warm<NTD1>(code_bytes);

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   const auto warm = l2_warm<NT0, 1>(P.warm);
   const auto warm_code = code_warm<NT0>(code_bytes);
   __syncthreads();
-  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::E0_BYTES; };
-  auto valid = [&](int s) -> bool { return b0 + s < B; };
+  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)max(sids[s], 0) * st::E0_BYTES; };
+  auto valid = [&](int s) -> bool { return b0 + s < B && sids[s] >= 0; };   // id -1 = masked slot (TileCtx::valid)
 
   // The 5 history rows of the strided conv (needed only in phase D/E) are requested together with the PCM so
   // that their HBM latency is paid once, up front; they are parked in registers until the staging area is free.
@@ -210,13 +210,13 @@ __global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const E
   if (tid < S1) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::E1_BYTES + st::PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::E1_BYTES + st::PHASE);
   }
   const auto warm = l2_warm<NT1, 2>(P.warm);
   const auto warm_code = code_warm<NT1>(code_bytes);
   __syncthreads();
-  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)sids[s] * st::E1_BYTES; };
-  auto valid = [&](int s) -> bool { return b0 + s < B; };
+  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)max(sids[s], 0) * st::E1_BYTES; };
+  auto valid = [&](int s) -> bool { return b0 + s < B && sids[s] >= 0; };
 
   TileCtx cx{state, sids, sphase, B - b0, st::E1_BYTES};
   const auto H0 = hist128_prefetch<S1, NT1>(cx, 1, st::E_R1_0);   // first block's history: same round trip as the input

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
   if (tid < S2) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)id * st::E2_BYTES + st::PHASE);
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::E2_BYTES + st::PHASE);
   }
   load_luts<NT2>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NT2, 1>(P.warm);

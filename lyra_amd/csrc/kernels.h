@@ -65,13 +65,27 @@ size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg();
 
 // ---- RVQ / packets / log-mel / state ---------------------------------------------------------------
 // cb: codebooks, natural layout [46][16][64]
+// mask_ids (optional): frame i is skipped (empty packet, packet_bytes[i] = 0) where mask_ids[i] < 0
 __global__ void rvq_encode_kernel(const float* cb, const float* feats, int B, int num_stages, int32_t* indices,
-                                  uint8_t* packets);
+                                  uint8_t* packets, const int32_t* mask_ids, int32_t* packet_bytes);
 __global__ void rvq_decode_kernel(const float* cb, const int32_t* indices, const uint8_t* packets, int num_stages,
                                   int B, float* feats);
 struct MelP { const double* hann; const double* tw_re; const double* tw_im; const int* band; const double* w;
+              const double* wsum;   // [160] total forward weight of every mel band (comfort-noise inverse mel)
               int start, end; };
-__global__ void logmel_kernel(const MelP* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* mel);
+__global__ void logmel_kernel(const MelP* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, int stride,
+                              int prev_off, float* mel);
+// NoiseEstimator::Create's constants (noise_estimator.cc:96-124): round(1 s / 20 ms), 0.5^(20 ms / 0.7 s), 0.5^(20 ms / 1 s)
+struct NoiseP { int hops_per_update; float max_smoothing, bound_decay; };
+__global__ void noise_update_kernel(NoiseP P, const int32_t* ids, int B, uint8_t* state, const float* mel,
+                                    int32_t* is_noise_out, int32_t* masked_ids);
+// Resampler (lyra/resampler.cc): out/in = up/down, coef[phase][tap] oldest tap first (oracle lo_resampler_design)
+struct ResampleP { int up, down; float coef[3][40]; };
+__global__ void resample_kernel(ResampleP P, const int32_t* ids, int B, uint8_t* state, const int16_t* in, int n_in,
+                                int16_t* out, int n_out);
+__global__ void cng_kernel(const MelP* P, unsigned long long seed, const int32_t* ids, int B, uint8_t* state,
+                           const uint8_t* noise_state, const float* features, int16_t* pcm);
+__global__ void noise_read_kernel(const int32_t* ids, int B, const uint8_t* state, int field_off, float* out);
 size_t logmel_lds_bytes();
 struct ResetP { int8_t e_r2_1, e_r2_2, e_d2, e_bott, d_r0_0, d_r0_1, d_r0_2; };
 // region base pointers and per-stream slot sizes (state_layout.h), filled on the host, passed by value

@@ -28,7 +28,9 @@ namespace lyra {
 __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ cb,
                                                           const float* __restrict__ feats, int B, int num_stages,
                                                           int32_t* __restrict__ indices,
-                                                          uint8_t* __restrict__ packets) {
+                                                          uint8_t* __restrict__ packets,
+                                                          const int32_t* __restrict__ mask_ids,
+                                                          int32_t* __restrict__ packet_bytes) {
   constexpr int W = 8, ROW = 68, WFLOATS = W * 16 * ROW;   // 3 x 34 KB of LDS: one workgroup per CU anyway
   __shared__ __attribute__((aligned(16))) float cbs[3][WFLOATS];
   __shared__ __attribute__((aligned(16))) float rs[16][ROW];
@@ -36,6 +38,8 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
   const int j = tid & 15;
   const int frame = blockIdx.x * 16 + (tid >> 4);
   const int f = min(frame, B - 1);
+  // DTX (lyra_encoder.cc:136-141): a stream whose hop is noise gets an empty packet; mask_ids[frame] < 0 marks it
+  const bool live = frame < B && !(mask_ids && mask_ids[f] < 0);
   const int ldrow = tid >> 4, ldc4 = tid & 15;  // this thread's float4 of each stage's [16][64] codebook
   const f32x4 LYRA_GLOBAL* cbg = reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(cb)) + ldrow * 16 + ldc4;
   f32x4 stage_in[W];
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
       mine = mine - t2;
       *reinterpret_cast<f32x4*>(&rme[j * 4]) = mine;
     }
-    if (j == 0 && frame < B) {
+    if (j == 0 && live) {
       if (indices) indices[(size_t)frame * 46 + k] = best;
       if (packets) {
         if (k & 1) packets[(size_t)frame * nbytes + (k >> 1)] = (uint8_t)(cur | best);
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
     stage(k, rowa, rowb);
     if (k + 1 < num_stages) stage(k + 1, rowb, rowa);
   }
-  if (j == 0 && frame < B) {
+  if (j == 0 && frame < B && packet_bytes) packet_bytes[frame] = live ? nbytes : 0;
+  if (j == 0 && live) {
     if (packets && (num_stages & 1)) packets[(size_t)frame * nbytes + (num_stages >> 1)] = (uint8_t)cur;
     if (indices)
       for (int k = num_stages; k < 46; ++k) indices[(size_t)frame * 46 + k] = -1;
@@ -164,9 +169,12 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const float* __restrict
 // =============================================================================================
 size_t logmel_lds_bytes() { return (size_t)(1024 * 2 + 520) * 8; }
 
+// `state` / `stride` / `prev_off`: where the previous hop of each stream lives -- the plugin-level extractor's own
+// region (R_MEL) or the slot of one of the two NoiseEstimators (R_NOISE_E / R_NOISE_D own their extractor).
 __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                       const int32_t* __restrict__ ids, int B,
-                                                      uint8_t* __restrict__ state, float* __restrict__ mel) {
+                                                      uint8_t* __restrict__ state, int stride, int prev_off,
+                                                      float* __restrict__ mel) {
   const MelP& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* re = dsm;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
   double* mag = dsm + 2048;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  int16_t* prev = reinterpret_cast<int16_t*>(state + (size_t)ids[b] * st::MEL_BYTES + st::M_PREV);
+  int16_t* prev = reinterpret_cast<int16_t*>(state + (size_t)ids[b] * stride + prev_off);
   for (int i = tid; i < 1024; i += 256) {
     double v = 0.0;
     if (i < 320) v = (double)prev[i] * P.hann[i];
@@ -212,6 +220,255 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
     v = v > 500.f ? v : 500.f;
     mel[(size_t)b * 160 + tid] = __builtin_logf(v) / 10.f;
   }
+}
+
+// =============================================================================================
+// NoiseEstimator::ReceiveSamples after the log-mel (lyra/noise_estimator.cc:161-173): ComputeIsNoise, then
+// DecayBounds or UpdateNoiseEstimate (SmoothingFactor, UpdateMinAndTemp, ComputeBounds), for one hop of B streams.
+// One wavefront per stream, lane l owns bins l, l + 64, l + 128 (< 160).  Same float operations in the same order
+// as the reference; the two Average() sums are sequential (std::accumulate from 0.f) and run on one lane out of
+// LDS.  std::exp(float) is evaluated as float(exp(double)): a <= 1 ULP double result rounds to the correctly rounded
+// float, which is what the host libm returns.  masked_ids (optional): ids[i], or -1 where the hop is noise -- the
+// stream list the DTX-enabled encoder runs on (lyra_encoder.cc:131-141).
+// =============================================================================================
+__device__ __forceinline__ float expf_via_double(float x) { return (float)exp((double)x); }
+
+__global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32_t* __restrict__ ids, int B,
+                                                            uint8_t* __restrict__ state, const float* __restrict__ mel,
+                                                            int32_t* __restrict__ is_noise_out,
+                                                            int32_t* __restrict__ masked_ids) {
+  __shared__ float sh[4][2][160];
+  __shared__ float avg[4][2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + w;
+  const bool on = b < B;
+  const int id = ids[on ? b : B - 1];
+  uint8_t* base = state + (size_t)id * st::NOISE_BYTES;
+  int* hdr = reinterpret_cast<int*>(base);
+  float* f_smooth = reinterpret_cast<float*>(base + st::N_SMOOTH);
+  float* f_sq = reinterpret_cast<float*>(base + st::N_SQ);
+  float* f_tmp = reinterpret_cast<float*>(base + st::N_TMPMIN);
+  float* f_est = reinterpret_cast<float*>(base + st::N_EST);
+  float* f_bound = reinterpret_cast<float*>(base + st::N_BOUND);
+  float cur[3], est[3], bound[3];
+  bool differs = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int bin = lane + 64 * i;
+    cur[i] = est[i] = bound[i] = 0.f;
+    if (bin < 160) {
+      cur[i] = mel[(size_t)(on ? b : B - 1) * 160 + bin];
+      est[i] = f_est[bin];
+      bound[i] = f_bound[bin];
+      differs = differs || (__builtin_fabsf(cur[i] - est[i]) > bound[i]);
+    }
+  }
+  const bool is_noise = __builtin_amdgcn_ballot_w64(differs) == 0ull;   // ComputeIsNoise (wave-uniform)
+  const int initialised = hdr[st::N_INIT / 4];
+  const int hops = hdr[st::N_HOPS / 4];
+  float sm[3], sq[3], tm[3];
+  if (!is_noise) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int bin = lane + 64 * i;
+      sm[i] = sq[i] = tm[i] = 0.f;
+      if (bin < 160) {
+        if (initialised) { sm[i] = f_smooth[bin]; sq[i] = f_sq[bin]; tm[i] = f_tmp[bin]; }
+        else { sm[i] = cur[i]; sq[i] = cur[i] * cur[i]; tm[i] = cur[i]; }   // first update (noise_estimator.cc:180-186)
+        sh[w][0][bin] = sm[i];
+        sh[w][1][bin] = cur[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (!is_noise && lane < 2) {   // Average(): sequential float sum from 0.f, then / 160
+    float a = 0.f;
+    for (int i = 0; i < 160; ++i) a = a + sh[w][lane][i];
+    avg[w][lane] = a / 160.f;
+  }
+  __syncthreads();
+  if (!on) return;
+  if (is_noise) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int bin = lane + 64 * i;
+      if (bin < 160) f_bound[bin] = bound[i] * P.bound_decay;   // DecayBounds
+    }
+  } else {
+    const float kPowDiff = 0.3f;
+    const float dd = (avg[w][0] - avg[w][1]) / kPowDiff;
+    const float correction = expf_via_double(-(dd * dd));
+    const double logn = 5.075173815233827;   // std::log(160) in double (noise_bound_.size())
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int bin = lane + 64 * i;
+      if (bin < 160) {
+        const float de = (sm[i] - est[i]) / kPowDiff;
+        const float sf = P.max_smoothing * correction * expf_via_double(-(de * de));
+        const float c2 = cur[i] * cur[i];
+        const float nsm = sf * sm[i] + (1.f - sf) * cur[i];   // (-ffp-contract=off: every product rounded)
+        const float nsq = sf * sq[i] + (1.f - sf) * c2;
+        float nest, ntm;
+        if (hops == 0) { nest = __builtin_fminf(tm[i], nsm); ntm = nsm; }                      // UpdateMinAndTemp
+        else { nest = __builtin_fminf(est[i], nsm); ntm = __builtin_fminf(tm[i], nsm); }
+        float var = nsq - nsm * nsm;
+        var = var > 0.f ? var : 0.f;
+        f_smooth[bin] = nsm; f_sq[bin] = nsq; f_tmp[bin] = ntm; f_est[bin] = nest;
+        f_bound[bin] = (float)((double)0.9f * __builtin_sqrt((double)var * logn));            // ComputeBounds
+      }
+    }
+  }
+  if (lane == 0) {
+    if (!is_noise) {
+      hdr[st::N_INIT / 4] = 1;
+      hdr[st::N_HOPS / 4] = (hops + 1) % P.hops_per_update;
+    }
+    hdr[st::N_IS_NOISE / 4] = is_noise ? 1 : 0;
+    if (is_noise_out) is_noise_out[b] = is_noise ? 1 : 0;
+    if (masked_ids) masked_ids[b] = is_noise ? -1 : id;
+  }
+}
+
+// noise_estimate() / noise_bound() of B streams -> dense [B][160] (NoiseEstimator::noise_estimate, :229-231)
+__global__ __launch_bounds__(256) void noise_read_kernel(const int32_t* __restrict__ ids, int B,
+                                                          const uint8_t* __restrict__ state, int field_off,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * 160) return;
+  const int b = i / 160, bin = i - b * 160;
+  out[i] = reinterpret_cast<const float*>(state + (size_t)ids[b] * st::NOISE_BYTES + field_off)[bin];
+}
+
+// =============================================================================================
+// Resampler::Resample (lyra/resampler.cc:57-62): audio_dsp::QResampler<float> restated as a polyphase FIR sampled from
+// a Kaiser-windowed sinc (oracle/lyra_oracle.c lo_resampler_design builds the same table; parity statement there).
+// One workgroup per stream: [34 history samples | n_in new samples] as floats in LDS, one output per thread and
+// iteration, taps oldest first in float -- bitwise the oracle's loop.  up-sampling: `up` outputs per input sample;
+// down-sampling: one output per `down` inputs, phase carried in the stream's slot.
+// =============================================================================================
+__global__ __launch_bounds__(256) void resample_kernel(ResampleP P, const int32_t* __restrict__ ids, int B,
+                                                        uint8_t* __restrict__ state, const int16_t* __restrict__ in,
+                                                        int n_in, int16_t* __restrict__ out, int n_out) {
+  extern __shared__ __attribute__((aligned(16))) float rsb[];   // [RS_TAPS - 1 + n_in]
+  constexpr int H = st::RS_TAPS - 1;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  uint8_t* slot = state + (size_t)ids[b] * st::RS_BYTES;
+  float* hist = reinterpret_cast<float*>(slot + st::RS_HIST);
+  const int in_pos = *reinterpret_cast<const int*>(slot + st::RS_IN_POS);
+  for (int i = tid; i < H + n_in; i += 256) rsb[i] = i < H ? hist[i] : (float)in[(size_t)b * n_in + (i - H)];
+  __syncthreads();
+  // first input index (0-based in this call) that yields an output when decimating
+  const int first = P.down == 1 ? 0 : ((P.down - in_pos % P.down) % P.down);
+  for (int o = tid; o < n_out; o += 256) {
+    int k, p;
+    if (P.down == 1) { k = o / P.up; p = o - k * P.up; }
+    else { k = first + o * P.down; p = 0; }
+    float acc = 0.f;
+#pragma unroll 5
+    for (int j = 0; j < st::RS_TAPS; ++j) acc = acc + P.coef[p][j] * rsb[k + j];
+    acc = acc < -32768.f ? -32768.f : (acc > 32767.f ? 32767.f : acc);   // ClipToInt16 (dsp_utils.h:56-72)
+    out[(size_t)b * n_out + o] = (int16_t)acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < H; i += 256) hist[i] = rsb[n_in + i];
+  if (tid == 0) *reinterpret_cast<int*>(slot + st::RS_IN_POS) = (in_pos + n_in) % (1 << 20);   // (multiple of every `down`)
+}
+
+// =============================================================================================
+// ComfortNoiseGenerator::AddFeatures + GenerateSamples(320) (lyra/comfort_noise_generator.cc:74-119): log-mel -> mel ->
+// estimated FFT magnitudes -> random phase -> inverse STFT (FFT 1024, step 320) -> ClipToInt16.  Restated construction,
+// counter-based phases, parity statement in oracle/lyra_oracle.c (lo_cng_generate) -- this kernel follows that function
+// operation by operation in fp64 (same radix-2 butterflies and host-built twiddles as the log-mel kernel).
+// features == nullptr: the stream's decoder-side noise estimate is used (lyra_decoder.cc:328-340).
+// =============================================================================================
+__device__ __forceinline__ unsigned long long splitmix64_dev(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void cng_kernel(const MelP* __restrict__ Pp, unsigned long long seed,
+                                                   const int32_t* __restrict__ ids, int B,
+                                                   uint8_t* __restrict__ state, const uint8_t* __restrict__ noise_state,
+                                                   const float* __restrict__ features, int16_t* __restrict__ pcm) {
+  const MelP& P = *Pp;
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* re = dsm;
+  double* im = dsm + 1024;
+  double* mel = dsm + 2048;   // [160], then unused
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int id = ids[b];
+  uint8_t* slot = state + (size_t)id * st::CNG_BYTES;
+  const unsigned long long hop = *reinterpret_cast<const unsigned long long*>(slot + st::C_HOP);
+  double* ola = reinterpret_cast<double*>(slot + st::C_OLA);
+  const float* feat = features ? features + (size_t)b * 160
+                               : reinterpret_cast<const float*>(noise_state + (size_t)id * st::NOISE_BYTES + st::N_EST);
+  if (tid < 160) mel[tid] = (double)(float)exp((double)(feat[tid] * 10.f));   // std::exp(float * kNorm), float
+  for (int i = tid; i < 1024; i += 256) { re[i] = 0.0; im[i] = 0.0; }
+  __syncthreads();
+  const double PI = 3.14159265358979323846;
+  const double gain = __builtin_sqrt(1024.0 * 320.0 / (384.0 * 240.0));
+  const unsigned long long sd = seed ^ (unsigned long long)(unsigned)id;
+  for (int i = P.start + tid; i <= P.end; i += 256) {
+    // band[v + 1] = first bin whose lower band is >= v: find this bin's lower band ch (-1 .. 159)
+    int lo = 0, hi = 161;   // band index domain v + 1
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (P.band[mid] <= i) lo = mid; else hi = mid; }
+    const int ch = lo - 1;
+    const double w = P.w[i];
+    double v = 0.0;
+    if (ch >= 0 && P.wsum[ch] > 0.0) v += w * mel[ch] / P.wsum[ch];
+    if (ch + 1 < 160 && P.wsum[ch + 1] > 0.0) v += (1.0 - w) * mel[ch + 1] / P.wsum[ch + 1];
+    const unsigned long long r = splitmix64_dev(sd ^ splitmix64_dev(hop * 1024ull + (unsigned long long)i));
+    const double ang = (double)(r >> 11) * (1.0 / 9007199254740992.0) * 2.0 * PI;
+    const double a = v * gain;
+    const double xr = a * cos(ang), xi = a * sin(ang);
+    // inverse DFT through the forward butterflies: conj in, conj out; inputs go to bit-reversed positions
+    const int r0 = __brev((unsigned)i) >> 22;
+    re[r0] = xr; im[r0] = (i == 0 || i == 512) ? 0.0 : -xi;
+    if (i > 0 && i < 512) { const int r1 = __brev((unsigned)(1024 - i)) >> 22; re[r1] = xr; im[r1] = xi; }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int p = 1; p <= 10; ++p) {
+    const int len = 1 << p, half = len >> 1;
+    for (int bf = tid; bf < 512; bf += 256) {
+      int grp = bf >> (p - 1), k = bf & (half - 1);
+      int i0 = grp * len + k, i1 = i0 + half;
+      double wr = P.tw_re[half - 1 + k], wi = P.tw_im[half - 1 + k];
+      double ur = re[i0], ui = im[i0];
+      double xr = re[i1], xi = im[i1];
+      double vr = xr * wr - xi * wi;
+      double vi = xr * wi + xi * wr;
+      re[i0] = ur + vr; im[i0] = ui + vi;
+      re[i1] = ur - vr; im[i1] = ui - vi;
+    }
+    __syncthreads();
+  }
+  // window, overlap-add, emit the first 320 samples, shift the accumulator by one hop
+  double acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = tid + 256 * q;
+    const double x = re[n] / 1024.0;
+    const double v = 0.5 - 0.5 * cos(2.0 * PI * n / 1024.0);
+    acc[q] = ola[n] + x * v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = tid + 256 * q;
+    if (n < 320) {
+      double y = acc[q];
+      y = y < -32768.0 ? -32768.0 : (y > 32767.0 ? 32767.0 : y);   // ClipToInt16<double>
+      pcm[(size_t)b * 320 + n] = (int16_t)y;
+    } else {
+      re[n - 320] = acc[q];   // staging for the shifted write-back
+    }
+  }
+  __syncthreads();
+  for (int n = tid; n < 1024; n += 256) ola[n] = n < 1024 - 320 ? re[n] : 0.0;
+  if (tid == 0) *reinterpret_cast<unsigned long long*>(slot + st::C_HOP) = hop + 1;
 }
 
 // =============================================================================================

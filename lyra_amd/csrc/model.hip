@@ -523,6 +523,13 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
     B.put(&M->mel.tw_im, twi);
     B.put(&M->mel.band, first);
     B.put(&M->mel.w, w);
+    std::vector<double> wsum(NB, 0.0);   // total forward weight per band (MelFilterbank two-tap scatter)
+    for (int i = start; i <= end; ++i) {
+      int ch = band[i];
+      if (ch >= 0) wsum[ch] += w[i];
+      if (ch + 1 < NB) wsum[ch + 1] += 1.0 - w[i];
+    }
+    B.put(&M->mel.wsum, wsum);
     M->mel.start = start;
     M->mel.end = end;
   }

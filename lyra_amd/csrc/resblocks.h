@@ -16,8 +16,10 @@ struct TileCtx {
   const int* sphase;   // LDS: frame phase of each tile slot (may be null when no ring is used)
   int nvalid;          // slots < nvalid are real streams
   int stride;          // bytes per stream in this region
-  __device__ __forceinline__ uint8_t* sbase(int s) const { return state + (size_t)sids[s] * stride; }
-  __device__ __forceinline__ bool valid(int s) const { return s < nvalid; }
+  // A stream id of -1 masks a slot (DTX: the hop is noise, the encoder must not run for that stream,
+  // lyra_encoder.cc:131-141): it reads stream 0's state like a tail slot reads the last stream's, and writes nothing.
+  __device__ __forceinline__ uint8_t* sbase(int s) const { return state + (size_t)max(sids[s], 0) * stride; }
+  __device__ __forceinline__ bool valid(int s) const { return s < nvalid && sids[s] >= 0; }
 };
 
 // ---- 64 channels x 20 rows; S streams per workgroup of NT threads: (S, NT) = (4, 256) or (8, 512) -------------

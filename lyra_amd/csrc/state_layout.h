@@ -25,7 +25,7 @@ constexpr int PHASE = 0;       // uint32, first word of a region slot (regions w
 constexpr int HDR = 64;
 constexpr int align256(int n) { return (n + 255) / 256 * 256; }
 
-enum Region { R_E0, R_E1, R_E2, R_D0, R_D1, R_D2, R_MEL, R_NOISE_E, R_NOISE_D, R_COUNT };
+enum Region { R_E0, R_E1, R_E2, R_D0, R_D1, R_D2, R_MEL, R_NOISE_E, R_NOISE_D, R_RS_E, R_RS_D, R_CNG, R_COUNT };
 
 // ---- R_E0: encoder stage 0 (enc_s0_kernel) ---------------------------------------------------------
 constexpr int E_FIRST = 0;                         // f32[48] natural order
@@ -90,9 +90,23 @@ constexpr int N_EST = N_TMPMIN + 160 * 4;          // f32[160] noise_estimate_
 constexpr int N_BOUND = N_EST + 160 * 4;           // f32[160] noise_bound_
 constexpr int NOISE_BYTES = align256(N_BOUND + 160 * 4);
 
+// ---- R_RS_E / R_RS_D: the encoder's (external rate -> 16 kHz) and the decoder's (16 kHz -> external rate) Resampler
+//      (lyra/resampler.h; one per codec object) ------------------------------------------------------------------------
+constexpr int RS_RADIUS = 17;                      // kernel radius in input samples (resampler.cc:33-38)
+constexpr int RS_TAPS = 2 * RS_RADIUS + 1;
+constexpr int RS_IN_POS = 0;                       // int32: input samples consumed so far (decimation phase)
+constexpr int RS_HIST = 16;                        // f32[34]: the last RS_TAPS - 1 input samples
+constexpr int RS_BYTES = align256(RS_HIST + (RS_TAPS - 1) * 4);
+
+// ---- R_CNG: ComfortNoiseGenerator (lyra/comfort_noise_generator.h): overlap-add tail of the inverse STFT --------------
+constexpr int C_HOP = 0;                           // uint64: hops generated (random-phase counter)
+constexpr int C_OLA = 64;                          // f64[1024] overlap-add accumulator, [0, 320) = next hop
+constexpr int CNG_BYTES = align256(C_OLA + 1024 * 8);
+
 constexpr int REGION_BYTES[R_COUNT] = {E0_BYTES, E1_BYTES, E2_BYTES, D0_BYTES, D1_BYTES, D2_BYTES, MEL_BYTES,
-                                        NOISE_BYTES, NOISE_BYTES};
-constexpr int BYTES = E0_BYTES + E1_BYTES + E2_BYTES + D0_BYTES + D1_BYTES + D2_BYTES + MEL_BYTES + 2 * NOISE_BYTES;
+                                        NOISE_BYTES, NOISE_BYTES, RS_BYTES, RS_BYTES, CNG_BYTES};
+constexpr int BYTES = E0_BYTES + E1_BYTES + E2_BYTES + D0_BYTES + D1_BYTES + D2_BYTES + MEL_BYTES + 2 * NOISE_BYTES +
+                      2 * RS_BYTES + CNG_BYTES;
 
 static_assert(E_R0_0 % 16 == 0 && E_R1_0 % 16 == 0 && E_R2_1 % 16 == 0 && D_HEAD % 16 == 0 && D_R0_0 % 16 == 0 &&
                   D_UP1 % 16 == 0 && D_R1_0 % 16 == 0 && D_UP3 % 16 == 0,

@@ -930,12 +930,12 @@ static void fft1024(double* re, double* im) {
   }
 }
 
-void lo_logmel(const lo_model* m, lo_stream* s, const int16_t* pcm, float* mel) {
+static void logmel_core(const lo_model* m, double* prev, const int16_t* pcm, float* mel) {
   double re[MEL_FFT], im[MEL_FFT];
   memset(re, 0, sizeof re);
   memset(im, 0, sizeof im);
-  for (int i = 0; i < 320; ++i) re[i] = s->mel_prev[i] * m->hann[i];
-  for (int i = 0; i < 320; ++i) { double v = (double)pcm[i]; re[320 + i] = v * m->hann[320 + i]; s->mel_prev[i] = v; }
+  for (int i = 0; i < 320; ++i) re[i] = prev[i] * m->hann[i];
+  for (int i = 0; i < 320; ++i) { double v = (double)pcm[i]; re[320 + i] = v * m->hann[320 + i]; prev[i] = v; }
   fft1024(re, im);
   double out[MEL_BANDS];
   memset(out, 0, sizeof out);
@@ -952,6 +952,103 @@ void lo_logmel(const lo_model* m, lo_stream* s, const int16_t* pcm, float* mel) 
     v = v > 500.f ? v : 500.f;
     mel[b] = logf(v) / 10.f;
   }
+}
+
+void lo_logmel(const lo_model* m, lo_stream* s, const int16_t* pcm, float* mel) { logmel_core(m, s->mel_prev, pcm, mel); }
+
+/* ------------------------------------------------------------------------ */
+/* NoiseEstimator (lyra/noise_estimator.cc:36-245): minimum statistics over the  */
+/* 160-bin log-mel of every hop; is_noise() drives the encoder's DTX decision   */
+/* (lyra_encoder.cc:131-141) and noise_estimate() feeds the decoder's comfort   */
+/* noise (lyra_decoder.cc:328-340).  All arithmetic in float as in the reference */
+/* (std::exp / std::pow float overloads; std::log(size_t) and the sqrt around it */
+/* are double, noise_estimator.cc:203-214); no FP contraction.                   */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int num_hops_per_update;   /* round(1 s / 20 ms) = 50 (noise_estimator.cc:113-121) */
+  float max_smoothing, bound_decay;
+  int initialised;           /* smoothed_power_ non-empty */
+  int num_hops_received;
+  int is_noise;
+  double mel_prev[320];      /* the estimator owns its log-mel extractor, hence its own previous hop */
+  float smoothed[MEL_BANDS], squared[MEL_BANDS], tmp_min[MEL_BANDS], estimate[MEL_BANDS], bound[MEL_BANDS];
+} lo_noise;
+
+lo_noise* lo_noise_new(int num_hops_per_update, float max_smoothing, float bound_decay) {
+  lo_noise* n = (lo_noise*)calloc(1, sizeof(lo_noise));
+  const float secs_per_hop = 320.f / 16000;   /* kNumSecondsPerHop */
+  n->num_hops_per_update = num_hops_per_update > 0 ? num_hops_per_update : (int)roundf(1.f / secs_per_hop);
+  n->max_smoothing = max_smoothing > 0.f ? max_smoothing : powf(0.5f, secs_per_hop / 0.7f);
+  n->bound_decay = bound_decay > 0.f ? bound_decay : powf(0.5f, secs_per_hop / 1.f);
+  n->is_noise = 1;                            /* noise_estimator.cc:139 */
+  return n;
+}
+void lo_noise_free(lo_noise* n) { free(n); }
+
+static float average160(const float* v) {     /* std::accumulate(..., 0.f) / size */
+  float a = 0.f;
+  for (int i = 0; i < MEL_BANDS; ++i) a = a + v[i];
+  return a / (float)MEL_BANDS;
+}
+static float squaref(float x) { return x * x; }
+
+int lo_noise_compute_is_noise(const lo_noise* n, const float* cur) {   /* noise_estimator.cc:216-227 */
+  for (int i = 0; i < MEL_BANDS; ++i)
+    if (fabsf(cur[i] - n->estimate[i]) > n->bound[i]) return 0;
+  return 1;
+}
+
+void lo_noise_update(lo_noise* n, const float* cur) {                  /* UpdateNoiseEstimate, :175-214 */
+  if (!n->initialised) {
+    n->initialised = 1;
+    for (int i = 0; i < MEL_BANDS; ++i) { n->smoothed[i] = cur[i]; n->squared[i] = squaref(cur[i]); n->tmp_min[i] = cur[i]; }
+  }
+  const float kPowDiff = 0.3f;
+  const float correction = expf(-squaref((average160(n->smoothed) - average160(cur)) / kPowDiff));
+  for (int i = 0; i < MEL_BANDS; ++i) {
+    const float sf = n->max_smoothing * correction * expf(-squaref((n->smoothed[i] - n->estimate[i]) / kPowDiff));
+    /* each product rounded before the sum: volatile-free because the oracle is built with -ffp-contract=off */
+    const float a = sf * n->smoothed[i], b = (1.f - sf) * cur[i];
+    const float c = sf * n->squared[i], d = (1.f - sf) * squaref(cur[i]);
+    n->smoothed[i] = a + b;
+    n->squared[i] = c + d;
+  }
+  if (n->num_hops_received == 0) {            /* UpdateMinAndTemp, :52-63 */
+    for (int i = 0; i < MEL_BANDS; ++i) {
+      n->estimate[i] = fminf(n->tmp_min[i], n->smoothed[i]);
+      n->tmp_min[i] = n->smoothed[i];
+    }
+  } else {
+    for (int i = 0; i < MEL_BANDS; ++i) {
+      n->estimate[i] = fminf(n->estimate[i], n->smoothed[i]);
+      n->tmp_min[i] = fminf(n->tmp_min[i], n->smoothed[i]);
+    }
+  }
+  const double logn = log((double)MEL_BANDS);   /* std::log(noise_bound_.size()) */
+  for (int i = 0; i < MEL_BANDS; ++i) {         /* ComputeBounds */
+    float var = n->squared[i] - squaref(n->smoothed[i]);
+    var = var > 0.f ? var : 0.f;
+    n->bound[i] = (float)((double)0.9f * sqrt((double)var * logn));
+  }
+  n->num_hops_received = (n->num_hops_received + 1) % n->num_hops_per_update;
+}
+
+/* ReceiveSamples for one full hop (:144-173): log-mel, decision, then decay or update.  Returns is_noise. */
+int lo_noise_receive(const lo_model* m, lo_noise* n, const int16_t* pcm, float* mel_out) {
+  float mel[MEL_BANDS];
+  logmel_core(m, n->mel_prev, pcm, mel);
+  if (mel_out) memcpy(mel_out, mel, sizeof mel);
+  n->is_noise = lo_noise_compute_is_noise(n, mel);
+  if (n->is_noise) {
+    for (int i = 0; i < MEL_BANDS; ++i) n->bound[i] = n->bound[i] * n->bound_decay;   /* DecayBounds */
+  } else {
+    lo_noise_update(n, mel);
+  }
+  return n->is_noise;
+}
+void lo_noise_get(const lo_noise* n, float* estimate, float* bound) {
+  if (estimate) memcpy(estimate, n->estimate, sizeof n->estimate);
+  if (bound) memcpy(bound, n->bound, sizeof n->bound);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1051,4 +1148,187 @@ void lo_rvq_encode_batch(const lo_model* m, const float* feats, long n, int num_
     pthread_create(&th[t], NULL, rvq_worker, &jobs[t]);
   }
   for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Resampler (lyra/resampler.cc:30-66): audio_dsp::QResampler<float>, kernel     */
+/* radius 17 input samples scaled by min(1, out/in), ResetFullyPrimed.            */
+/* audio_dsp is an un-vendored dependency (WORKSPACE:68-78, mchinen fork          */
+/* @14a45c5): its published design is restated here -- a polyphase FIR sampled    */
+/* from a Kaiser-windowed sinc, QResamplerParams defaults cutoff_proportion 0.9   */
+/* and kaiser_beta 6.0, unit DC gain per phase, zero initial state so that the    */
+/* output is delayed by `radius` input samples.  PARITY UNPINNED beyond what       */
+/* lyra/resampler_test.cc holds (sample counts, zeros in -> zeros out, 16k ->     */
+/* 32k -> 16k round trip delayed by 17 + floor(17 / 2) samples within +-25).      */
+/* float coefficients, float accumulation, taps oldest first.                      */
+/* ------------------------------------------------------------------------ */
+#define RS_MAX_TAPS 40
+#define RS_MAX_PHASES 3
+typedef struct {
+  int in_rate, out_rate;
+  int up, down;             /* out/in = up/down in lowest terms (1/2, 2, 3, 1) */
+  int radius;               /* input samples */
+  int taps;                 /* 2 * radius + 1 */
+  float coef[RS_MAX_PHASES][RS_MAX_TAPS];   /* per output phase, oldest tap first */
+  float hist[2 * RS_MAX_TAPS];              /* last `taps - 1` input samples */
+  long in_pos;              /* input samples consumed so far (phase bookkeeping for `down`) */
+} lo_resampler;
+
+static double bessel_i0(double x) {
+  double sum = 1.0, term = 1.0;
+  for (int k = 1; k < 64; ++k) { term *= (x / (2.0 * k)) * (x / (2.0 * k)); sum += term; if (term < 1e-18 * sum) break; }
+  return sum;
+}
+static int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+/* coefficient tables shared with the GPU path (lyra_amd/csrc builds the same table with the same code) */
+void lo_resampler_design(int in_rate, int out_rate, int* up, int* down, int* radius, float* coef /*[3][40]*/) {
+  const double PI = 3.14159265358979323846;
+  int g = igcd(in_rate, out_rate);
+  *up = out_rate / g; *down = in_rate / g;
+  /* radius: filter_radius_factor * max(1, in/out) input samples with factor 17 * min(1, out/in) -> 17 either way */
+  *radius = 17;
+  const int taps = 2 * *radius + 1;
+  const double cutoff = 0.9 * 0.5 * (in_rate < out_rate ? in_rate : out_rate);   /* Hz */
+  const double wc = 2.0 * cutoff / in_rate;                                       /* cycles per input sample x 2 */
+  const double beta = 6.0, i0b = bessel_i0(beta);
+  for (int p = 0; p < *up; ++p) {
+    /* output m = k * up + p sits at input time k + p / up - radius; tap j multiplies x[k - (taps - 1) + j],
+       i.e. the kernel is evaluated at t = (radius - j) + p / up ... centred on the delayed output instant */
+    double sum = 0.0, h[RS_MAX_TAPS];
+    for (int j = 0; j < taps; ++j) {
+      const double x = (double)(*radius - j) + (double)p / *up;      /* distance output instant -> tap, input samples */
+      double v = 0.0;
+      if (fabs(x) <= *radius) {
+        const double a = PI * wc * x;
+        const double sinc = fabs(a) < 1e-12 ? 1.0 : sin(a) / a;
+        const double y = x / *radius;
+        v = wc * sinc * bessel_i0(beta * sqrt(1.0 - y * y)) / i0b;
+      }
+      h[j] = v; sum += v;
+    }
+    for (int j = 0; j < RS_MAX_TAPS; ++j) coef[p * RS_MAX_TAPS + j] = j < taps ? (float)(h[j] / sum) : 0.f;
+  }
+}
+
+lo_resampler* lo_resampler_new(int in_rate, int out_rate) {
+  lo_resampler* r = (lo_resampler*)calloc(1, sizeof(lo_resampler));
+  r->in_rate = in_rate; r->out_rate = out_rate;
+  lo_resampler_design(in_rate, out_rate, &r->up, &r->down, &r->radius, &r->coef[0][0]);
+  r->taps = 2 * r->radius + 1;
+  return r;
+}
+void lo_resampler_free(lo_resampler* r) { free(r); }
+void lo_resampler_reset(lo_resampler* r) { memset(r->hist, 0, sizeof r->hist); r->in_pos = 0; }
+
+/* Resampler::Resample: n_in samples in, returns the number of output samples written (n_in * up / down when n_in is a
+   multiple of `down`, as every hop size of the codec is). */
+int lo_resample(lo_resampler* r, const int16_t* in, int n_in, int16_t* out) {
+  const int T = r->taps, H = T - 1;
+  float buf[H + 8192];
+  if (n_in > 8192) return -1;
+  memcpy(buf, r->hist, sizeof(float) * H);
+  for (int i = 0; i < n_in; ++i) buf[H + i] = (float)in[i];
+  int n_out = 0;
+  if (r->down == 1) {                      /* integer up-sampling (or 1:1 copy through the same filter bank) */
+    for (int k = 0; k < n_in; ++k)
+      for (int p = 0; p < r->up; ++p) {
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) acc = acc + r->coef[p][j] * buf[k + j];
+        acc = acc < -32768.f ? -32768.f : (acc > 32767.f ? 32767.f : acc);   /* ClipToInt16 (dsp_utils.h:56-72) */
+        out[n_out++] = (int16_t)acc;
+      }
+  } else {                                 /* integer down-sampling: one output per `down` inputs */
+    for (int k = 0; k < n_in; ++k) {
+      if ((r->in_pos + k) % r->down != 0) continue;
+      float acc = 0.f;
+      for (int j = 0; j < T; ++j) acc = acc + r->coef[0][j] * buf[k + j];
+      acc = acc < -32768.f ? -32768.f : (acc > 32767.f ? 32767.f : acc);
+      out[n_out++] = (int16_t)acc;
+    }
+  }
+  memcpy(r->hist, buf + n_in, sizeof(float) * H);
+  r->in_pos += n_in;
+  return n_out;
+}
+
+/* ------------------------------------------------------------------------ */
+/* ComfortNoiseGenerator (lyra/comfort_noise_generator.cc:74-119): log-mel ->     */
+/* mel -> estimated squared-magnitude FFT (MelFilterbank::EstimateInverse) ->     */
+/* random phase -> InverseSpectrogram (FFT 1024, step 320) -> ClipToInt16.         */
+/* MelFilterbank / InverseSpectrogram are audio_dsp classes (un-vendored) and the  */
+/* phase comes from a non-deterministic absl::BitGen: the reference's output is a  */
+/* random process, so this is a restatement of the published construction with a   */
+/* counter-based generator, PINNED ONLY STATISTICALLY by the reference's own tests  */
+/* (comfort_noise_generator_test.cc:83-140, noise_estimator_test.cc:129-173).       */
+/*  * inverse mel: bin i between band centres ch and ch+1 gets                      */
+/*      w_i * mel[ch] / W[ch] + (1 - w_i) * mel[ch+1] / W[ch+1],  W[c] = total      */
+/*    forward weight of band c (a locally flat spectrum round-trips);               */
+/*  * inverse STFT: irfft-1024 of the random-phase spectrum, periodic Hann          */
+/*    synthesis window, overlap-add at step 320, scaled so that the 640-sample      */
+/*    Hann analysis of the output has the prescribed magnitude in expectation.      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  uint64_t seed;            /* context seed ^ stream id */
+  uint64_t hop;             /* hops generated */
+  double ola[MEL_FFT];      /* overlap-add accumulator; ola[0..319] is the next hop */
+} lo_cng;
+
+static uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+lo_cng* lo_cng_new(uint64_t seed) { lo_cng* c = (lo_cng*)calloc(1, sizeof(lo_cng)); c->seed = seed; return c; }
+void lo_cng_free(lo_cng* c) { free(c); }
+
+/* total forward weight per mel band (lazily, from the same tables as the log-mel front end) */
+static void mel_band_weights(const lo_model* m, double* W) {
+  for (int c = 0; c < MEL_BANDS; ++c) W[c] = 0.0;
+  for (int i = m->mel_start; i <= m->mel_end; ++i) {
+    int ch = m->mel_band[i];
+    if (ch >= 0) W[ch] += m->mel_w[i];
+    if (ch + 1 < MEL_BANDS) W[ch + 1] += 1.0 - m->mel_w[i];
+  }
+}
+
+/* AddFeatures + GenerateSamples(320): one hop of comfort noise for log-mel features[160] */
+void lo_cng_generate(const lo_model* m, lo_cng* c, const float* features, int16_t* out) {
+  const double PI = 3.14159265358979323846;
+  double mel[MEL_BANDS], W[MEL_BANDS], re[MEL_FFT], im[MEL_FFT];
+  for (int i = 0; i < MEL_BANDS; ++i) mel[i] = (double)expf(features[i] * 10.f);   /* std::exp(float * kNorm) */
+  mel_band_weights(m, W);
+  /* scale: synthesis Hann (sum v^2 = 384) overlap-added at step 320, analysed by the 640-sample Hann (sum w^2 = 240):
+     E|STFT|^2 = A^2 * 384 / (1024 * 320) * 240  =>  A = M * sqrt(1024 * 320 / (384 * 240)) */
+  const double gain = sqrt(1024.0 * 320.0 / (384.0 * 240.0));
+  memset(re, 0, sizeof re); memset(im, 0, sizeof im);
+  for (int i = m->mel_start; i <= m->mel_end; ++i) {
+    const int ch = m->mel_band[i];
+    double v = 0.0;
+    if (ch >= 0 && W[ch] > 0.0) v += m->mel_w[i] * mel[ch] / W[ch];
+    if (ch + 1 < MEL_BANDS && W[ch + 1] > 0.0) v += (1.0 - m->mel_w[i]) * mel[ch + 1] / W[ch + 1];
+    const uint64_t r = splitmix64(c->seed ^ splitmix64(c->hop * 1024 + (uint64_t)i));
+    const double ang = (double)(r >> 11) * (1.0 / 9007199254740992.0) * 2.0 * PI;   /* U[0, 2 pi) */
+    const double a = v * gain;
+    re[i] = a * cos(ang); im[i] = a * sin(ang);
+    if (i > 0 && i < MEL_FFT / 2) { re[MEL_FFT - i] = re[i]; im[MEL_FFT - i] = -im[i]; }   /* Hermitian: real output */
+  }
+  im[0] = 0.0; im[MEL_FFT / 2] = 0.0;
+  /* inverse DFT through the forward routine: conj -> fft -> conj, / N */
+  for (int i = 0; i < MEL_FFT; ++i) im[i] = -im[i];
+  fft1024(re, im);
+  for (int n = 0; n < MEL_FFT; ++n) {
+    const double x = re[n] / MEL_FFT;
+    const double v = 0.5 - 0.5 * cos(2.0 * PI * n / MEL_FFT);
+    c->ola[n] += x * v;
+  }
+  for (int n = 0; n < 320; ++n) {
+    double y = c->ola[n];
+    y = y < -32768.0 ? -32768.0 : (y > 32767.0 ? 32767.0 : y);    /* ClipToInt16<double> */
+    out[n] = (int16_t)y;
+  }
+  memmove(c->ola, c->ola + 320, sizeof(double) * (MEL_FFT - 320));
+  memset(c->ola + MEL_FFT - 320, 0, sizeof(double) * 320);
+  c->hop += 1;
 }

@@ -45,6 +45,23 @@ def lib():
         L.lo_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.lo_rvq_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.lo_rvq_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_noise_new.restype = C.c_void_p
+        L.lo_noise_new.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.lo_noise_free.argtypes = [C.c_void_p]
+        L.lo_noise_compute_is_noise.argtypes = [C.c_void_p, C.c_void_p]
+        L.lo_noise_update.argtypes = [C.c_void_p, C.c_void_p]
+        L.lo_noise_receive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_noise_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_resampler_new.restype = C.c_void_p
+        L.lo_resampler_new.argtypes = [C.c_int, C.c_int]
+        L.lo_resampler_free.argtypes = [C.c_void_p]
+        L.lo_resampler_reset.argtypes = [C.c_void_p]
+        L.lo_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.lo_resampler_design.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_cng_new.restype = C.c_void_p
+        L.lo_cng_new.argtypes = [C.c_uint64]
+        L.lo_cng_free.argtypes = [C.c_void_p]
+        L.lo_cng_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.lo_rvq_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_int]
         L.lo_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.lo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -165,6 +182,92 @@ class Stream:
         mel = np.empty(160, np.float32)
         self.L.lo_logmel(self.o.h, self.h, _p(pcm), _p(mel))
         return mel
+
+
+class NoiseEstimator:
+    """lyra/noise_estimator.{h,cc}: one instance per encoder (DTX) or decoder stream."""
+
+    def __init__(self, oracle, num_hops_per_update=0, max_smoothing=0.0, bound_decay=0.0):
+        self.o = oracle
+        self.L = oracle.L
+        self.h = self.L.lo_noise_new(num_hops_per_update, max_smoothing, bound_decay)
+
+    def __del__(self):
+        try:
+            self.L.lo_noise_free(self.h)
+        except Exception:
+            pass
+
+    def ReceiveSamples(self, pcm):
+        """One full hop (320 samples) -> is_noise; also returns the hop's log-mel."""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        assert pcm.size == 320
+        mel = np.empty(160, np.float32)
+        return bool(self.L.lo_noise_receive(self.o.h, self.h, _p(pcm), _p(mel))), mel
+
+    def UpdateNoiseEstimate(self, mel):
+        mel = np.ascontiguousarray(mel, np.float32)
+        self.L.lo_noise_update(self.h, _p(mel))
+
+    def ComputeIsNoise(self, mel):
+        mel = np.ascontiguousarray(mel, np.float32)
+        return bool(self.L.lo_noise_compute_is_noise(self.h, _p(mel)))
+
+    def noise_estimate(self):
+        est = np.empty(160, np.float32)
+        self.L.lo_noise_get(self.h, _p(est), None)
+        return est
+
+    def noise_bound(self):
+        b = np.empty(160, np.float32)
+        self.L.lo_noise_get(self.h, None, _p(b))
+        return b
+
+
+class Resampler:
+    """lyra/resampler.{h,cc}: Create(input_rate, target_rate) + Resample(int16 span)."""
+
+    def __init__(self, in_rate, out_rate):
+        self.L = lib()
+        self.h = self.L.lo_resampler_new(in_rate, out_rate)
+        self.in_rate, self.out_rate = in_rate, out_rate
+
+    def __del__(self):
+        try:
+            self.L.lo_resampler_free(self.h)
+        except Exception:
+            pass
+
+    def Reset(self):
+        self.L.lo_resampler_reset(self.h)
+
+    def Resample(self, audio):
+        audio = np.ascontiguousarray(audio, np.int16)
+        out = np.empty(audio.size * max(1, self.out_rate // self.in_rate) + 8, np.int16)
+        n = self.L.lo_resample(self.h, _p(audio), audio.size, _p(out))
+        assert n >= 0
+        return out[:n].copy()
+
+
+class ComfortNoiseGenerator:
+    """lyra/comfort_noise_generator.{h,cc}: one hop of noise per AddFeatures(log-mel[160])."""
+
+    def __init__(self, oracle, seed=0):
+        self.o, self.L = oracle, oracle.L
+        self.h = self.L.lo_cng_new(seed)
+
+    def __del__(self):
+        try:
+            self.L.lo_cng_free(self.h)
+        except Exception:
+            pass
+
+    def generate(self, features):
+        features = np.ascontiguousarray(features, np.float32)
+        assert features.size == 160
+        out = np.empty(320, np.int16)
+        self.L.lo_cng_generate(self.o.h, self.h, _p(features), _p(out))
+        return out
 
 
 def run_batch(oracle, pcm, num_stages, do_decode=True, threads=1, want_feats=False):
