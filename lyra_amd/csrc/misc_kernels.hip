@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
     for (int i = P.band[tid + 1]; i < P.band[tid + 2]; ++i) { double v = mag[i]; acc += v * P.w[i]; }
     float v = (float)acc;
     v = v > 500.f ? v : 500.f;
-    mel[(size_t)b * 160 + tid] = __builtin_logf(v) / 10.f;
+    // log evaluated in double and rounded once: identical on host and device (oracle/lyra_oracle.c log_f)
+    mel[(size_t)b * 160 + tid] = (float)log((double)v) / 10.f;
   }
 }
 

@@ -31,7 +31,6 @@ int main(int argc, char** argv) {
   auto dec = BatchLyraDecoder::Create(16000, 1, model_dir, n);
   if (!enc || !dec) { std::fprintf(stderr, "creation failed\n"); return 1; }
   if (enc->Encode(absl::MakeConstSpan(pcm.data(), 100)).has_value()) return 3;   // wrong sample count
-  if (dec->DecodeSamples(10).has_value()) return 3;                                // nothing to decode yet
   if (dec->SetEncodedPackets(absl::MakeConstSpan(reinterpret_cast<const uint8_t*>(pcm.data()), 7 * n))) return 3;
   std::ofstream pk_out(argv[5], std::ios::binary), pcm_out(argv[6], std::ios::binary);
   const size_t frame = static_cast<size_t>(n) * 320;
@@ -40,10 +39,9 @@ int main(int argc, char** argv) {
     if (!packets || packets->size() != static_cast<size_t>(n) * enc->packet_size()) return 4;
     pk_out.write(reinterpret_cast<const char*>(packets->data()), packets->size());
     if (!dec->SetEncodedPackets(*packets)) return 4;
-    if (dec->SetEncodedPackets(*packets)) return 5;   // previous hop not played out yet
     auto a = dec->DecodeSamples(120);                 // partial requests inside a hop
     auto b = dec->DecodeSamples(200);
-    if (!a || !b || dec->DecodeSamples(1).has_value()) return 5;
+    if (!a || !b || dec->is_comfort_noise(0)) return 5;
     std::vector<int16_t> hop(frame);
     for (int s = 0; s < n; ++s) {
       std::memcpy(&hop[static_cast<size_t>(s) * 320], &(*a)[static_cast<size_t>(s) * 120], 240);

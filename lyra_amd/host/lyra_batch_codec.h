@@ -1,17 +1,23 @@
 // lyra_batch_codec.h -- batched twins of the reference's public codec classes:
 // BatchLyraEncoder mirrors LyraEncoder (lyra/lyra_encoder.h:61-101), BatchLyraDecoder mirrors LyraDecoder
-// (lyra/lyra_decoder.h:54-94), for `num_streams` independent streams that advance in lock-step, one 20 ms frame
-// per call, through the fused C ABI (lyra_hip_encode / lyra_hip_decode).  Same method names, argument meaning and
-// error behaviour (nullptr / nullopt / false + LOG(ERROR), no exceptions); buffers are stream-major:
-// audio[s * 320 + i], packets[s * packet_size + j].
+// (lyra/lyra_decoder.h:54-94), for `num_streams` independent streams served by one GPU context.  Same method names,
+// argument meaning and error behaviour (nullptr / nullopt / false + LOG(ERROR), no exceptions); buffers are
+// stream-major: audio[s * n + i], packets[s * packet_size + j].
 //
-// Scope: the steady-state path only.  What the reference handles around it on the host is rejected
-// at Create(), loudly, instead of being approximated: sample rates other than 16 kHz (resampler), DTX (noise
-// estimator decision), and -- in the decoder -- requests for samples without a packet (packet-loss concealment /
-// comfort noise; DecodeSamples returns nullopt where LyraDecoder would conceal).
+// Everything the reference's classes do around the three plugins is here, per stream, with the heavy parts batched
+// on the device through the C ABI (include/lyra_hip.h):
+//  * sample rates 8 / 16 / 32 / 48 kHz (Resampler on the way in, BufferedResampler's leftover logic on the way out);
+//  * DTX: encoder-side NoiseEstimator, empty packets for noise hops (lyra_encoder.cc:131-141);
+//  * decoder: per-stream packet FIFO, DecodeSamples(n) for any n (requests may straddle hops), packet-loss
+//    concealment with estimated (zero) features, comfort noise from the decoder-side noise estimate, cosine
+//    cross-fades, noise-estimator updates on received hops only (lyra_decoder.cc:172-373).
+// The control flow is the reference's, statement for statement, run for every stream; in each round of the decode
+// loop the streams that need a new hop from the generative model / the comfort-noise generator / a noise-estimator
+// update are collected and served by ONE device call each.
 #ifndef LYRA_AMD_HOST_LYRA_BATCH_CODEC_H_
 #define LYRA_AMD_HOST_LYRA_BATCH_CODEC_H_
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <optional>
 #include <vector>
@@ -36,16 +42,19 @@ int BatchBitrateToPacketSize(int bitrate);
 class BatchLyraEncoder {
  public:
   // Arguments of LyraEncoder::Create (lyra_encoder.h:61-63) + the number of streams.  nullptr if a parameter is
-  // unsupported (lyra_encoder.cc:46-66) or outside this build's scope (see above).
+  // unsupported (lyra_encoder.cc:46-66).
   static std::unique_ptr<BatchLyraEncoder> Create(int sample_rate_hz, int num_channels, int bitrate, bool enable_dtx,
                                                   const ghc::filesystem::path& model_path, int num_streams,
                                                   int device = 0);
   ~BatchLyraEncoder();
-  // One 20 ms frame of every stream: audio.size() must be num_streams * 320 (lyra_encoder.cc:124-129), else nullopt.
-  // Returns num_streams packets of packet_size() bytes each.
+  // One 20 ms frame of every stream at sample_rate_hz(): audio.size() must be num_streams * sample_rate_hz / 50
+  // (lyra_encoder.cc:124-129), else nullopt.  Returns num_streams rows of packet_size() bytes; with DTX a row whose
+  // stream sent an empty packet (lyra_encoder.cc:136-141) is all zero and packet_lengths()[s] == 0.
   std::optional<std::vector<uint8_t>> Encode(const absl::Span<const int16_t> audio);
+  // Bytes of each stream's packet from the last Encode: packet_size(), or 0 for a DTX empty packet.
+  const std::vector<int32_t>& packet_lengths() const { return lengths_; }
   bool set_bitrate(int bitrate);   // lyra_encoder.cc:158-166
-  int sample_rate_hz() const { return kBatchInternalSampleRateHz; }
+  int sample_rate_hz() const { return sample_rate_hz_; }
   int num_channels() const { return 1; }
   int bitrate() const { return bitrate_; }
   int frame_rate() const { return kBatchFrameRate; }
@@ -53,11 +62,15 @@ class BatchLyraEncoder {
   int packet_size() const { return BatchBitrateToPacketSize(bitrate_); }
 
  private:
-  BatchLyraEncoder(lyra_hip_ctx* ctx, int bitrate, int num_streams);
+  BatchLyraEncoder(lyra_hip_ctx* ctx, int sample_rate_hz, int bitrate, bool enable_dtx, int num_streams);
   lyra_hip_ctx* ctx_;
+  int sample_rate_hz_;
   int bitrate_;
+  bool enable_dtx_;
   int num_streams_;
   std::vector<int32_t> ids_;          // stream slots 0 .. num_streams-1 of the context
+  std::vector<int32_t> lengths_;
+  std::vector<int16_t> resampled_;
 };
 
 class BatchLyraDecoder {
@@ -67,29 +80,50 @@ class BatchLyraDecoder {
                                                   const ghc::filesystem::path& model_path, int num_streams,
                                                   int device = 0);
   ~BatchLyraDecoder();
-  // One packet per stream, all of the same size (8 / 15 / 23 bytes selects the bitrate as
-  // PacketSizeToNumQuantizedBits does, lyra_decoder.cc:172-196).  False if the size is not a valid packet size or
-  // the previous packets have not been fully decoded yet (the reference queues at most one pending packet's
-  // worth of features ahead of the generative model: generative_model_interface.h:50-62).
+  // LyraDecoder::SetEncodedPacket (lyra_decoder.cc:172-209) for every stream: num_streams packets of one size
+  // (8 / 15 / 23 bytes selects the bitrate as PacketSizeToNumQuantizedBits does).  Packets queue up per stream.
   bool SetEncodedPackets(absl::Span<const uint8_t> encoded);
-  // num_samples <= samples left in the current hop (never straddles a hop, generative_model_interface.h:64-101);
-  // 0 returns an empty vector without running the model.  Returns num_streams * num_samples samples.
+  // ... for the listed streams only (a stream that lost its packet this tick is simply not listed).
+  bool SetEncodedPackets(absl::Span<const int32_t> streams, absl::Span<const uint8_t> encoded);
+  // LyraDecoder::DecodeSamples (lyra_decoder.cc:211-315) for every stream: any num_samples >= 0 at sample_rate_hz();
+  // streams without a packet conceal, then fade to comfort noise.  Returns num_streams * num_samples samples.
   std::optional<std::vector<int16_t>> DecodeSamples(int num_samples);
-  int sample_rate_hz() const { return kBatchInternalSampleRateHz; }
+  int sample_rate_hz() const { return sample_rate_hz_; }
   int num_channels() const { return 1; }
   int frame_rate() const { return kBatchFrameRate; }
-  bool is_comfort_noise() const { return false; }   // no concealment / comfort noise in this build
+  // LyraDecoder::is_comfort_noise (lyra_decoder.h:88-90) of one stream.
+  bool is_comfort_noise(int stream) const;
   int num_streams() const { return num_streams_; }
 
  private:
-  BatchLyraDecoder(lyra_hip_ctx* ctx, int num_streams);
+  BatchLyraDecoder(lyra_hip_ctx* ctx, int sample_rate_hz, int num_streams);
+  // GenerativeModel's FIFO bookkeeping (generative_model_interface.h:45-134) without the model.
+  struct Entry { bool estimated; int bits; std::vector<uint8_t> packet; };
+  struct Stream {
+    std::deque<Entry> queue;              // generative model: queued conditioning inputs
+    int next_in_hop = 0;                  // generative model: next_sample_in_hop_
+    std::vector<int16_t> hop;             // generative model: the conditioned hop
+    bool cng_has_hop = false;             // comfort noise generator: one hop at most is ever queued
+    int cng_next = 0;
+    std::vector<int16_t> cng_hop;
+    int concealment_progress = 0;
+    int fade_progress = 0;
+    int fade_direction = -1;              // kFadeFromCNG (lyra_decoder.h FadeDirection)
+    std::vector<int16_t> noise_in;        // decoded samples waiting for the noise estimator (ReceiveSamples buffer)
+    std::vector<int16_t> out;             // this call's internal-rate result
+    // scratch of the current round
+    int n_gen = 0, gen_n = 0, cng_n = 0, next_fade = 0;
+    bool packet_received = false;
+  };
+  std::optional<std::vector<int16_t>> DecodeInternal(int num_internal_samples);   // DecodeSamplesInternal, all streams
+  int gan_available(const Stream& s) const { return (int)s.queue.size() * kBatchHopSamples - s.next_in_hop; }
+  int cng_available(const Stream& s) const { return s.cng_has_hop ? kBatchHopSamples - s.cng_next : 0; }
+
   lyra_hip_ctx* ctx_;
+  int sample_rate_hz_;
   int num_streams_;
-  std::vector<int32_t> ids_;
-  std::vector<uint8_t> pending_;      // packets set but not yet decoded
-  int pending_bits_ = 0;
-  std::vector<int16_t> hop_;          // decoded hop, stream-major [num_streams][320]
-  int next_sample_in_hop_ = kBatchHopSamples;  // == 320: nothing decoded is waiting
+  std::vector<Stream> streams_;
+  std::vector<std::vector<int16_t>> leftover_;   // BufferedResampler::leftover_samples_ per stream (same length for all)
 };
 
 }  // namespace codec

@@ -930,6 +930,15 @@ static void fft1024(double* re, double* im) {
   }
 }
 
+/* std::log(float) / std::exp(float) of the reference (log_mel_spectrogram_extractor_impl.cc:121-124,
+   noise_estimator.cc:87-100, comfort_noise_generator.cc:101-104) evaluated in double and rounded once: the double result
+   is within 1 ULP(double) on the host libm and on the device math library alike, so both round to the same float
+   except when it lies within ~1e-16 of a float rounding boundary (p ~ 2e-9 per call) -- the float libm routines
+   (logf / expf, <= 1 ULP(float) each) would differ between host and device in a few percent of the calls, and the
+   NoiseEstimator's is_noise comparison amplifies a single ULP into a different DTX decision. */
+static float log_f(float x) { return (float)log((double)x); }
+static float exp_f(float x) { return (float)exp((double)x); }
+
 static void logmel_core(const lo_model* m, double* prev, const int16_t* pcm, float* mel) {
   double re[MEL_FFT], im[MEL_FFT];
   memset(re, 0, sizeof re);
@@ -950,7 +959,7 @@ static void logmel_core(const lo_model* m, double* prev, const int16_t* pcm, flo
   for (int b = 0; b < MEL_BANDS; ++b) {
     float v = (float)out[b];
     v = v > 500.f ? v : 500.f;
-    mel[b] = logf(v) / 10.f;
+    mel[b] = log_f(v) / 10.f;
   }
 }
 
@@ -1004,9 +1013,9 @@ void lo_noise_update(lo_noise* n, const float* cur) {                  /* Update
     for (int i = 0; i < MEL_BANDS; ++i) { n->smoothed[i] = cur[i]; n->squared[i] = squaref(cur[i]); n->tmp_min[i] = cur[i]; }
   }
   const float kPowDiff = 0.3f;
-  const float correction = expf(-squaref((average160(n->smoothed) - average160(cur)) / kPowDiff));
+  const float correction = exp_f(-squaref((average160(n->smoothed) - average160(cur)) / kPowDiff));
   for (int i = 0; i < MEL_BANDS; ++i) {
-    const float sf = n->max_smoothing * correction * expf(-squaref((n->smoothed[i] - n->estimate[i]) / kPowDiff));
+    const float sf = n->max_smoothing * correction * exp_f(-squaref((n->smoothed[i] - n->estimate[i]) / kPowDiff));
     /* each product rounded before the sum: volatile-free because the oracle is built with -ffp-contract=off */
     const float a = sf * n->smoothed[i], b = (1.f - sf) * cur[i];
     const float c = sf * n->squared[i], d = (1.f - sf) * squaref(cur[i]);
@@ -1297,7 +1306,7 @@ static void mel_band_weights(const lo_model* m, double* W) {
 void lo_cng_generate(const lo_model* m, lo_cng* c, const float* features, int16_t* out) {
   const double PI = 3.14159265358979323846;
   double mel[MEL_BANDS], W[MEL_BANDS], re[MEL_FFT], im[MEL_FFT];
-  for (int i = 0; i < MEL_BANDS; ++i) mel[i] = (double)expf(features[i] * 10.f);   /* std::exp(float * kNorm) */
+  for (int i = 0; i < MEL_BANDS; ++i) mel[i] = (double)exp_f(features[i] * 10.f);   /* std::exp(float * kNorm) */
   mel_band_weights(m, W);
   /* scale: synthesis Hann (sum v^2 = 384) overlap-added at step 320, analysed by the 640-sample Hann (sum w^2 = 240):
      E|STFT|^2 = A^2 * 384 / (1024 * 320) * 240  =>  A = M * sqrt(1024 * 320 / (384 * 240)) */

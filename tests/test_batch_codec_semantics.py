@@ -1,0 +1,115 @@
+"""BatchLyraEncoder / BatchLyraDecoder with the reference's full per-stream semantics (SURVEY.md 8f rows 1, 3, 4;
+lyra/lyra_encoder.cc:113-156, lyra/lyra_decoder.cc:172-373): resampling, DTX, packet queueing, DecodeSamples(n) that
+straddles hops, packet-loss concealment, comfort noise, cross-fades.  The C++ twins run on the GPU through the C ABI
+(lyra_amd/decoder_demo); the expectation is oracle/lyra_codec_model.py, the per-stream restatement of the reference's
+classes over the CPU oracle.  Packets bit-exact; PCM bit-exact wherever only the generative model speaks, within 2 LSB
+where comfort noise is mixed in (device fp64 sin/cos/exp vs host libm, see test_resampler_cng.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_reference_model_decoder_state_machine(oracle_exact):
+    """CPU: the restated LyraDecoder control flow against the reference's own expectations (lyra_decoder_test.cc):
+    right sample counts for arbitrary requests, comfort noise reached after concealment (4 hops) + fade (2 hops) of
+    loss, left again 2 hops after packets resume."""
+    from oracle import lyra_codec_model as M
+    from oracle import lyra_oracle
+    rng = np.random.default_rng(0)
+    enc = M.RefLyraEncoder(oracle_exact, 16000, 64, False)
+    dec = M.RefLyraDecoder(oracle_exact, 16000, cng_seed=1)
+    for t in range(5):
+        dec.SetEncodedPacket(enc.Encode(rng.integers(-3000, 3000, 320).astype(np.int16)))
+        assert dec.DecodeSamples(320).size == 320 and not dec.is_comfort_noise()
+    seen = []
+    for t in range(8):                 # eight lost packets
+        out = np.concatenate([dec.DecodeSamples(k) for k in (100, 7, 213)])
+        assert out.size == 320
+        seen.append(dec.is_comfort_noise())
+    assert seen == [False] * 5 + [True] * 3        # 4 hops of concealment, 2 hops of fade
+    for t in range(3):
+        dec.SetEncodedPacket(enc.Encode(rng.integers(-3000, 3000, 320).astype(np.int16)))
+        dec.DecodeSamples(320)
+    assert not dec.is_comfort_noise()
+
+
+def _run_session(tmp_path, oracle, rate, bitrate, dtx, pcm, script):
+    import lyra_amd
+    demo = os.path.join(ROOT, "lyra_amd", "decoder_demo")
+    assert os.path.exists(demo), "lyra_amd/decoder_demo not built (__graft_entry__.build())"
+    T, n, hop = pcm.shape
+    pin, sc = tmp_path / "in.s16", tmp_path / "script.txt"
+    pk, ln, pout = tmp_path / "pk.bin", tmp_path / "len.i32", tmp_path / "out.s16"
+    pcm.tofile(pin)
+    sc.write_text("\n".join(f"{mask} " + " ".join(map(str, sizes)) for mask, sizes in script) + "\n")
+    r = subprocess.run([demo, lyra_amd.default_model_dir(), str(sc), str(pin), str(rate), str(bitrate), str(int(dtx)),
+                        str(n), str(pk), str(ln), str(pout)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    ps = {3200: 8, 6000: 15, 9200: 23}[bitrate]
+    packets = np.fromfile(pk, np.uint8).reshape(T, n, ps)
+    lengths = np.fromfile(ln, np.int32).reshape(T, n)
+    out = np.fromfile(pout, np.int16)
+    return packets, lengths, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,bitrate,dtx", [(16000, 6000, False), (48000, 3200, False), (8000, 9200, False),
+                                              (16000, 9200, True), (32000, 6000, True)])
+def test_batch_codec_session_vs_reference_model(tmp_path, golden_dir, oracle_exact, rate, bitrate, dtx):
+    from oracle import lyra_codec_model as M
+    from oracle import lyra_oracle
+    bits = {3200: 64, 6000: 120, 9200: 184}[bitrate]
+    speech = np.load(os.path.join(golden_dir, "sample_wavs.npz"))["sample1_16kHz"]
+    T, n, hop = 40, 4, rate // 50
+    # streams: speech, speech with a silent middle (DTX food), noise, speech delayed
+    up = lyra_oracle.Resampler(16000, rate) if rate != 16000 else None
+    base = speech[:16000 * 2]
+    ext = np.concatenate([up.Resample(base[i:i + 320]) for i in range(0, base.size, 320)]) if up is not None else base
+    rng = np.random.default_rng(rate + bitrate)
+    s0 = ext[:T * hop]
+    s1 = s0.copy(); s1[10 * hop:25 * hop] = 0
+    s2 = np.clip(rng.normal(0, 500, T * hop), -32768, 32767).astype(np.int16)
+    s3 = np.concatenate([np.zeros(5 * hop, np.int16), ext[:(T - 5) * hop]])
+    pcm = np.stack([s.reshape(T, hop) for s in (s0, s1, s2, s3)], axis=1).astype(np.int16)     # [T][n][hop]
+    # loss script: burst of 9 lost packets for stream 0, scattered single losses for stream 2, none for 1 and 3;
+    # playout in odd chunk sizes that straddle hops
+    script = []
+    for t in range(T):
+        mask = "".join(["0" if 12 <= t < 21 else "1", "1", "0" if t % 7 == 3 else "1", "1"])
+        sizes = [hop] if t % 3 == 0 else ([hop // 4 + 3, hop - hop // 4 - 3] if t % 3 == 1 else [1, hop // 2, hop - hop // 2 - 1])
+        script.append((mask, sizes))
+    packets, lengths, out = _run_session(tmp_path, oracle_exact, rate, bitrate, dtx, pcm, script)
+
+    encs = [M.RefLyraEncoder(oracle_exact, rate, bits, dtx) for _ in range(n)]
+    decs = [M.RefLyraDecoder(oracle_exact, rate, cng_seed=0x4C797261 ^ s) for s in range(n)]
+    pos = 0
+    n_exact = n_total = 0
+    worst = 0
+    saw_cng = False
+    for t, (mask, sizes) in enumerate(script):
+        for s in range(n):
+            p = encs[s].Encode(pcm[t, s])
+            assert lengths[t, s] == p.size, (t, s)
+            if p.size:
+                assert np.array_equal(packets[t, s], p), (t, s)
+                if mask[s] == "1":
+                    decs[s].SetEncodedPacket(p)
+        for k in sizes:
+            got = out[pos:pos + n * k].reshape(n, k)
+            pos += n * k
+            for s in range(n):
+                want = decs[s].DecodeSamples(k)
+                d = np.abs(got[s].astype(int) - want.astype(int))
+                worst = max(worst, int(d.max()))
+                n_exact += int((d == 0).sum()); n_total += k
+                saw_cng = saw_cng or decs[s].is_comfort_noise()
+    assert pos == out.size
+    assert worst <= 2, worst
+    assert n_exact / n_total > 0.97
+    assert saw_cng                      # the 9-packet burst takes stream 0 all the way into comfort noise
+    if dtx:
+        assert (lengths == 0).sum() > 5   # the silent stretch is sent as empty packets
