@@ -347,8 +347,8 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
 
 int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
   { ProfScope ps(c, K_LOGMEL, c->sd[0]);
-    hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, d_pcm, d_ids, B,
-                       c->sm.base[st::R_MEL], (int)st::MEL_BYTES, (int)st::M_PREV, d_mel); }
+    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, d_pcm,
+                       d_ids, B, c->sm.base[st::R_MEL], (int)st::MEL_BYTES, (int)st::M_PREV, d_mel); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -369,8 +369,8 @@ int launch_noise(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const i
   uint8_t* region = c->sm.base[side == 0 ? st::R_NOISE_E : st::R_NOISE_D];
   float* mel = side == 0 ? c->d_mel_enc : c->d_mel;
   { ProfScope ps(c, K_LOGMEL, st_);
-    hipLaunchKernelGGL(logmel_kernel, dim3(B), dim3(256), logmel_lds_bytes(), st_, c->model.d_mel, d_pcm, d_ids, B,
-                       region, (int)st::NOISE_BYTES, (int)st::N_PREV, mel); }
+    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), st_, c->model.d_mel, d_pcm, d_ids,
+                       B, region, (int)st::NOISE_BYTES, (int)st::N_PREV, mel); }
   { ProfScope ps(c, K_NOISE, st_);
     hipLaunchKernelGGL(noise_update_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st_, noise_params(), d_ids, B, region,
                        (const float*)mel, d_is_noise, d_masked_ids); }

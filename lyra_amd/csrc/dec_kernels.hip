@@ -77,6 +77,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * SD0;
   const int mode = P.mode;
+  wg_schedule_hint();
   LYRA_TSTAMP(40);
   LYRA_WSTAMP(100);
   LYRA_WG_BEGIN();
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
   float* SB = DB + 4 * SD1 * CS1;       // [5][S][72]: tail of the previous frame's transposed conv
   int* sids = reinterpret_cast<int*>(SB + 5 * SD1 * 72);
   int* sphase = sids + SD1;
+  wg_schedule_hint();
   const int tid = threadIdx.x, wave = tid >> 6;
   const int b0 = blockIdx.x * SD1;
   if (tid < SD1) {
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restric
   int* sids = reinterpret_cast<int*>(SB + SD2 * 48);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
+  wg_schedule_hint();
   const int b0 = blockIdx.x * SD2;
   if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NTD2, 1>(P.warm);

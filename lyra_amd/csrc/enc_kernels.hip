@@ -51,6 +51,7 @@ __global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict
   const int b0 = blockIdx.x * S0;
   LYRA_WG_BEGIN();
   LYRA_TSTAMP(0);
+  wg_schedule_hint();
   if (tid < S0) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NT0, 1>(P.warm);
   const auto warm_code = code_warm<NT0>(code_bytes);
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const E
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * S1;
+  wg_schedule_hint();
   LYRA_TSTAMP(70);
   LYRA_WSTAMP(102);
   if (tid < S1) {

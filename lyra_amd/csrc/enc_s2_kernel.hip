@@ -59,6 +59,7 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * S2;
   const int mode = P.mode;
+  wg_schedule_hint();
   LYRA_TSTAMP(0);
   LYRA_WSTAMP(100);
   LYRA_WG_BEGIN();

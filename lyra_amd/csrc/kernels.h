@@ -72,6 +72,7 @@ __global__ void rvq_decode_kernel(const float* cb, const int32_t* indices, const
                                   int B, float* feats);
 struct MelP { const double* hann; const double* tw_re; const double* tw_im; const int* band; const double* w;
               const double* wsum;   // [160] total forward weight of every mel band (comfort-noise inverse mel)
+              const double* tw4_re; const double* tw4_im;   // [768] W_1024^j, radix-4 log-mel FFT
               int start, end; };
 __global__ void logmel_kernel(const MelP* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, int stride,
                               int prev_off, float* mel);

@@ -132,6 +132,35 @@ __device__ __forceinline__ const T LYRA_GLOBAL* as_global(const T* p) {
   return (const T LYRA_GLOBAL*)p;
 }
 
+// Experiments on how co-resident workgroups share a SIMD (build flags, see DESIGN.md "what was tried"):
+//   LYRA_PRIO_MFMA   raise the wave's priority around every MFMA cluster (guide T5)
+//   LYRA_PRIO_SLOT   static priority = the wave's slot on its SIMD (0..3): co-resident tiles pipeline instead of
+//                    marching in lock-step
+//   LYRA_STAGGER=N   tiles in wave slot k start k * N * 64 cycles late
+#ifdef LYRA_PRIO_MFMA
+#define LYRA_MFMA_BEGIN() __builtin_amdgcn_s_setprio(2)
+#define LYRA_MFMA_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define LYRA_MFMA_BEGIN() do { } while (0)
+#define LYRA_MFMA_END() do { } while (0)
+#endif
+__device__ __forceinline__ void wg_schedule_hint() {
+#if defined(LYRA_PRIO_SLOT) || defined(LYRA_STAGGER)
+  const unsigned slot = __builtin_amdgcn_s_getreg(63492) & 15u;   // HW_ID.wave_id: the wave's slot on its SIMD
+#endif
+#ifdef LYRA_PRIO_SLOT
+  switch (slot & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+  }
+#endif
+#ifdef LYRA_STAGGER
+  for (unsigned i = 0; i < (slot & 3u) * LYRA_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+#endif
+}
+
 // Software-pipelined: the B fragments (L2, ~500+ cycles) and A fragments (LDS) of chunk c+PF are requested
 // before the MFMAs of chunk c issue; the K loop is fully unrolled so the PF+1 register stages are static and
 // the compiler emits counted s_waitcnt (the prefetches stay in flight across the MFMA block).
@@ -168,6 +197,7 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
       for (int i = 0; i < MTW; ++i) aq[sl][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c + PF));
     }
     const int cur = c % (PF + 1);
+    LYRA_MFMA_BEGIN();
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -175,6 +205,7 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], acc[i][j], 0, 0, 0);
+    LYRA_MFMA_END();
   }
 }
 

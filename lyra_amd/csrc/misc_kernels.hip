@@ -163,14 +163,23 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const float* __restrict
 // =============================================================================================
 // log-mel: LogMelSpectrogramExtractorImpl::Extract (lyra/log_mel_spectrogram_extractor_impl.cc:96-126)
 // as instantiated by NoiseEstimator (16 kHz, hop 320, window 640, 160 bands).
-// One workgroup per stream-frame: fp64 radix-2 FFT-1024 in LDS (same butterfly order and twiddles as
-// the oracle), |X|, then one thread per mel band accumulating its bins in ascending order (== the
-// reference's scatter loop order per band), float log/floor.
-// =============================================================================================
-size_t logmel_lds_bytes() { return (size_t)(1024 * 2 + 520) * 8; }
-
+// One workgroup per PAIR of stream-frames: the two real windows are packed into one complex sequence
+// (re = frame A, im = frame B), transformed by ONE fp64 FFT-1024 in five radix-4 passes in LDS (digit-reversed
+// input, host-built twiddles), and separated again by the conjugate symmetry of real spectra -- a quarter of the
+// butterfly passes per frame of a per-frame radix-2 transform.  Then |X|, one thread per mel band accumulating its
+// bins in ascending order (== the reference's scatter loop order per band), log / floor.
+// The spectrum differs from the oracle's radix-2 one in the last bits of the doubles; after the cast to float the
+// two agree except when a band sum lies within ~1e-16 of a float rounding boundary.
 // `state` / `stride` / `prev_off`: where the previous hop of each stream lives -- the plugin-level extractor's own
 // region (R_MEL) or the slot of one of the two NoiseEstimators (R_NOISE_E / R_NOISE_D own their extractor).
+// =============================================================================================
+size_t logmel_lds_bytes() { return (size_t)(1024 * 2 + 160) * 8; }   // (+160: the comfort-noise kernel's mel vector)
+
+__device__ __forceinline__ int digit_reverse4_1024(int n) {   // reverse the five base-4 digits of n
+  unsigned r = __brev((unsigned)n) >> 22;
+  return (int)(((r & 0x2AAu) >> 1) | ((r & 0x155u) << 1));
+}
+
 __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, int stride, int prev_off,
@@ -179,47 +188,101 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* re = dsm;
   double* im = dsm + 1024;
-  double* mag = dsm + 2048;
+  double* mag0 = re;                  // |X_A[k]|, k = 0..512, written in place over Z (see below)
+  double* mag1 = im;                  // |X_B[k]|
   const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  int16_t* prev = reinterpret_cast<int16_t*>(state + (size_t)ids[b] * stride + prev_off);
-  for (int i = tid; i < 1024; i += 256) {
-    double v = 0.0;
-    if (i < 320) v = (double)prev[i] * P.hann[i];
-    else if (i < 640) v = (double)pcm[(size_t)b * 320 + (i - 320)] * P.hann[i];
-    int rv = __brev((unsigned)i) >> 22;
-    re[rv] = v;
-    im[rv] = 0.0;
+  const int b0 = blockIdx.x * 2, b1 = b0 + 1;
+  const bool two = b1 < B;
+  int16_t* prev0 = reinterpret_cast<int16_t*>(state + (size_t)ids[b0] * stride + prev_off);
+  int16_t* prev1 = reinterpret_cast<int16_t*>(state + (size_t)ids[two ? b1 : b0] * stride + prev_off);
+  // window = [previous hop | this hop] x periodic Hann, zero-padded to 1024, in digit-reversed order.  Items of eight
+  // samples (one 16-byte load each): 80 per frame; the previous hop is replaced in the same pass (each item rewrites
+  // exactly the eight history samples it has just read, or none).
+  for (int i = 640 + tid; i < 1024; i += 256) { const int r = digit_reverse4_1024(i); re[r] = 0.0; im[r] = 0.0; }
+  if (tid < 160) {
+    const int f = tid >= 80, c = tid - 80 * f;            // frame, chunk of 8 samples within the 640-sample window
+    if (!f || two) {
+      int16_t* prev = f ? prev1 : prev0;
+      const int16_t* cur = pcm + (size_t)(f ? b1 : b0) * 320;
+      const i32x4 raw = c < 40 ? *reinterpret_cast<const i32x4*>(prev + c * 8)
+                               : *reinterpret_cast<const i32x4*>(cur + (c - 40) * 8);
+      if (c < 40) *reinterpret_cast<i32x4*>(prev + c * 8) = *reinterpret_cast<const i32x4*>(cur + c * 8);
+      double* dst = f ? im : re;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = c * 8 + e;
+        const int16_t x = (int16_t)((raw[e >> 1] >> ((e & 1) * 16)) & 0xffff);
+        dst[digit_reverse4_1024(i)] = (double)x * P.hann[i];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) im[digit_reverse4_1024(c * 8 + e)] = 0.0;
+    }
   }
   __syncthreads();
-  for (int i = tid; i < 320; i += 256) prev[i] = pcm[(size_t)b * 320 + i];
+  // five radix-4 decimation-in-time passes; pass s combines four L-point transforms (L = 4^s) into one 4L-point one:
+  //   y_q = sum_r (-i)^(r q) W_4L^(r k) F_r[k].  The twiddles of pass s+1 (L2-resident table) are requested before
+  // the butterflies of pass s, so their latency hides behind the LDS round trip and the barrier.
+  double w1r = 1.0, w1i = 0.0, w2r = 1.0, w2i = 0.0, w3r = 1.0, w3i = 0.0;   // pass 0: L = 1, k = 0
+  const double wsel0 = P.w[tid + 1], wsel1 = tid < 254 ? P.w[tid + 257] : 0.0;   // mel weights, parked for the epilogue
 #pragma unroll 1
-  for (int p = 1; p <= 10; ++p) {
-    const int len = 1 << p, half = len >> 1;
-    for (int bf = tid; bf < 512; bf += 256) {
-      int grp = bf >> (p - 1), k = bf & (half - 1);
-      int i0 = grp * len + k, i1 = i0 + half;
-      double wr = P.tw_re[half - 1 + k], wi = P.tw_im[half - 1 + k];
-      double ur = re[i0], ui = im[i0];
-      double xr = re[i1], xi = im[i1];
-      double vr = xr * wr - xi * wi;
-      double vi = xr * wi + xi * wr;
-      re[i0] = ur + vr; im[i0] = ui + vi;
-      re[i1] = ur - vr; im[i1] = ui - vi;
+  for (int s = 0; s < 5; ++s) {
+    const int L = 1 << (2 * s);
+    const int k = tid & (L - 1), g = tid >> (2 * s);
+    const int i0 = g * 4 * L + k, i1 = i0 + L, i2 = i1 + L, i3 = i2 + L;
+    double n1r = 1.0, n1i = 0.0, n2r = 1.0, n2i = 0.0, n3r = 1.0, n3i = 0.0;
+    if (s < 4) {
+      const int Ln = 4 * L, kn = tid & (Ln - 1);
+      const int t1 = kn * (256 >> (2 * (s + 1)));     // W_4L^k = W_1024^(k * 1024 / 4L)
+      n1r = P.tw4_re[t1]; n1i = P.tw4_im[t1]; n2r = P.tw4_re[2 * t1]; n2i = P.tw4_im[2 * t1];
+      n3r = P.tw4_re[3 * t1]; n3i = P.tw4_im[3 * t1];
     }
+    const double ar = re[i0], ai = im[i0];
+    const double xr1 = re[i1], xi1 = im[i1], xr2 = re[i2], xi2 = im[i2], xr3 = re[i3], xi3 = im[i3];
+    const double br = xr1 * w1r - xi1 * w1i, bi = xr1 * w1i + xi1 * w1r;
+    const double cr = xr2 * w2r - xi2 * w2i, ci = xr2 * w2i + xi2 * w2r;
+    const double dr = xr3 * w3r - xi3 * w3i, di = xr3 * w3i + xi3 * w3r;
+    const double s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
+    const double s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
+    re[i0] = s0r + s2r; im[i0] = s0i + s2i;
+    re[i1] = s1r + s3i; im[i1] = s1i - s3r;     // (a - c) - i (b - d)
+    re[i2] = s0r - s2r; im[i2] = s0i - s2i;
+    re[i3] = s1r - s3i; im[i3] = s1i + s3r;     // (a - c) + i (b - d)
+    w1r = n1r; w1i = n1i; w2r = n2r; w2i = n2i; w3r = n3r; w3i = n3i;
     __syncthreads();
   }
-  for (int i = tid; i <= 512; i += 256) mag[i] = __builtin_sqrt(re[i] * re[i] + im[i] * im[i]);
+  // Z = FFT(a + i b):  A[k] = (Z[k] + conj(Z[N-k])) / 2,  B[k] = (Z[k] - conj(Z[N-k])) / (2 i).  In place: the item
+  // for bin k <= 512 reads Z[k] and Z[N - k] and writes index k only; index k < 512 is read by no other item and
+  // indices > 512 are never written, so no staging buffer (and no barrier before the writes) is needed.
+  for (int k = tid; k <= 512; k += 256) {
+    const int n = (1024 - k) & 1023;
+    const double zr = re[k], zi = im[k], yr = re[n], yi = im[n];
+    const double Ar = 0.5 * (zr + yr), Ai = 0.5 * (zi - yi);
+    const double Br = 0.5 * (zi + yi), Bi = 0.5 * (yr - zr);
+    mag0[k] = __builtin_sqrt(Ar * Ar + Ai * Ai);
+    mag1[k] = __builtin_sqrt(Br * Br + Bi * Bi);
+  }
+  __syncthreads();
+  // the mel weights of bins 1..510 go to the now unused upper half of `re` (index 513 + bin): the band loops below
+  // would otherwise wait for one L2 round trip per bin
+  double* wl = re + 513;
+  wl[tid + 1] = wsel0;
+  if (tid < 254) wl[tid + 257] = wsel1;
   __syncthreads();
   if (tid < 160) {
-    // bins whose lower band is tid-1 contribute (v - v*w); bins whose lower band is tid contribute v*w
-    double acc = 0.0;
-    for (int i = P.band[tid]; i < P.band[tid + 1]; ++i) { double v = mag[i]; double w = v * P.w[i]; acc += v - w; }
-    for (int i = P.band[tid + 1]; i < P.band[tid + 2]; ++i) { double v = mag[i]; acc += v * P.w[i]; }
-    float v = (float)acc;
-    v = v > 500.f ? v : 500.f;
-    // log evaluated in double and rounded once: identical on host and device (oracle/lyra_oracle.c log_f)
-    mel[(size_t)b * 160 + tid] = (float)log((double)v) / 10.f;
+    const int e0 = P.band[tid], e1 = P.band[tid + 1], e2 = P.band[tid + 2];
+#pragma unroll 1
+    for (int f = 0; f < (two ? 2 : 1); ++f) {
+      const double* mag = f ? mag1 : mag0;
+      // bins whose lower band is tid-1 contribute (v - v*w); bins whose lower band is tid contribute v*w
+      double acc = 0.0;
+      for (int i = e0; i < e1; ++i) { double v = mag[i]; double w = v * wl[i]; acc += v - w; }
+      for (int i = e1; i < e2; ++i) { double v = mag[i]; acc += v * wl[i]; }
+      float v = (float)acc;
+      v = v > 500.f ? v : 500.f;
+      // log evaluated in double and rounded once: identical on host and device (oracle/lyra_oracle.c log_f)
+      mel[(size_t)(b0 + f) * 160 + tid] = (float)log((double)v) / 10.f;
+    }
   }
 }
 

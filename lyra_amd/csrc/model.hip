@@ -530,6 +530,10 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
       if (ch + 1 < NB) wsum[ch + 1] += 1.0 - w[i];
     }
     B.put(&M->mel.wsum, wsum);
+    std::vector<double> t4r(768), t4i(768);   // W_1024^j = exp(-2 pi i j / 1024), j < 3 * 256
+    for (int j = 0; j < 768; ++j) { t4r[j] = std::cos(-2.0 * PI * j / 1024); t4i[j] = std::sin(-2.0 * PI * j / 1024); }
+    B.put(&M->mel.tw4_re, t4r);
+    B.put(&M->mel.tw4_im, t4i);
     M->mel.start = start;
     M->mel.end = end;
   }
