@@ -298,8 +298,9 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
     hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes(), st_,
                        M.d_enc1, e0, d_ids, B, c->sm.base[st::R_E1], e1, c->cw[K_ENC_S1]); }
   { ProfScope ps(c, K_ENC_S2, st_);
-    hipLaunchKernelGGL(enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512), enc_s2_lds_bytes(), st_,
-                       M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes, c->cw[K_ENC_S2]); }
+    hipLaunchKernelGGL(c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512),
+                       enc_s2_lds_bytes(), st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
+                       c->cw[K_ENC_S2]); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
   return 0;
@@ -331,7 +332,8 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
   float* d0 = c->d_d0 + (size_t)lo * 512;
   float* d1 = c->d_d1 + (size_t)lo * 1280;
   { ProfScope ps(c, K_DEC_S0, st_);
-    hipLaunchKernelGGL(dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512), dec_s0_lds_bytes(), st_,
+    hipLaunchKernelGGL(c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512),
+                       dec_s0_lds_bytes(), st_,
                        M.d_dec0, d_feat, d_ids, B, c->sm.base[st::R_D0], d0, d_pkt, num_stages, M.cb,
                        c->cw[K_DEC_S0]); }
   { ProfScope ps(c, K_DEC_S1, st_);
@@ -482,10 +484,12 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   }
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
       set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
+      set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
   for (int i = 0; i < K_COUNT; ++i) c->cw[i] = code_warm_bytes(kKernelNames[i]);
+  if (c->mode) { c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_dr_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_dr_kernel"); }
   for (int k = 0; k < c->nsub; ++k)
     if (enc_side_done(c, k) != 0) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
   *out = c;

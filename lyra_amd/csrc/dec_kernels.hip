@@ -55,11 +55,12 @@ int dec_s0_streams_per_wg() { return SD0; }
 // feats != nullptr: lossy features [B][64] (GenerativeModel::AddFeatures path).  Otherwise the features are rebuilt
 // here from the packets exactly as rvq_decode_kernel does (quantizer.tflite `decode` + DecodeToLossyFeatures,
 // residual_vector_quantizer.cc:112-168): ((v0 + v1) + v2) + ... left to right, unused stages contribute v * 0.0f.
-__global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
-                                                       const int32_t* __restrict__ ids, int B,
-                                                       uint8_t* __restrict__ state, float* __restrict__ out0,
-                                                       const uint8_t* __restrict__ packets, int num_stages,
-                                                       const float* __restrict__ cb, int code_bytes) {
+// MODE: requantisation flavour, compile-time (see enc_s2_kernel.hip).
+template <int MODE>
+__device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+                                            const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
+                                            float* __restrict__ out0, const uint8_t* __restrict__ packets, int num_stages,
+                                            const float* __restrict__ cb, int code_bytes) {
   const DecS0P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* FB = smem;                                   // [3][16][72]: two history rows + new features (rows s < S used)
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * SD0;
-  const int mode = P.mode;
+  constexpr int mode = MODE;
   wg_schedule_hint();
   LYRA_TSTAMP(40);
   LYRA_WSTAMP(100);
@@ -343,6 +344,21 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restric
   l2_warm_sink(warm_cb, state, B);
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);
+}
+
+__global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+                                                       const int32_t* __restrict__ ids, int B,
+                                                       uint8_t* __restrict__ state, float* __restrict__ out0,
+                                                       const uint8_t* __restrict__ packets, int num_stages,
+                                                       const float* __restrict__ cb, int code_bytes) {
+  dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
+}
+__global__ __launch_bounds__(NTD0, 4) void dec_s0_dr_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+                                                          const int32_t* __restrict__ ids, int B,
+                                                          uint8_t* __restrict__ state, float* __restrict__ out0,
+                                                          const uint8_t* __restrict__ packets, int num_stages,
+                                                          const float* __restrict__ cb, int code_bytes) {
+  dec_s0_body<1>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
 }
 
 // =============================================================================================

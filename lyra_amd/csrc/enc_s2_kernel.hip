@@ -38,10 +38,13 @@ static_assert(4 * S2 * QS + 16 * QS <= XF_BYTES && 3 * S2 * QS5 + 16 * QS5 <= XF
 size_t enc_s2_lds_bytes() { return (size_t)2 * XF_BYTES + 3 * QB_BYTES + 2 * S2 * 4 + NLR * 256 + NADD * 2048; }
 int enc_s2_streams_per_wg() { return S2; }
 
-__global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
-                                                      const int32_t* __restrict__ ids, int B,
-                                                      uint8_t* __restrict__ state, float* __restrict__ feats,
-                                                      float* __restrict__ codes_dbg, int code_bytes) {
+// MODE: requantisation flavour of the int8 conv layers (0 exact / 1 gemmlowp double rounding), a compile-time constant:
+// as a run-time value every requantisation carried both arithmetic paths and a (uniform) branch -- a third of this
+// kernel's instructions -- which costs issue slots and, the code being executed once per workgroup, instruction fetch.
+template <int MODE>
+__device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+                                            const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
+                                            float* __restrict__ feats, float* __restrict__ codes_dbg, int code_bytes) {
   const EncS2P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* DF = smem;                                  // [2][S][CS2] depthwise out; later int8 staging QB4
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * S2;
-  const int mode = P.mode;
+  constexpr int mode = MODE;
   wg_schedule_hint();
   LYRA_TSTAMP(0);
   LYRA_WSTAMP(100);
@@ -238,6 +241,19 @@ __global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict
   }
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);
+}
+
+__global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+                                                      const int32_t* __restrict__ ids, int B,
+                                                      uint8_t* __restrict__ state, float* __restrict__ feats,
+                                                      float* __restrict__ codes_dbg, int code_bytes) {
+  enc_s2_body<0>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes);
+}
+__global__ __launch_bounds__(NT2, 4) void enc_s2_dr_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+                                                         const int32_t* __restrict__ ids, int B,
+                                                         uint8_t* __restrict__ state, float* __restrict__ feats,
+                                                         float* __restrict__ codes_dbg, int code_bytes) {
+  enc_s2_body<1>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes);
 }
 
 }  // namespace lyra

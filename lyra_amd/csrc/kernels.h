@@ -28,6 +28,8 @@ __global__ void enc_s1_kernel(const EncS1P* P, const float* in0, const int32_t* 
                               int code_bytes);
 __global__ void enc_s2_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, float* feats,
                               float* codes_dbg, int code_bytes);
+__global__ void enc_s2_dr_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state,
+                                 float* feats, float* codes_dbg, int code_bytes);   // gemmlowp double rounding
 size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg();
 size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg(); int enc_s1_threads();
 size_t enc_s2_lds_bytes(); int enc_s2_streams_per_wg();
@@ -55,6 +57,8 @@ struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; War
 
 __global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0,
                               const uint8_t* packets, int num_stages, const float* cb, int code_bytes);
+__global__ void dec_s0_dr_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state,
+                                 float* out0, const uint8_t* packets, int num_stages, const float* cb, int code_bytes);
 __global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1,
                               int code_bytes);
 __global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm,
