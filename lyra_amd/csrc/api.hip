@@ -292,7 +292,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   float* e1 = c->d_e1 + (size_t)lo * 512;
   float* codes = c->d_codes + (size_t)lo * 64;
   { ProfScope ps(c, K_ENC_S0, st_);
-    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(256), enc_s0_lds_bytes(), st_,
+    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(enc_s0_threads()), enc_s0_lds_bytes(), st_,
                        M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0]); }
   { ProfScope ps(c, K_ENC_S1, st_);
     hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes(), st_,
@@ -340,7 +340,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
     hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(dec_s1_threads()), dec_s1_lds_bytes(), st_,
                        M.d_dec1, d0, d_ids, B, c->sm.base[st::R_D1], d1, c->cw[K_DEC_S1]); }
   { ProfScope ps(c, K_DEC_S2, st_);
-    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(256), dec_s2_lds_bytes(), st_,
+    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(dec_s2_threads()), dec_s2_lds_bytes(), st_,
                        M.d_dec2, d1, d_ids, B, c->sm.base[st::R_D2], d_pcm, c->cw[K_DEC_S2]); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;

@@ -494,13 +494,17 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
 // stage 2
 // =============================================================================================
 namespace {
-constexpr int SD2 = 4;
+#ifndef LYRA_S0_STREAMS
+#define LYRA_S0_STREAMS 4
+#endif
+constexpr int SD2 = LYRA_S0_STREAMS;   // 4 streams with 256 threads, or 8 with 512
 constexpr int CS0 = 72;
-constexpr int NTD2 = 256;
+constexpr int NTD2 = 64 * SD2;
 }  // namespace
 
 size_t dec_s2_lds_bytes() { return (size_t)(27 * SD2 * CS0 + SD2 * 48) * 4 + 64; }
 int dec_s2_streams_per_wg() { return SD2; }
+int dec_s2_threads() { return NTD2; }
 
 __global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                           const int32_t* __restrict__ ids, int B,
@@ -548,8 +552,8 @@ __global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restric
       XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
   __syncthreads();
   // tconv k64/s16, polyphase: blocks b = 0..22 (+1 of padding), rows (b, s); K = 4 x 64 (oldest input first);
-  // N = 16 phases.  24*S rows = 6 M tiles: waves 0..2 take two each.
-  if (wave < 3) {
+  // N = 16 phases.  24*S rows = 6 M tiles per 4 streams: waves 0..(3 * S / 4 - 1) take two each.
+  if (wave < 3 * SD2 / 4) {
     f32x4 acc[2][1];
     auto aoff = [&](int i, int c) {
       int R = (2 * wave + i) * 16 + m, b = R / SD2, s = R & (SD2 - 1);

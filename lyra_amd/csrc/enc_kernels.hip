@@ -26,17 +26,21 @@ namespace lyra {
 // stage 0
 // =============================================================================================
 namespace {
-constexpr int S0 = 4;      // streams per workgroup
+#ifndef LYRA_S0_STREAMS
+#define LYRA_S0_STREAMS 4
+#endif
+constexpr int S0 = LYRA_S0_STREAMS;      // streams per workgroup (4 with 256 threads, 8 with 512)
 constexpr int CS0 = 72;    // LDS row stride (64 + 8) floats
 constexpr int PBS = 376;   // PCM staging row stride (368 + 8) floats
-constexpr int NT0 = 256;   // threads
+constexpr int NT0 = 64 * S0;   // threads
 constexpr int NW0 = NT0 / 64;
 }  // namespace
 
 size_t enc_s0_lds_bytes() { return (size_t)(25 * S0 * CS0) * 4 + 64; }
 int enc_s0_streams_per_wg() { return S0; }
+int enc_s0_threads() { return NT0; }
 
-__global__ __launch_bounds__(NT0, 4) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
+__global__ __launch_bounds__(NT0, NT0 == 512 ? 4 : 4) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ out0,
                                                          int code_bytes) {

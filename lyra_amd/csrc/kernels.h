@@ -30,7 +30,7 @@ __global__ void enc_s2_kernel(const EncS2P* P, const float* in1, const int32_t* 
                               float* codes_dbg, int code_bytes);
 __global__ void enc_s2_dr_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state,
                                  float* feats, float* codes_dbg, int code_bytes);   // gemmlowp double rounding
-size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg();
+size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg(); int enc_s0_threads();
 size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg(); int enc_s1_threads();
 size_t enc_s2_lds_bytes(); int enc_s2_streams_per_wg();
 
@@ -65,7 +65,7 @@ __global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* 
                               int code_bytes);
 size_t dec_s0_lds_bytes(); int dec_s0_streams_per_wg();
 size_t dec_s1_lds_bytes(); int dec_s1_streams_per_wg(); int dec_s1_threads();
-size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg();
+size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg(); int dec_s2_threads();
 
 // ---- RVQ / packets / log-mel / state ---------------------------------------------------------------
 // cb: codebooks, natural layout [46][16][64]
