@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 rocpd databases (gpurun_out/prof/*) into the small summaries kept under profiles/.
 
-    python tools/rocprof_summary.py gpurun_out/prof r01
+    python tools/rocprof_summary.py gpurun_out/prof r01 [out_dir]
 
 Writes profiles/<tag>_kernel_trace_stats.csv (per-kernel calls / total / average / share from the
 --kernel-trace --stats run), profiles/<tag>_pmc_hbm.csv (per-kernel FETCH_SIZE / WRITE_SIZE per launch from the
@@ -22,7 +22,7 @@ def short(name):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     os.makedirs(out, exist_ok=True)
     rows = []
     db = os.path.join(src, "trace", f"{tag}_results.db")
@@ -59,6 +59,7 @@ def main():
                 if "kernel" in k and "lyra" not in k and "at::" not in k:
                     traffic[k] = {"hbm_bytes_per_launch": hbm, "fetch_kb": round(fe[1], 1), "write_kb": round(wr[1], 1)}
                 print(k, round(fe[1], 1), round(wr[1], 1), hbm)
+        traffic["_batch"] = 4096   # streams per launch of the profiled run (bench.py default config)
         json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
 
