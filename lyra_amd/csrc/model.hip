@@ -181,6 +181,29 @@ struct Builder {
     put(&out->b, std::vector<float>(b, b + cout));
   }
 
+  // ---- fp32 1x1 conv [64][1][64] for the wave-private residual blocks (resblocks_w.h): the WEIGHTS are the MFMA A
+  //      operand.  Fragment (c, j), lane (m = lane & 15, q = lane >> 4), element kk:
+  //        W[out = 16j + 4(m & 3) + (m >> 2)][in = 16c + 4kk + q]        (output channels AT16-permuted inside a tile)
+  //      stored [(c * 4 + j) * 64 + lane]; bias in AT16 channel order.
+  void conv_f_sw(const char* pre, int idx, ConvF* out) {
+    const uint32_t C = 64;
+    const float* w = pk.f32(key(pre, "conv", idx, "w"), {C, 1, C});
+    const float* b = pk.f32(key(pre, "conv", idx, "b"), {C});
+    if (!w || !b) return;
+    std::vector<float> frag((size_t)16 * 64 * 4), bp(C);
+    for (int c = 0; c < 4; ++c)
+      for (int j = 0; j < 4; ++j)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int kk = 0; kk < 4; ++kk) {
+            const int m = lane & 15, q = lane >> 4;
+            const int o = 16 * j + 4 * (m & 3) + (m >> 2), i = 16 * c + 4 * kk + q;
+            frag[(((size_t)c * 4 + j) * 64 + lane) * 4 + kk] = w[(size_t)o * C + i];
+          }
+    for (int ch = 0; ch < (int)C; ++ch) bp[at16(ch)] = b[ch];
+    put(&out->w, frag);
+    put(&out->b, bp);
+  }
+
   // ---- fp32 transposed conv [cout][k][cin], stride s -> polyphase B fragments ---------------------
   //   K = (k/s)*cin with the OLDEST input block first, N = s*cout (n = phase*cout + co)
   void tconv_f(const char* pre, int idx, ConvF* out, uint32_t cout, uint32_t k, uint32_t cin, int s) {
@@ -459,8 +482,13 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
     B.dw_f("dec", 6 + r, &M->dec2.dw[r], 64);
+#ifdef LYRA_WAVE_PRIVATE
+    B.conv_f_sw("dec", 13 + 2 * r, &M->dec2.pw[r]);
+    B.conv_f_sw("dec", 14 + 2 * r, &M->dec2.cv[r]);
+#else
     B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r], 64, 1, 64);
     B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r], 64, 1, 64);
+#endif
   }
   B.tconv_f("dec", 7, &M->dec2.up, 1, 64, 64, 16);
   {

@@ -1,4 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-( timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3 )
-VARIANTS="head cur" bash tools/ab_variants.sh
+for v in WP WPNH WPSW WPBOTH; do
+  s=$(LYRA_HIP_LIB=$GRAFT_REPO_ROOT/lyra_amd/variants/$v.so MODES=full python tools/pipeline_probe.py 2>&1 | grep "^full")
+  echo "$v | $s"
+done
