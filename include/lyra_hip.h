@@ -89,7 +89,12 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  * output for that directory; used first if present).  Version identifier 3 as
  * lyra_config.h:145-166.  The container is validated (bounds, dtypes, the
  * layer shapes the kernels are specialised to): a truncated or foreign file
- * gives LYRA_HIP_EMODEL. */
+ * gives LYRA_HIP_EMODEL.
+ * Developer switches read from the environment here (results are bit-identical
+ * either way): LYRA_HIP_FUSED=<mask> -- bit 0: the encoder side
+ * (lyra_hip_extract / lyra_hip_encode) as one launch instead of three, bit 1: the
+ * decoder side likewise (slower at B = 4096; default 0);
+ * LYRA_HIP_NO_CODE_WARM -- skip the stage kernels' instruction pre-fetch. */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
 /* The same from an in-memory lyra_v1.lyrapack image (e.g. read once by rank 0 and broadcast to the other GPUs' ranks
  * over RCCL); the image is copied, the caller keeps ownership. */

@@ -39,6 +39,7 @@ struct lyra_hip_ctx {
   hipEvent_t ev_enc[KMAX] = {};    // end of the latest encode-side work on se[k]
   hipEvent_t ev_dec[2][KMAX] = {}; // end of the two latest decode-side calls on sd[k]
   long n_dec_calls = 0;
+  int fused = 0;                   // bit 0: encoder side in one launch, bit 1: decoder side (LYRA_HIP_FUSED)
   bool serial = false;             // lyra_hip_set_serial: encode side also waits for the latest decode-side call
   hipEvent_t ev_caller = nullptr;  // scratch event for lyra_hip_wait_for_stream / lyra_hip_stream_wait
   Model model;
@@ -202,10 +203,11 @@ int code_warm_bytes(const char* kernel) {
 }
 
 enum { K_ENC_S0, K_ENC_S1, K_ENC_S2, K_RVQ_ENC, K_RVQ_DEC, K_DEC_S0, K_DEC_S1, K_DEC_S2, K_LOGMEL, K_NOISE, K_RESAMPLE,
-       K_CNG, K_COUNT };
+       K_CNG, K_ENC_SIDE, K_DEC_SIDE, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"enc_s0_kernel", "enc_s1_kernel", "enc_s2_kernel", "rvq_encode_kernel",
                                            "rvq_decode_kernel", "dec_s0_kernel", "dec_s1_kernel", "dec_s2_kernel",
-                                           "logmel_kernel", "noise_update_kernel", "resample_kernel", "cng_kernel"};
+                                           "logmel_kernel", "noise_update_kernel", "resample_kernel", "cng_kernel",
+                                           "enc_side_kernel", "dec_side_kernel"};
 
 hipEvent_t take_event(lyra_hip_ctx* c) {
   if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
@@ -291,6 +293,15 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   float* e0 = c->d_e0 + (size_t)lo * 512;
   float* e1 = c->d_e1 + (size_t)lo * 512;
   float* codes = c->d_codes + (size_t)lo * 64;
+  if (c->fused & 1) {   // the whole side in one launch (enc_side_kernel.hip)
+    { ProfScope ps(c, K_ENC_SIDE, st_);
+      hipLaunchKernelGGL(c->mode ? enc_side_dr_kernel : enc_side_kernel, dim3(cdiv(B, 8)), dim3(512), enc_side_lds_bytes(), st_,
+                         M.d_enc0, M.d_enc1, M.d_enc2, d_pcm, d_ids, B, c->sm.base[st::R_E0], c->sm.base[st::R_E1],
+                         c->sm.base[st::R_E2], e0, e1, d_feat, codes, c->cw[K_ENC_SIDE]); }
+    HIPCHK(c, hipGetLastError());
+    c->last_B_enc = B;
+    return 0;
+  }
   { ProfScope ps(c, K_ENC_S0, st_);
     hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(enc_s0_threads()), enc_s0_lds_bytes(), st_,
                        M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0]); }
@@ -331,6 +342,15 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
   hipStream_t st_ = c->sd[k];
   float* d0 = c->d_d0 + (size_t)lo * 512;
   float* d1 = c->d_d1 + (size_t)lo * 1280;
+  if (c->fused & 2) {   // the whole side in one launch (dec_side_kernel.hip)
+    { ProfScope ps(c, K_DEC_SIDE, st_);
+      hipLaunchKernelGGL(c->mode ? dec_side_dr_kernel : dec_side_kernel, dim3(cdiv(B, 8)), dim3(512), dec_side_lds_bytes(), st_,
+                         M.d_dec0, M.d_dec1, M.d_dec2, d_feat, d_ids, B, c->sm.base[st::R_D0], c->sm.base[st::R_D1],
+                         c->sm.base[st::R_D2], d0, d1, d_pcm, d_pkt, num_stages, M.cb, c->cw[K_DEC_SIDE]); }
+    HIPCHK(c, hipGetLastError());
+    c->last_B_dec = B;
+    return 0;
+  }
   { ProfScope ps(c, K_DEC_S0, st_);
     hipLaunchKernelGGL(c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512),
                        dec_s0_lds_bytes(), st_,
@@ -483,13 +503,19 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     }
   }
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
-      set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
+      set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(enc_side_kernel, enc_side_lds_bytes()) != hipSuccess ||
+      set_lds(enc_side_dr_kernel, enc_side_lds_bytes()) != hipSuccess || set_lds(dec_side_kernel, dec_side_lds_bytes()) != hipSuccess ||
+      set_lds(dec_side_dr_kernel, dec_side_lds_bytes()) != hipSuccess || set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
   for (int i = 0; i < K_COUNT; ++i) c->cw[i] = code_warm_bytes(kKernelNames[i]);
-  if (c->mode) { c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_dr_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_dr_kernel"); }
+  if (c->mode) {
+    c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_dr_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_dr_kernel");
+    c->cw[K_ENC_SIDE] = code_warm_bytes("enc_side_dr_kernel"); c->cw[K_DEC_SIDE] = code_warm_bytes("dec_side_dr_kernel");
+  }
+  if (const char* f = getenv("LYRA_HIP_FUSED")) c->fused = atoi(f);
   for (int k = 0; k < c->nsub; ++k)
     if (enc_side_done(c, k) != 0) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
   *out = c;

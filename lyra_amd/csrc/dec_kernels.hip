@@ -1,17 +1,5 @@
-// dec_kernels.hip -- LyraGAN decoder (replaces lyragan.tflite as run by LyraGanModel::RunConditioning /
-// RunModel, lyra/lyra_gan_model.cc:53-64, incl. the float->int16 conversion of dsp_utils.h:54-88) as three
-// stream-tiled gfx950 kernels.
-//
-//   dec_s0  8 streams/WG  features -> conv k3 g4 (fp32) -> int8: 4x tconv k4/s2, 3 resblocks @256ch x 2 rows,
-//                         2x tconv k4/s2 -> [4][128] fp32
-//   dec_s1  8 streams/WG  3 fp32 resblocks @128ch x 4 rows -> tconv k10/s5 (two chained GEMM passes) -> [20][64]
-//   dec_s2  4 streams/WG  3 fp32 resblocks @64ch x 20 rows -> tconv k64/s16 -> 320 samples -> int16 PCM
-//
-// Transposed convs run in polyphase form: output block b (s rows) = [x[b-taps+1] .. x[b]] (K = taps*Cin,
-// oldest input first) times W[K][s*Cout] -- per output element exactly the oracle's chain (input position
-// ascending, channel ascending).  The tail rows that belong to the next frame are carried in the state with
-// the bias removed, as the graph does.
-#include "resblock_q.h"
+// dec_kernels.hip -- the three decoder stages as kernels of their own (bodies: dec_stages.h).
+#include "dec_stages.h"
 
 #ifdef LYRA_TIMING
 extern "C" int lyra_hip_debug_timing_d0(long long* out) {
@@ -24,327 +12,8 @@ extern "C" int lyra_hip_debug_wgtrace_d0(long long* out) {
 
 namespace lyra {
 
-// =============================================================================================
-// stage 0 -- like encoder stage 2 a long chain of small dependent phases: small tile (S = 8 streams, 512 threads,
-// ~68 KB LDS), two workgroups per CU.  Rows of [2][S] matrices are t*S + s (one 16-row MFMA tile); GEMMs whose
-// rows are just the 8 streams fold two N tiles into the idle upper lanes before their epilogue (fold_rows8).
-// =============================================================================================
-namespace {
-constexpr int SD0 = 8;
-constexpr int FS = 72;      // feature row stride (64 + 8) floats
-constexpr int CS2 = 264;    // 256 + 8 floats
-constexpr int QS = 288;     // int8 row stride, C = 256
-constexpr int QS5 = 544;    // int8 row stride, C = 512
-constexpr int NTD0 = 512;
-constexpr int MTD0 = (2 * SD0) / 16;
-constexpr int FB_FLOATS = 3 * 16 * FS;      // sized for a full 16-row M tile (rows >= S are padding)
-constexpr int XF_FLOATS = 2 * SD0 * CS2;
-constexpr int H8_BYTES = 16 * QS5;
-constexpr int QB_BYTES = 2 * SD0 * QS;      // [2][S] rows = one 16-row M tile
-constexpr int QA_BYTES = 2 * 16 * QS;       // 2 M tiles of 16 rows: the up1 GEMM reads [t][16 rows]
-constexpr int NLR = 6, NADD = 2;            // LeakyReLU / ADD lookup tables (resblock_q.h)
-static_assert(SD0 == 8, "tile size the index math below supports");
-}  // namespace
-
-size_t dec_s0_lds_bytes() {
-  return (size_t)(FB_FLOATS + XF_FLOATS) * 4 + H8_BYTES + 3 * QB_BYTES + QA_BYTES + 2 * SD0 * 4 + NLR * 256 +
-         NADD * 2048;
-}
+size_t dec_s0_lds_bytes() { return dec_s0_lds(); }
 int dec_s0_streams_per_wg() { return SD0; }
-
-// feats != nullptr: lossy features [B][64] (GenerativeModel::AddFeatures path).  Otherwise the features are rebuilt
-// here from the packets exactly as rvq_decode_kernel does (quantizer.tflite `decode` + DecodeToLossyFeatures,
-// residual_vector_quantizer.cc:112-168): ((v0 + v1) + v2) + ... left to right, unused stages contribute v * 0.0f.
-// MODE: requantisation flavour, compile-time (see enc_s2_kernel.hip).
-template <int MODE>
-__device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
-                                            const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
-                                            float* __restrict__ out0, const uint8_t* __restrict__ packets, int num_stages,
-                                            const float* __restrict__ cb, int code_bytes) {
-  const DecS0P& P = *Pp;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* FB = smem;                                   // [3][16][72]: two history rows + new features (rows s < S used)
-  float* XF = FB + FB_FLOATS;                         // [2][S][264]: x164 (float skip of resblock 0)
-  int8_t* H8 = reinterpret_cast<int8_t*>(XF + XF_FLOATS);  // [16][544]
-  int8_t* QX = H8 + H8_BYTES;
-  int8_t* QA = QX + QB_BYTES;
-  int8_t* QD = QA + QA_BYTES;
-  int8_t* QP = QD + QB_BYTES;
-  int* sids = reinterpret_cast<int*>(QP + QB_BYTES);
-  int* sphase = sids + SD0;
-  int32_t* LA = sphase + SD0;                                // [NADD][2][256] ADD operand tables
-  int8_t* LQ = reinterpret_cast<int8_t*>(LA + NADD * 512);   // [NLR][256] LeakyReLU tables
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * SD0;
-  constexpr int mode = MODE;
-  wg_schedule_hint();
-  LYRA_TSTAMP(40);
-  LYRA_WSTAMP(100);
-  LYRA_WG_BEGIN();
-  if (tid < SD0) {
-    int id = ids[min(b0 + tid, B - 1)];
-    sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::D0_BYTES + st::PHASE);
-  }
-  load_luts<NTD0>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
-  const auto warm = l2_warm<NTD0, 1>(P.warm);
-  const auto warm_code = code_warm<NTD0>(code_bytes);
-  const auto warm_cb = l2_warm<NTD0, 1>(feats ? WarmRange{nullptr, 0} : WarmRange{reinterpret_cast<const uint8_t*>(cb), 46 * 16 * 64 * 4});
-  __syncthreads();
-  TileCtx cx{state, sids, sphase, B - b0, st::D0_BYTES};
-
-  // ---- feature window [f-2, f-1, f] (history ring R=2, T=1); GEMM rows = streams, 16-row tile ----------
-  {
-    const int c = tid & 63, s = tid >> 6;          // SD0 * 64 == NTD0: one feature element per thread
-    const int b = min(b0 + s, B - 1);
-    float f;
-    if (feats) {
-      f = feats[(size_t)b * 64 + c];
-    } else {
-      const int nbytes = (num_stages + 1) >> 1;
-      const uint8_t* pk = packets + (size_t)b * nbytes;
-      f = 0.f;
-#pragma unroll 23
-      for (int k = 0; k < 46; ++k) {   // addresses depend only on the packet: 23 codebook loads in flight at a time
-        const int id = k < num_stages ? ((pk[k >> 1] >> ((k & 1) ? 0 : 4)) & 15) : -1;
-        const float mask = id != -1 ? 1.f : 0.f;
-        const int i = id < 0 ? 0 : id;
-        const float v = cb[((size_t)k * 16 + i) * 64 + c] * mask;
-        f = k == 0 ? v : f + v;
-      }
-    }
-    FB[(2 * 16 + s) * FS + at16(c)] = f;
-  }
-  for (int idx = tid; idx < 2 * SD0 * 16; idx += NTD0) {
-    int p4 = idx & 15, s = (idx >> 4) & (SD0 - 1), j = (idx >> 4) / SD0;
-    int slot = (sphase[s] + j) & 1;
-    *reinterpret_cast<f32x4*>(&FB[(j * 16 + s) * FS + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4);
-  }
-  __syncthreads();
-  for (int idx = tid; idx < SD0 * 16; idx += NTD0) {
-    int p4 = idx & 15, s = idx >> 4;
-    int slot = sphase[s] & 1;
-    if (cx.valid(s))
-      *reinterpret_cast<f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4) =
-          *reinterpret_cast<const f32x4*>(&FB[(2 * 16 + s) * FS + p4 * 4]);
-  }
-  LYRA_TSTAMP(41);
-  {  // conv k3 g4: per group [16 rows] x K=48 x N=128; LeakyReLU; QUANTIZE -> H8
-    f32x4 acc[1][4];
-    const int g = wave >> 1;
-    auto aoff = [&](int i, int c) { return (c * 16 + m) * FS + g * 16 + q * 4; };
-    gemm_f32<1, 4, 3>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, acc);
-    fold_rows8<2>(acc[0]);   // rows = 8 streams: lanes 32-63 take over N tiles 2, 3
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int n = (wave * 4 + j + 2 * (lane >> 5)) * 16 + (lane & 15);
-      float bias = as_global(P.head.b)[n];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        H8[((q & 1) * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0.s, P.q0.z);
-    }
-  }
-  __syncthreads();
-  LYRA_TSTAMP(42);
-  {  // 4 grouped int8 transposed convs k4/s2 (one input row -> 4 output rows), carried tail of 2 rows
-    i32x4 acc[1][8];
-    const int g = wave >> 1;
-    const TconvQ U = P.up0[g];
-    auto aoff = [&](int i, int c) { return m * QS5 + g * 128 + c * 64 + q * 16; };
-    // after fold_rows8 lane L works on channel tile ct, streams (q & 1) * 4 + e: request its epilogue operands
-    // (carried tail rows, bias, fold terms) before the GEMM so that their latency overlaps it
-    const int ct = (wave & 1) * 2 + (lane >> 5);
-    const int co = ct * 16 + (lane & 15);
-    const int bias = as_global(U.bias)[co];
-    const float sub = as_global(P.up0_sub[g])[co];
-    const int pc = at16(g * 64 + co);
-    int zfv[4];
-#pragma unroll
-    for (int tap = 0; tap < 4; ++tap) zfv[tap] = as_global(U.zfold)[tap * 64 + co];
-    float told[2][4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float LYRA_GLOBAL* stp =
-          as_global(reinterpret_cast<const float*>(cx.sbase((q & 1) * 4 + e) + st::D_UP0 + g * 512));
-      told[0][e] = stp[co];
-      told[1][e] = stp[64 + co];
-    }
-    gemm_i8<1, 8, 2>(H8, aoff, U.w + ((wave & 1) * 8) * 2 * 64, acc);
-    fold_rows8<4>(acc[0]);   // lanes 32-63 take over this wave's second channel tile (N tiles 4..7)
-#pragma unroll
-    for (int tap = 0; tap < 4; ++tap) {
-      const int zf = zfv[tap];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int s = (q & 1) * 4 + e;
-        float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP0 + g * 512);
-        int c8 = clamp8(requant(acc[0][tap][e] + zf + bias, U.M, U.sh, mode) + U.zout);
-        float y = dequantize_f(c8, P.up0_dq[g].s, P.up0_dq[g].z);
-        if (tap < 2) {
-          y = y + told[tap < 2 ? tap : 0][e];
-          XF[(tap * SD0 + s) * CS2 + pc] = y;
-        } else {
-          y = y + 0.f;
-          if (cx.valid(s)) stp[(tap - 2) * 64 + co] = y - sub;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  LYRA_TSTAMP(43);
-  // ---- a0 = QUANTIZE(lrelu(x164)); resblock 0 (int8 body, float skip) depthwise, dilation 1 --------------
-  // Thread (s, w4) owns channels 4*w4 .. 4*w4+3 of stream s for both rows: quantize -> depthwise over
-  // [a(t-2), a(t-1), a(t)] -> history (2 rows, replaced) stay in registers; no LDS round trip, one barrier.
-  const RbqPre pre1 = resblock_q_prefetch<SD0>(cx, 3, st::D_R0_1, P.dwq[1], P.pwq[1], P.cvq[1]);
-  {
-    const DwQ dq = P.dwq[0];
-    const int w4 = tid & 63, s = tid >> 6;
-    uint8_t* hp = cx.sbase(s) + st::D_R0_0 + w4 * 4;
-    const int h0 = *reinterpret_cast<const int*>(hp), h1 = *reinterpret_cast<const int*>(hp + 256);
-    int ww[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) ww[j] = *reinterpret_cast<const int LYRA_GLOBAL*>(&as_global(dq.w)[j * 256 + w4 * 4]);
-    const i32x4 db = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.b)[w4 * 4]);
-    const i32x4 dM = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.M)[w4 * 4]);
-    const i32x4 dsh = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.sh)[w4 * 4]);
-    int a[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      int c8[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        c8[e] = quantize_f(lrelu(XF[(t * SD0 + s) * CS2 + at16(w4 * 4 + e)]), P.q1.s, P.q1.z);
-      a[t] = pack8(c8[0], c8[1], c8[2], c8[3]);
-    }
-    const int x[2][3] = {{h0, h1, a[0]}, {h1, a[0], a[1]}};
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      int o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int acc = db[e];                                  // zero point folded into dq.b
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc += sx8(x[t][j], e) * sx8(ww[j], e);
-        o[e] = clamp8(requant(acc, dM[e], dsh[e], mode) + dq.zout);
-      }
-      *reinterpret_cast<int*>(&QD[(t * SD0 + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
-      if (cx.valid(s)) *reinterpret_cast<int*>(hp + t * 256) = a[t];
-    }
-    __syncthreads();
-    LYRA_TSTAMP(44);
-    {
-      i32x4 acc[MTD0][2];
-      auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
-      gemm_i8<MTD0, 2, 4>(QD, aoff, P.pwq[0].w + (wave * 2) * 4 * 64, acc);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int n = (wave * 2 + j) * 16 + (lane & 15);
-        int bias = as_global(P.pwq[0].b)[n], M = as_global(P.pwq[0].M)[n], sh = as_global(P.pwq[0].sh)[n];
-#pragma unroll
-        for (int i = 0; i < MTD0; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.pwq[0].zout);
-            QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lut8(LQ, c8);
-          }
-      }
-    }
-    __syncthreads();
-    {
-      i32x4 acc[MTD0][2];
-      const int g = wave >> 1;
-      auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 64 + q * 16; };
-      gemm_i8<MTD0, 2, 1>(QP, aoff, P.cvq[0].w + (wave * 2) * 64, acc);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int n = (wave * 2 + j) * 16 + (lane & 15);
-        int bias = as_global(P.cvq[0].b)[n], M = as_global(P.cvq[0].M)[n], sh = as_global(P.cvq[0].sh)[n];
-        int pc = at16(n);
-#pragma unroll
-        for (int i = 0; i < MTD0; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int row = i * 16 + q * 4 + e;
-            int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.cvq[0].zout);
-            float v = dequantize_f(c8, P.dq_r0.s, P.dq_r0.z) + XF[row * CS2 + pc];
-            QX[row * QS + n] = (int8_t)quantize_f(v, P.q3.s, P.q3.z);
-          }
-      }
-    }
-    __syncthreads();
-  }
-  LYRA_TSTAMP(45);
-  const RbqPre pre2 = resblock_q_prefetch<SD0>(cx, 9, st::D_R0_2, P.dwq[2], P.pwq[2], P.cvq[2]);
-  resblock_q256<SD0>(QX, QD, QP, cx, 3, st::D_R0_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[1], P.pwq[1], P.cvq[1],
-                     P.add[0], LA, mode, pre1, 20);
-  resblock_q256<SD0>(QX, QD, QP, cx, 9, st::D_R0_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[2], P.pwq[2], P.cvq[2],
-                     P.add[1], LA + 512, mode, pre2, 30);
-  LYRA_TSTAMP(46);
-  // a = int8 LeakyReLU(X3), laid out for the up1 GEMM as [t][16 rows][QS] (rows s >= S are padding)
-  for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
-    int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
-    int w = *reinterpret_cast<const int*>(&QX[(t * SD0 + s) * QS + w4 * 4]);
-    *reinterpret_cast<int*>(&QA[(t * 16 + s) * QS + w4 * 4]) =
-        lut8w(LQ + 5 * 256, w);
-  }
-  __syncthreads();
-  LYRA_TSTAMP(47);
-  {  // 2 grouped int8 transposed convs k4/s2: rows t=0,1 -> 6 output rows (integer overlap-add), tail of 2
-    i32x4 acc[2][4];
-    const int g = wave >> 2, ct = wave & 3;
-    const TconvQ U = P.up1[g];
-    auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 128 + c * 64 + q * 16; };
-    gemm_i8<2, 4, 2>(QA, aoff, U.w + (ct * 4) * 2 * 64, acc);
-    const int co = ct * 16 + (lane & 15);
-    const int bias = as_global(U.bias)[co];
-    const float sub = as_global(P.up1_sub[g])[co];
-    const int pc = at16(g * 64 + co);
-    int zf[4];
-#pragma unroll
-    for (int tap = 0; tap < 4; ++tap) zf[tap] = as_global(U.zfold)[tap * 64 + co];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int s = q * 4 + e;
-      if (s >= SD0) continue;
-      float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP1 + g * 512);
-      int o[6];
-      o[0] = acc[0][0][e] + zf[0];
-      o[1] = acc[0][1][e] + zf[1];
-      o[2] = (acc[0][2][e] + zf[2]) + (acc[1][0][e] + zf[0]);
-      o[3] = (acc[0][3][e] + zf[3]) + (acc[1][1][e] + zf[1]);
-      o[4] = acc[1][2][e] + zf[2];
-      o[5] = acc[1][3][e] + zf[3];
-      float y[6];
-#pragma unroll
-      for (int tau = 0; tau < 6; ++tau) {
-        int c8 = clamp8(requant(o[tau] + bias, U.M, U.sh, mode) + U.zout);
-        y[tau] = dequantize_f(c8, P.up1_dq[g].s, P.up1_dq[g].z);
-      }
-      y[0] = y[0] + stp[co];
-      y[1] = y[1] + stp[64 + co];
-#pragma unroll
-      for (int tau = 2; tau < 6; ++tau) y[tau] = y[tau] + 0.f;
-      if (cx.valid(s)) {
-#pragma unroll
-        for (int tau = 0; tau < 4; ++tau) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = y[tau];
-        stp[co] = y[4] - sub;
-        stp[64 + co] = y[5] - sub;
-      }
-    }
-  }
-  LYRA_TSTAMP(48);
-  LYRA_WSTAMP(101);
-  LYRA_WG_END();
-  if (tid < SD0 && cx.valid(tid)) {   // this region's ring phase
-    int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
-  }
-  l2_warm_sink(warm_cb, state, B);
-  l2_warm_sink(warm, state, B);
-  l2_warm_sink(warm_code, state, B);
-}
 
 __global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                        const int32_t* __restrict__ ids, int B,
@@ -361,133 +30,15 @@ __global__ __launch_bounds__(NTD0, 4) void dec_s0_dr_kernel(const DecS0P* __rest
   dec_s0_body<1>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
 }
 
-// =============================================================================================
-// stage 1
-// =============================================================================================
-namespace {
-constexpr int SD1 = 8;
-constexpr int CS1 = 136;
-#ifndef LYRA_S1_THREADS
-#define LYRA_S1_THREADS 512   // 8 waves per tile: 4 waves per SIMD with two tiles per CU (256 = the 4-wave layout)
-#endif
-constexpr int NTD1 = LYRA_S1_THREADS;
-}  // namespace
-
-// tconv k10/s5, polyphase: output block b (5 rows x 64 ch = N 320) = x[b-1] . W[taps 5..9] then x[b] . W[taps 0..4],
-// ONE fp32 chain per output (earlier input first).  Pass 1 runs every input row t against taps 5..9 (the
-// partial chains of block t+1), the C tiles are shifted down by one input row (8 of a tile's 16 rows:
-// a 32-lane rotation) and become pass 2's initial accumulators; block 4 = x[3] alone is the carried tail.
-// A wave computes NTW of the 20 N tiles starting at tile0.
-template <int NTW>
-__device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, const DecS1P& P, const TileCtx& cx,
-                                             int b0, float* __restrict__ out1, int tile0) {
-  const int lane = threadIdx.x & 63;
-  const int m = lane & 15, q = lane >> 4;
-  f32x4 acc[2][NTW];
-  auto aoff = [&](int i, int c) {
-    int R = i * 16 + m, t = R / SD1, s = R & (SD1 - 1);
-    return (t * SD1 + s) * CS1 + c * 16 + q * 4;
-  };
-  const f32x4* wfrag = P.up.w + tile0 * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 5..9, 8-15 taps 0..4
-  gemm_f32<2, NTW, 8, 16>(XB, aoff, wfrag, acc);
-  f32x4 tail[NTW];
-  const bool lo = lane < 32;
-#pragma unroll
-  for (int j = 0; j < NTW; ++j)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = acc[0][j][e], bb = acc[1][j][e];
-      rot32_pair(a, bb);                       // a = [Y(t1), Y(t0)], bb = [Y(t3), Y(t2)]
-      acc[0][j][e] = lo ? 0.f : a;             // blocks 0 | 1  <-  0     | Y(t0)
-      acc[1][j][e] = lo ? a : bb;              // blocks 2 | 3  <-  Y(t1) | Y(t2)
-      tail[j][e] = bb;                         // lanes 0-31: block 4 = Y(t3)
-    }
-  gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int n = (tile0 + j) * 16 + (lane & 15);
-    const int jj = n >> 6, co = n & 63;
-    const float bias = as_global(P.up.b)[co], sub = as_global(P.up_sub)[co];
-    const int pc = at16(co);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int R = i * 16 + q * 4 + e, b = R / SD1, s = R & (SD1 - 1);
-        const int tau = 5 * b + jj;
-        float y = acc[i][j][e] + bias;
-        y = y + (tau < 5 ? SB[(tau * SD1 + s) * 72 + co] : 0.f);
-        if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + tau) * 64 + pc] = y;
-      }
-    if (lo) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int s = q * 4 + e;
-        float y = tail[j][e] + bias;
-        y = y + 0.f;
-        if (cx.valid(s)) reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y - sub;
-      }
-    }
-  }
-}
-
-size_t dec_s1_lds_bytes() { return (size_t)(4 * SD1 * CS1 + 4 * SD1 * CS1 + 5 * SD1 * 72) * 4 + 2 * SD1 * 4; }
+size_t dec_s1_lds_bytes() { return dec_s1_lds(); }
 int dec_s1_streams_per_wg() { return SD1; }
 int dec_s1_threads() { return NTD1; }
 
 __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
-                                                          const int32_t* __restrict__ ids, int B,
-                                                          uint8_t* __restrict__ state, float* __restrict__ out1,
-                                                          int code_bytes) {
-  const DecS1P& P = *Pp;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XB = smem;                     // [4][S][136]: X[t]
-  float* DB = XB + 4 * SD1 * CS1;       // [4][S][136]
-  float* SB = DB + 4 * SD1 * CS1;       // [5][S][72]: tail of the previous frame's transposed conv
-  int* sids = reinterpret_cast<int*>(SB + 5 * SD1 * 72);
-  int* sphase = sids + SD1;
-  wg_schedule_hint();
-  const int tid = threadIdx.x, wave = tid >> 6;
-  const int b0 = blockIdx.x * SD1;
-  if (tid < SD1) {
-    int id = ids[min(b0 + tid, B - 1)];
-    sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::D1_BYTES + st::PHASE);
-  }
-  const auto warm = l2_warm<NTD1, 2>(P.warm);
-  const auto warm_code = code_warm<NTD1>(code_bytes);
-  __syncthreads();
-  TileCtx cx{state, sids, sphase, B - b0, st::D1_BYTES};
-  const auto H0 = hist128_prefetch<SD1, NTD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
-  for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
-    int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
-    int b = min(b0 + s, B - 1);
-    *reinterpret_cast<f32x4*>(&XB[(t * SD1 + s) * CS1 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
-  }
-  for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {   // carried tail: fetched with the input, used at the end
-    int p4 = idx & 15, s = (idx >> 4) & (SD1 - 1), j = (idx >> 4) / SD1;
-    *reinterpret_cast<f32x4*>(&SB[(j * SD1 + s) * 72 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
-  }
-  __syncthreads();
-  resblocks128<SD1, NTD1>(XB, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2, H0);
-  for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
-    int p4 = idx & 31, rs = idx >> 5;
-    f32x4* x = reinterpret_cast<f32x4*>(&XB[rs * CS1 + p4 * 4]);
-    *x = lrelu4(*x);
-  }
-  __syncthreads();
-  // transposed conv k10/s5: 20 N tiles over the waves (5 each with 4 waves; 3,3,3,3,2,2,2,2 with 8)
-  if (NTD1 == 256) dec_s1_tconv<5>(XB, SB, P, cx, b0, out1, wave * 5);
-  else if (wave < 4) dec_s1_tconv<3>(XB, SB, P, cx, b0, out1, wave * 3);
-  else dec_s1_tconv<2>(XB, SB, P, cx, b0, out1, 12 + (wave - 4) * 2);
-  if (tid < SD1 && cx.valid(tid)) {   // this region's ring phase
-    int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
-  }
-  l2_warm_sink(warm, state, B);
-  l2_warm_sink(warm_code, state, B);
+                                                                          const int32_t* __restrict__ ids, int B,
+                                                                          uint8_t* __restrict__ state, float* __restrict__ out1,
+                                                                          int code_bytes) {
+  dec_s1_body(*Pp, in0, ids, B, state, out1, code_bytes);
 }
 
 #ifdef LYRA_WAVE_PRIVATE
@@ -501,7 +52,6 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
 namespace lyra {
 namespace {
 constexpr int SD2 = 16;
-constexpr int CS0 = 72;
 constexpr int NTD2 = 640;
 }  // namespace
 
@@ -591,103 +141,23 @@ __global__ __launch_bounds__(NTD2, 3) void dec_s2_kernel(const DecS2P* __restric
   l2_warm_sink(warm_code, state, B);
 }
 #else
-// =============================================================================================
-// stage 2
-// =============================================================================================
 namespace {
 #ifndef LYRA_S0_STREAMS
 #define LYRA_S0_STREAMS 4
 #endif
 constexpr int SD2 = LYRA_S0_STREAMS;   // 4 streams with 256 threads, or 8 with 512
-constexpr int CS0 = 72;
-constexpr int NTD2 = 64 * SD2;
 }  // namespace
 
-size_t dec_s2_lds_bytes() { return (size_t)(27 * SD2 * CS0 + SD2 * 48) * 4 + 64; }
+size_t dec_s2_lds_bytes() { return dec_s2_lds(SD2); }
 int dec_s2_streams_per_wg() { return SD2; }
-int dec_s2_threads() { return NTD2; }
+int dec_s2_threads() { return 64 * SD2; }
 
-__global__ __launch_bounds__(NTD2, 4) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
-                                                          const int32_t* __restrict__ ids, int B,
-                                                          uint8_t* __restrict__ state, int16_t* __restrict__ pcm,
-                                                          int code_bytes) {
-  const DecS2P& P = *Pp;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* XB = smem;                     // [27][S][72]: rows 0-2 zeros, rows 3-22 activations, rows 23-26 zeros
-  float* SB = XB + 27 * SD2 * CS0;      // old overlap tail [S][48]
-  int* sids = reinterpret_cast<int*>(SB + SD2 * 48);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, q = lane >> 4;
-  wg_schedule_hint();
-  const int b0 = blockIdx.x * SD2;
-  if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
-  const auto warm = l2_warm<NTD2, 1>(P.warm);
-  const auto warm_code = code_warm<NTD2>(code_bytes);
-  __syncthreads();
-  TileCtx cx{state, sids, nullptr, B - b0, st::D2_BYTES};   // T = 20 >= every 2*dilation: no ring, no phase
-  const int wn = wave & 3, wm = wave >> 2;
-  const int pcol = at16(wn * 16 + (lane & 15));
-  f32x4 xr[5][1];  // residual stream in registers (MFMA C layout)
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / SD2, s = R & (SD2 - 1);
-      int b = min(b0 + s, B - 1);
-      xr[i][0][e] = in1[((size_t)b * 20 + t) * 64 + pcol];
-    }
-  for (int idx = tid; idx < 7 * SD2 * 16; idx += NTD2) {
-    int p4 = idx & 15, s = (idx >> 4) & (SD2 - 1), j = (idx >> 4) / SD2;
-    int row = j < 3 ? j : 20 + j;
-    *reinterpret_cast<f32x4*>(&XB[(row * SD2 + s) * CS0 + p4 * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  for (int idx = tid; idx < SD2 * 48; idx += NTD2) {
-    int s = idx / 48, i = idx - s * 48;
-    SB[idx] = reinterpret_cast<const float*>(cx.sbase(s) + st::D_UP3)[i];
-  }
-  resblocks64r<SD2, NTD2>(xr, XB + 3 * SD2 * CS0, cx, P.dw, P.pw, P.cv, st::D_R2_0, st::D_R2_1, st::D_R2_2);
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
-  __syncthreads();
-  // tconv k64/s16, polyphase: blocks b = 0..22 (+1 of padding), rows (b, s); K = 4 x 64 (oldest input first);
-  // N = 16 phases.  24*S rows = 6 M tiles per 4 streams: waves 0..(3 * S / 4 - 1) take two each.
-  if (wave < 3 * SD2 / 4) {
-    f32x4 acc[2][1];
-    auto aoff = [&](int i, int c) {
-      int R = (2 * wave + i) * 16 + m, b = R / SD2, s = R & (SD2 - 1);
-      return ((b + (c >> 2)) * SD2 + s) * CS0 + (c & 3) * 16 + q * 4;
-    };
-    gemm_f32<2, 1, 16>(XB, aoff, P.up.w, acc);
-    const int j = lane & 15;
-    const float bias = as_global(P.up.b)[0];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int R = (2 * wave + i) * 16 + q * 4 + e, b = R / SD2, s = R & (SD2 - 1);
-        if (b > 22) continue;
-        const int tau = 16 * b + j;
-        float y = acc[i][0][e] + bias;
-        y = y + (tau < 48 ? SB[s * 48 + tau] : 0.f);
-        if (!cx.valid(s)) continue;
-        if (tau < 320) {
-          // UnitToInt16Scalar (dsp_utils.h:54-88): scale, clip, C truncation
-          float v = y * 32768.f;
-          v = v < -32768.f ? -32768.f : v;
-          v = v > 32767.f ? 32767.f : v;
-          pcm[(size_t)(b0 + s) * 320 + tau] = (int16_t)v;
-        } else {
-          reinterpret_cast<float*>(cx.sbase(s) + st::D_UP3)[tau - 320] = y - P.up_sub;
-        }
-      }
-  }
-  l2_warm_sink(warm, state, B);
-  l2_warm_sink(warm_code, state, B);
+__global__ __launch_bounds__(64 * SD2, 4) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
+                                                            const int32_t* __restrict__ ids, int B,
+                                                            uint8_t* __restrict__ state, int16_t* __restrict__ pcm,
+                                                            int code_bytes) {
+  dec_s2_body<SD2>(*Pp, in1, ids, B, state, pcm, code_bytes);
 }
-
 #endif  // LYRA_WAVE_PRIVATE
 
 }  // namespace lyra

@@ -16,7 +16,7 @@ ctx.L.lyra_hip_debug_timing.argtypes = [ctypes.c_void_p]
 ctx.L.lyra_hip_debug_timing(buf)
 t = np.array(buf[:])
 names = {0: "start", 1: "pcm staged+state", 2: "first conv", 3: "resblocks done", 4: "lrelu+halo", 5: "k10s5 gemm", 6: "end"}
-print("total", t[6] - t[0])
+print("total", t[6] - t[0], "cycles;", (t[101] - t[100]) / 100.0, "us on the 100 MHz clock ->", (t[6] - t[0]) / max(t[101] - t[100], 1) / 10.0, "GHz effective")
 for i in range(1, 7):
     print(f"  {names[i]:20s} {t[i] - t[i-1]:8d}")
 ph = ["->top", "a write+bar", "dw", "bar+state wr+bar", "D write+bar", "pw gemm", "bar+P write+bar", "cv gemm+resid"]
