@@ -3,6 +3,33 @@
 
 namespace lyra {
 
+// The 64-term distance chain of one codeword, dims in ascending order: df = r - c, sq = df * df, sum = sum + sq, three
+// separate fp32 operations per term as the graph's SUB / MUL / SUM (residual_vector_quantizer.cc:77-110 runs them
+// through the `encode` subgraph).  `mine` = the lane's four residual dims; lane d4 of the row holds dims 4*d4..4*d4+3.
+// x(lane L of the 16-lane row) - c: the row broadcast (DPP row_newbcast) rides on the subtraction's first operand, so the
+// residual never travels through LDS and costs no instruction of its own.  (The compiler's DPP combiner does not fold a
+// row_newbcast v_mov into its user, hence the instruction is spelled out; x must not have been written by the two
+// preceding VALU instructions -- stage() separates the update of `mine` from the next chain.)
+template <int L>
+__device__ __forceinline__ float bcast_sub(float x, float c) {
+  float d;
+  asm("v_sub_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(x), "v"(c), "n"(L));
+  return d;
+}
+template <int D4>
+__device__ __forceinline__ void rvq_terms(float& sum, float m0, float m1, float m2, float m3, const f32x4 (&row)[16]) {
+  if constexpr (D4 < 16) {
+    const f32x4 c = row[D4];
+    const f32x4 df = {bcast_sub<D4>(m0, c[0]), bcast_sub<D4>(m1, c[1]), bcast_sub<D4>(m2, c[2]), bcast_sub<D4>(m3, c[3])};
+    const f32x4 sq = df * df;
+    sum = sum + sq[0];
+    sum = sum + sq[1];
+    sum = sum + sq[2];
+    sum = sum + sq[3];
+    rvq_terms<D4 + 1>(sum, m0, m1, m2, m3, row);
+  }
+}
+
 // =============================================================================================
 // RVQ encode: replaces quantizer.tflite `encode` (555 ops) + the bit-string assembly of
 // ResidualVectorQuantizer::Quantize (lyra/residual_vector_quantizer.cc:77-110) + Packet<>::Pack
@@ -33,7 +60,6 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
                                                           int32_t* __restrict__ packet_bytes) {
   constexpr int W = 8, ROW = 68, WFLOATS = W * 16 * ROW;   // 3 x 34 KB of LDS: one workgroup per CU anyway
   __shared__ __attribute__((aligned(16))) float cbs[3][WFLOATS];
-  __shared__ __attribute__((aligned(16))) float rs[16][ROW];
   const int tid = threadIdx.x;
   const int j = tid & 15;
   const int frame = blockIdx.x * 16 + (tid >> 4);
@@ -53,9 +79,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
     for (int v = 0; v < W; ++v) *reinterpret_cast<f32x4*>(dst + v * 16 * ROW) = stage_in[v];
   };
   gload(0);
-  float* rme = rs[tid >> 4];
   f32x4 mine = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + j * 4]);   // this lane's four residual dims
-  *reinterpret_cast<f32x4*>(&rme[j * 4]) = mine;
   lstore(0);
   gload(1);
   __syncthreads();
@@ -78,32 +102,32 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
       gload(win + 2);
       __syncthreads();
     }
-    asm volatile("" ::: "memory");   // rs is rewritten by the other lanes of the frame: never carry it in registers
+    // residual dims 4*d4 .. 4*d4+3 live in lane d4 of the frame's 16-lane row: DPP row broadcast (row_newbcast, folded
+    // into the subtraction's operand fetch) instead of a round trip through LDS
     float sum = 0.f;
-#pragma unroll
-    for (int d4 = 0; d4 < 16; ++d4) {
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(&rme[d4 * 4]);
-      const f32x4 df = rv - row[d4];
-      const f32x4 sq = df * df;
-      sum = sum + sq[0];
-      sum = sum + sq[1];
-      sum = sum + sq[2];
-      sum = sum + sq[3];
+    {
+      float m0 = mine[0], m1 = mine[1], m2 = mine[2], m3 = mine[3];
+      // a DPP operand must not have been written by the two preceding VALU instructions (`mine` is updated at the end
+      // of the previous stage); tied to the data so it cannot be scheduled away from between the two
+      asm volatile("s_nop 1" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
+      rvq_terms<0>(sum, m0, m1, m2, m3, row);
     }
-    // Off the critical path: issued after the chain (the residual reads above must not queue behind it) and before
-    // the reduction, so the 16 reads drain while the DPP steps run and the winner-row read below finds the LDS idle.
+    // Off the critical path: issued after the chain and before the reduction, so the 16 reads drain while the DPP
+    // steps run and the winner-row read below finds the LDS idle.
     __builtin_amdgcn_sched_barrier(0);
     if (k + 1 < num_stages) load_row(next, k + 1);
     __builtin_amdgcn_sched_barrier(0);
     // ARG_MIN = first minimum, branch-free: the row minimum of the distance by a 16-lane all-reduce with DPP row
     // rotations (register-only, no LDS crossbar), then the lowest lane of the frame's 16-lane field that holds it
-    // (ballot + find-first-set).  Distances are sums of squares (>= 0, finite for finite features); fminf returns
-    // one of its operands exactly.
-    float m = sum;
-#define LYRA_ROR_MINF(N) \
-    m = __builtin_fminf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + (N), 0xf, 0xf, false)));
-    LYRA_ROR_MINF(8) LYRA_ROR_MINF(4) LYRA_ROR_MINF(2) LYRA_ROR_MINF(1)
-#undef LYRA_ROR_MINF
+    // (ballot + find-first-set).  Distances are sums of squares (>= +0, finite for finite features).
+    // (as unsigned integers: non-negative floats order like their bit patterns -- one v_min_u32 with a DPP operand per
+    // step instead of move + two canonicalising maxima + minimum)
+    unsigned mbits = __builtin_bit_cast(unsigned, sum);
+#define LYRA_ROR_MINU(N) \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(mbits) : "v"(mbits));
+    LYRA_ROR_MINU(8) LYRA_ROR_MINU(4) LYRA_ROR_MINU(2) LYRA_ROR_MINU(1)
+#undef LYRA_ROR_MINU
+    const float m = __builtin_bit_cast(float, mbits);
     const unsigned long long holders = __builtin_amdgcn_ballot_w64(sum == m);
     const int best = __builtin_ctz((unsigned)(holders >> (tid & 48)) | 0x10000u) & 15;   // (& 15: NaN distances only)
     {  // r <- r - (r + (q - r)), the graph's three separate fp32 ops, on this lane's four dimensions
@@ -112,7 +136,6 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
       const f32x4 t1 = qv - mine;
       const f32x4 t2 = mine + t1;
       mine = mine - t2;
-      *reinterpret_cast<f32x4*>(&rme[j * 4]) = mine;
     }
     if (j == 0 && live) {
       if (indices) indices[(size_t)frame * 46 + k] = best;
