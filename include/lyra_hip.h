@@ -30,15 +30,20 @@
  * do not synchronise.
  *
  * Streams: a context runs two HIP streams -- the ENCODE side (extract,
- * rvq_encode, encode) and the DECODE side (rvq_decode, generate, decode,
- * logmel, and the stateless helpers rvq_decode_dev / logmel_dev count as
- * decode-side calls too); encoder and decoder state are disjoint.  What the
- * library guarantees on the GPU, without any caller synchronisation:
+ * rvq_encode, the feature extractor of encode) and the DECODE side (rvq_decode,
+ * generate, decode, logmel; the stateless helpers rvq_decode_dev / logmel_dev
+ * count as decode-side calls too); encoder and decoder state are disjoint.
+ * The quantizer of lyra_hip_encode_dev / lyra_hip_encode_dtx_dev runs on the
+ * DECODE-side stream once the features are ready, i.e. in front of the
+ * decode-side work enqueued next: the next call's feature extractor overlaps
+ * it instead of queueing behind a kernel that leaves the chip nearly idle.
+ * What the library guarantees on the GPU, without any caller synchronisation:
  *   (1) a decode-side call is ordered after EVERY earlier encode-side call, so
  *       encode_dev -> decode_dev on the produced packets just works;
- *   (2) an encode-side call is ordered after every earlier decode-side call
- *       EXCEPT THE MOST RECENT ONE: encode of frame i+1 overlaps decode of
- *       frame i, but not decode of frame i-1.
+ *   (2) the outputs of an encode-side call are written after every earlier
+ *       decode-side call EXCEPT (at most) THE MOST RECENT ONE has finished:
+ *       encode of frame i+1 overlaps decode of frame i, but its packets never
+ *       overtake the decode of frame i-1.
  * Two-buffer rule for `_dev` callers: alternate two packet/PCM buffer sets
  * (step i uses set i & 1).  By (2) the encode that rewrites set i & 1 at step
  * i+2 is ordered after the decode that read it at step i.  A caller that

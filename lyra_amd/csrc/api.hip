@@ -1,11 +1,12 @@
 // api.hip -- the C ABI of include/lyra_hip.h: context, scratch, launches.  No CPU fallback anywhere:
 // every entry point either runs the gfx950 kernels or fails with an error code.
 //
-// Two HIP streams per context: the ENCODE side (extract, rvq_encode, encode) and the DECODE side (rvq_decode,
-// generate, decode, logmel).  Encoder and decoder state are disjoint, so decode of step i can overlap encode of
-// step i+1; every stage kernel is a chain of short dependent phases, and two chains in flight fill each other's
-// bubbles.  Ordering: a decode-side call waits (on the GPU) for every earlier encode-side call; an encode-side call
-// waits for every decode-side call except the most recent one (enc_side_begin; include/lyra_hip.h "Streams").
+// Two HIP streams per context: the ENCODE side (extract, rvq_encode, the extractor of encode) and the DECODE side
+// (rvq_decode, generate, decode, logmel -- and the quantizer of the `_dev` encode calls, see encq_begin).  Encoder and
+// decoder state are disjoint, so decode of step i overlaps the extractor of step i+1; every stage kernel is a chain of
+// short dependent phases, and two chains in flight fill each other's bubbles.  Ordering: a decode-side call waits (on
+// the GPU) for every earlier encode-side call; encode-side outputs never overtake any decode-side call but the most
+// recent one (include/lyra_hip.h "Streams").
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -36,7 +37,12 @@ struct lyra_hip_ctx {
   int nsub = 1;                    // sub-batches a `_dev` call is split into (independent stream pairs)
   hipStream_t se[KMAX] = {};       // encode side
   hipStream_t sd[KMAX] = {};       // decode side
-  hipEvent_t ev_enc[KMAX] = {};    // end of the latest encode-side work on se[k]
+  hipEvent_t ev_enc[KMAX] = {};    // handle (not owned): end of the latest encode-side work of chunk k, one of ev_encs
+  hipEvent_t ev_encs[3][KMAX] = {};// [0], [1]: `_dev` encode calls by parity, recorded on sd[k] after the quantizer;
+                                   // [2]: every other encode-side call, recorded on se[k]
+  bool enc_on_sd[KMAX] = {};       // ev_enc[k] was recorded on sd[k] itself (a decode-side wait on it would be a no-op)
+  hipEvent_t ev_feat[KMAX] = {};   // features of the current `_dev` encode call ready on se[k]
+  long n_encq_calls = 0;           // `_dev` encode calls so far (parity selects the feature buffer and ev_encs slot)
   hipEvent_t ev_dec[2][KMAX] = {}; // end of the two latest decode-side calls on sd[k]
   long n_dec_calls = 0;
   int fused = 0;                   // bit 0: encoder side in one launch, bit 1: decoder side (LYRA_HIP_FUSED)
@@ -54,6 +60,7 @@ struct lyra_hip_ctx {
   float* d_e0 = nullptr;     // [cap][4][128]
   float* d_e1 = nullptr;     // [cap][2][256]
   float* d_feat = nullptr;   // [cap][64]
+  float* d_feat2 = nullptr;  // [cap][64]  second feature buffer of the `_dev` encode calls (alternating)
   float* d_codes = nullptr;  // [cap][64]
   int32_t* d_idx = nullptr;  // [cap][46]
   uint8_t* d_pkt = nullptr;  // [cap][23]
@@ -66,6 +73,7 @@ struct lyra_hip_ctx {
   int32_t* d_flag_enc = nullptr;  // [cap] is_noise, encode side
   int32_t* d_flag_dec = nullptr;  // [cap] is_noise, decode side
   int32_t* d_live_ids = nullptr;  // [cap] stream ids with noise hops masked to -1 (DTX)
+  int32_t* d_live_ids2 = nullptr; // [cap] second mask buffer of lyra_hip_encode_dtx_dev (alternating with the features)
   int32_t* d_pkt_bytes = nullptr; // [cap]
   int16_t* d_rs_in = nullptr;     // [cap][960] resampler staging (host-pointer entry points)
   int16_t* d_rs_out = nullptr;    // [cap][960]
@@ -112,15 +120,15 @@ int sync_all(lyra_hip_ctx* c) {
 }
 
 void free_scratch(lyra_hip_ctx* c) {
-  void* ps[] = {c->d_ids, c->d_ids_dec, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_codes, c->d_idx, c->d_pkt,
+  void* ps[] = {c->d_ids, c->d_ids_dec, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_feat2, c->d_codes, c->d_idx, c->d_pkt,
                 c->d_lossy, c->d_d0, c->d_d1, c->d_pcm_out, c->d_mel, c->d_mel_enc, c->d_flag_enc, c->d_flag_dec,
-                c->d_live_ids, c->d_pkt_bytes, c->d_rs_in, c->d_rs_out};
+                c->d_live_ids, c->d_live_ids2, c->d_pkt_bytes, c->d_rs_in, c->d_rs_out};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   c->d_ids = nullptr; c->d_ids_dec = nullptr; c->d_pcm_in = nullptr; c->d_e0 = nullptr; c->d_e1 = nullptr;
-  c->d_feat = nullptr; c->d_codes = nullptr; c->d_idx = nullptr; c->d_pkt = nullptr; c->d_lossy = nullptr;
+  c->d_feat = nullptr; c->d_feat2 = nullptr; c->d_codes = nullptr; c->d_idx = nullptr; c->d_pkt = nullptr; c->d_lossy = nullptr;
   c->d_d0 = nullptr; c->d_d1 = nullptr; c->d_pcm_out = nullptr; c->d_mel = nullptr; c->d_mel_enc = nullptr;
-  c->d_flag_enc = nullptr; c->d_flag_dec = nullptr; c->d_live_ids = nullptr; c->d_pkt_bytes = nullptr;
+  c->d_flag_enc = nullptr; c->d_flag_dec = nullptr; c->d_live_ids = nullptr; c->d_live_ids2 = nullptr; c->d_pkt_bytes = nullptr;
   c->d_rs_in = nullptr; c->d_rs_out = nullptr;
   c->cap = 0;
 }
@@ -137,6 +145,7 @@ int ensure_scratch(lyra_hip_ctx* c, int B) {
   HIPCHK(c, dalloc(&c->d_e0, n * 4 * 128));
   HIPCHK(c, dalloc(&c->d_e1, n * 2 * 256));
   HIPCHK(c, dalloc(&c->d_feat, n * 64));
+  HIPCHK(c, dalloc(&c->d_feat2, n * 64));
   HIPCHK(c, dalloc(&c->d_codes, n * 64));
   HIPCHK(c, dalloc(&c->d_idx, n * 46));
   HIPCHK(c, dalloc(&c->d_pkt, n * 23));
@@ -149,6 +158,7 @@ int ensure_scratch(lyra_hip_ctx* c, int B) {
   HIPCHK(c, dalloc(&c->d_flag_enc, n));
   HIPCHK(c, dalloc(&c->d_flag_dec, n));
   HIPCHK(c, dalloc(&c->d_live_ids, n));
+  HIPCHK(c, dalloc(&c->d_live_ids2, n));
   HIPCHK(c, dalloc(&c->d_pkt_bytes, n));
   HIPCHK(c, dalloc(&c->d_rs_in, n * 960));
   HIPCHK(c, dalloc(&c->d_rs_out, n * 960));
@@ -246,11 +256,44 @@ int enc_side_begin(lyra_hip_ctx* c, int k) {
   return 0;
 }
 int enc_side_done(lyra_hip_ctx* c, int k) {
-  HIPCHK(c, hipEventRecord(c->ev_enc[k], c->se[k]));
+  HIPCHK(c, hipEventRecord(c->ev_encs[2][k], c->se[k]));
+  c->ev_enc[k] = c->ev_encs[2][k];
+  c->enc_on_sd[k] = false;
+  return 0;
+}
+// The `_dev` encode calls (lyra_hip_encode_dev, lyra_hip_encode_dtx_dev) run the feature extractor on se[k] and the
+// quantizer on sd[k], in front of the decode-side work enqueued next: rvq_encode is a 46-stage dependent chain on one
+// wavefront per SIMD that leaves the chip nearly idle, and on se[k] it kept the next call's extractor waiting behind
+// it (rocprofv3 timeline: ~50 us of quantizer + ~12 us of cross-stream event latency per step with nothing else
+// running).  On sd[k] the next call's extractor overlaps it, the packets are written in decode-side stream order (so
+// they can never overtake a pending decode that still reads the caller's other buffer: no encode-side wait on the
+// decode side is needed at all), and the features travel through two alternating buffers.
+int encq_begin(lyra_hip_ctx* c, int k) {
+  if (c->serial && c->n_dec_calls >= 1)
+    HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_dec[(c->n_dec_calls - 1) & 1][k], 0));
+  return 0;
+}
+// The feature buffer of this call was last read by the quantizer of the call before the previous one: the extractor's
+// last stage (the only writer) waits for it, stages 0 and 1 do not.
+hipEvent_t encq_buffer_free(lyra_hip_ctx* c, int k) {
+  return c->n_encq_calls >= 2 ? c->ev_encs[c->n_encq_calls & 1][k] : nullptr;
+}
+float* encq_features(lyra_hip_ctx* c) { return (c->n_encq_calls & 1) ? c->d_feat2 : c->d_feat; }
+int encq_handoff(lyra_hip_ctx* c, int k) {   // extractor done on se[k] -> quantizer may start on sd[k]
+  HIPCHK(c, hipEventRecord(c->ev_feat[k], c->se[k]));
+  HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_feat[k], 0));
+  return 0;
+}
+int encq_done(lyra_hip_ctx* c, int k) {
+  const int p = (int)(c->n_encq_calls & 1);
+  HIPCHK(c, hipEventRecord(c->ev_encs[p][k], c->sd[k]));
+  c->ev_enc[k] = c->ev_encs[p][k];
+  c->enc_on_sd[k] = true;
   return 0;
 }
 int dec_side_begin(lyra_hip_ctx* c, int k) {
-  for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0));
+  for (int j = 0; j < c->nsub; ++j)
+    if (!(j == k && c->enc_on_sd[j])) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0));
   return 0;
 }
 int dec_side_done(lyra_hip_ctx* c, int k, int nk = 0) {
@@ -287,13 +330,16 @@ void chunk_of(const lyra_hip_ctx* c, int B, int k, int* lo, int* n) {
 }
 int chunks_for(const lyra_hip_ctx* c, int B) { return (c->nsub > 1 && B >= 64 * c->nsub) ? c->nsub : 1; }
 
-int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat) {
+// before_s2: an event the LAST stage (the only one that writes d_feat) has to wait for -- the earlier stages run ahead.
+int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat,
+                   hipEvent_t before_s2 = nullptr) {
   const Model& M = c->model;
   hipStream_t st_ = c->se[k];
   float* e0 = c->d_e0 + (size_t)lo * 512;
   float* e1 = c->d_e1 + (size_t)lo * 512;
   float* codes = c->d_codes + (size_t)lo * 64;
   if (c->fused & 1) {   // the whole side in one launch (enc_side_kernel.hip)
+    if (before_s2) HIPCHK(c, hipStreamWaitEvent(st_, before_s2, 0));
     { ProfScope ps(c, K_ENC_SIDE, st_);
       hipLaunchKernelGGL(c->mode ? enc_side_dr_kernel : enc_side_kernel, dim3(cdiv(B, 8)), dim3(512), enc_side_lds_bytes(), st_,
                          M.d_enc0, M.d_enc1, M.d_enc2, d_pcm, d_ids, B, c->sm.base[st::R_E0], c->sm.base[st::R_E1],
@@ -308,6 +354,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   { ProfScope ps(c, K_ENC_S1, st_);
     hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes(), st_,
                        M.d_enc1, e0, d_ids, B, c->sm.base[st::R_E1], e1, c->cw[K_ENC_S1]); }
+  if (before_s2) HIPCHK(c, hipStreamWaitEvent(st_, before_s2, 0));
   { ProfScope ps(c, K_ENC_S2, st_);
     hipLaunchKernelGGL(c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512),
                        enc_s2_lds_bytes(), st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
@@ -318,9 +365,11 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
 }
 
 int launch_rvq_encode(lyra_hip_ctx* c, int k, int B, const float* d_feat, int num_stages, int32_t* d_idx,
-                      uint8_t* d_pkt, const int32_t* d_mask_ids = nullptr, int32_t* d_pkt_bytes = nullptr) {
-  { ProfScope ps(c, K_RVQ_ENC, c->se[k]);
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, c->se[k], c->model.cb, d_feat, B,
+                      uint8_t* d_pkt, const int32_t* d_mask_ids = nullptr, int32_t* d_pkt_bytes = nullptr,
+                      bool on_decode_stream = false) {
+  hipStream_t st_ = on_decode_stream ? c->sd[k] : c->se[k];
+  { ProfScope ps(c, K_RVQ_ENC, st_);
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, st_, c->model.cb, d_feat, B,
                        num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes); }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -485,12 +534,18 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     int ns = ev ? atoi(ev) : 1;  // measured on MI355X at B = 4096: 1 -> 488 us/step, 2 -> 548, 4 -> 737
     c->nsub = ns < 1 ? 1 : (ns > lyra_hip_ctx::KMAX ? lyra_hip_ctx::KMAX : ns);
   }
+  // The internal events only order work of this device's streams against each other: no system-scope fence (cache
+  // write-back) when they are recorded -- a recorded event costs ~5.5 us of stream bubble with it (rocprofv3 timeline).
+  const unsigned evflags = hipEventDisableTiming | (getenv("LYRA_HIP_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
   for (int k = 0; k < c->nsub; ++k)
     if (hipStreamCreateWithFlags(&c->se[k], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sd[k], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_enc[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_dec[0][k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_dec[1][k], hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_encs[0][k], evflags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_encs[1][k], evflags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_encs[2][k], evflags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_feat[k], evflags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dec[0][k], evflags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dec[1][k], evflags) != hipSuccess)
       return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
@@ -534,7 +589,9 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->ev_caller) (void)hipEventDestroy(c->ev_caller);
   for (int k = 0; k < lyra_hip_ctx::KMAX; ++k) {
-    if (c->ev_enc[k]) (void)hipEventDestroy(c->ev_enc[k]);
+    for (int i = 0; i < 3; ++i)
+      if (c->ev_encs[i][k]) (void)hipEventDestroy(c->ev_encs[i][k]);
+    if (c->ev_feat[k]) (void)hipEventDestroy(c->ev_feat[k]);
     if (c->ev_dec[0][k]) (void)hipEventDestroy(c->ev_dec[0][k]);
     if (c->ev_dec[1][k]) (void)hipEventDestroy(c->ev_dec[1][k]);
     if (c->se[k]) (void)hipStreamDestroy(c->se[k]);
@@ -669,12 +726,15 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    if ((rc = enc_side_begin(c, k))) break;
-    float* feat = c->d_feat + (size_t)lo * 64;
-    rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, feat);
-    if (!rc) rc = launch_rvq_encode(c, k, n, feat, num_bits / 4, nullptr, d_packets + (size_t)lo * nbytes);
-    if (!rc) rc = enc_side_done(c, k);
+    if ((rc = encq_begin(c, k))) break;
+    float* feat = encq_features(c) + (size_t)lo * 64;
+    rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, feat, encq_buffer_free(c, k));
+    if (!rc) rc = encq_handoff(c, k);
+    if (!rc) rc = launch_rvq_encode(c, k, n, feat, num_bits / 4, nullptr, d_packets + (size_t)lo * nbytes, nullptr, nullptr,
+                                    true);
+    if (!rc) rc = encq_done(c, k);
   }
+  c->n_encq_calls++;
   return rc;
 }
 
@@ -872,12 +932,20 @@ int lyra_hip_encode_dtx_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const 
   if (!d_ids || !d_pcm || !d_packets || !d_packet_bytes) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   DEVSCOPE(c);
   if ((rc = ensure_scratch(c, B))) return rc;
-  if ((rc = enc_side_begin(c, 0))) return rc;
+  if ((rc = encq_begin(c, 0))) return rc;
   // lyra_encoder.cc:131-141: the noise estimator sees every hop; only non-noise hops reach the feature extractor
-  rc = launch_noise(c, 0, d_ids, B, d_pcm, c->d_flag_enc, c->d_live_ids);
-  if (!rc) rc = launch_extract(c, 0, 0, c->d_live_ids, B, d_pcm, c->d_feat);
-  if (!rc) rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, nullptr, d_packets, c->d_live_ids, d_packet_bytes);
-  if (!rc) rc = enc_side_done(c, 0);
+  // (d_live_ids / d_flag_enc are rewritten by the next call's noise kernel on se[0]: it must not overtake this call's
+  // quantizer, which reads d_live_ids on sd[0] -- the next call's encq_begin waits for the call before the previous
+  // one only, so the mask travels with the features: one buffer per parity)
+  float* feat = encq_features(c);
+  int32_t* live = (c->n_encq_calls & 1) ? c->d_live_ids2 : c->d_live_ids;
+  if (hipEvent_t e = encq_buffer_free(c, 0)) HIPCHK(c, hipStreamWaitEvent(c->se[0], e, 0));   // `live` travels with the features
+  rc = launch_noise(c, 0, d_ids, B, d_pcm, c->d_flag_enc, live);
+  if (!rc) rc = launch_extract(c, 0, 0, live, B, d_pcm, feat);
+  if (!rc) rc = encq_handoff(c, 0);
+  if (!rc) rc = launch_rvq_encode(c, 0, B, feat, num_bits / 4, nullptr, d_packets, live, d_packet_bytes, true);
+  if (!rc) rc = encq_done(c, 0);
+  c->n_encq_calls++;
   return rc;
 }
 

@@ -422,6 +422,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   wg_schedule_hint();
   const int tid = threadIdx.x, wave = tid >> 6;
   const int b0 = blockIdx.x * SD1;
+  LYRA_TSTAMP(50);
   if (tid < SD1) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
@@ -444,6 +445,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
         *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
   }
   __syncthreads();
+  LYRA_TSTAMP(51);
   resblocks128<SD1, NTD1>(XB, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2, H0);
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, rs = idx >> 5;
@@ -484,6 +486,7 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   const int m = lane & 15, q = lane >> 4;
   wg_schedule_hint();
   const int b0 = blockIdx.x * SD2;
+  LYRA_TSTAMP(60);
   if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NTD2, 1>(P.warm);
   const auto warm_code = code_warm<NTD2>(code_bytes);
@@ -509,6 +512,7 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
     int s = idx / 48, i = idx - s * 48;
     SB[idx] = reinterpret_cast<const float*>(cx.sbase(s) + st::D_UP3)[i];
   }
+  LYRA_TSTAMP(61);
   resblocks64r<SD2, NTD2>(xr, XB + 3 * SD2 * CS0, cx, P.dw, P.pw, P.cv, st::D_R2_0, st::D_R2_1, st::D_R2_2);
 #pragma unroll
   for (int i = 0; i < 5; ++i)

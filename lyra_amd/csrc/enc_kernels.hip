@@ -2,6 +2,9 @@
 #include "enc_stages.h"
 
 #ifdef LYRA_TIMING
+extern "C" int lyra_hip_debug_exit_at_s0(int i) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lyra_exit_at), &i, sizeof(int));
+}
 extern "C" int lyra_hip_debug_wgtrace_s0(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_wgtrace), sizeof(long long) * 2048 * 4);
 }

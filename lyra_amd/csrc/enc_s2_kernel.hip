@@ -2,6 +2,9 @@
 #include "enc_s2_stage.h"
 
 #ifdef LYRA_TIMING
+extern "C" int lyra_hip_debug_exit_at_s2(int i) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lyra_exit_at), &i, sizeof(int));
+}
 extern "C" int lyra_hip_debug_timing_s2(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_tdbg), sizeof(long long) * 128);
 }

@@ -24,7 +24,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef LYRA_TIMING
 static __device__ long long g_lyra_tdbg[128];
-#define LYRA_TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lyra_tdbg[i] = clock64(); } while (0)
+// g_lyra_exit_at = i: every workgroup of this translation unit's kernels returns at stamp i (top-level stamps only) --
+// the kernel's duration is then the cumulative cost of the phases before it, under the real co-residency.
+static __device__ int g_lyra_exit_at = -1;
+#define LYRA_TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lyra_tdbg[i] = clock64(); \
+    if (g_lyra_exit_at == (i)) return; } while (0)
 #define LYRA_WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lyra_tdbg[i] = wall_clock64(); } while (0)
 // per-workgroup trace: [wg][0] start (100 MHz wall clock), [1] end, [2] HW_ID, [3] XCC_ID
 static __device__ long long g_lyra_wgtrace[2048 * 4];

@@ -1,5 +1,9 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_rvq_million.py tests/test_noise_estimator.py -x -q -m gpu 2>&1 | tail -3
-echo "$(MODES=full python tools/pipeline_probe.py 2>&1 | grep '^full')"
-python bench.py --no-cpu-baseline --no-kernel-table --steps 300 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])'
+python - <<'PY'
+import torch
+print("priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream,"priority_range") else None)
+PY
+for pr in "0,0" "0,-1" "-1,0" "1,-1" "0,-2"; do
+  echo "prio $pr: $(LYRA_HIP_PRIO=$pr python bench.py --no-cpu-baseline --no-kernel-table --steps 300 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')"
+done

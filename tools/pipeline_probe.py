@@ -54,5 +54,16 @@ def run(mode, n=60):
     print(f"{mode:10s} wall/step {wall:7.1f} us | " + "  ".join(f"{k.replace('_kernel','')}={ms / c * 1e3:.1f}" for k, (ms, c) in p.items() if c), flush=True)
 
 
+# EXIT_AT="d0:43,44,.." (timing variant only): every workgroup of that translation unit's kernels returns at the stamp --
+# the kernel's duration is the cumulative cost of the phases before it (outputs are garbage)
+if os.environ.get("EXIT_AT"):
+    tu, stamps = os.environ["EXIT_AT"].split(":")
+    fn = getattr(ctx.L, "lyra_hip_debug_exit_at_" + tu)
+    for st_ in stamps.split(","):
+        fn(int(st_))
+        print("exit_at", tu, st_, end=" | ")
+        run("full", 30)
+    fn(-1)
+    sys.exit(0)
 for m in os.environ.get("MODES", "full,enc,dec,full+gap,full+flush,full").split(","):
     run(m)
