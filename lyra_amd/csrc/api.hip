@@ -45,6 +45,7 @@ struct lyra_hip_ctx {
   long n_encq_calls = 0;           // `_dev` encode calls so far (parity selects the feature buffer and ev_encs slot)
   hipEvent_t ev_dec[2][KMAX] = {}; // end of the two latest decode-side calls on sd[k]
   long n_dec_calls = 0;
+  int rvq_wide = 0;                // LYRA_HIP_RVQ_WIDE: the 104 KB / 244-VGPR quantizer kernel (experiment)
   int fused = 0;                   // bit 0: encoder side in one launch, bit 1: decoder side (LYRA_HIP_FUSED)
   bool serial = false;             // lyra_hip_set_serial: encode side also waits for the latest decode-side call
   hipEvent_t ev_caller = nullptr;  // scratch event for lyra_hip_wait_for_stream / lyra_hip_stream_wait
@@ -369,7 +370,7 @@ int launch_rvq_encode(lyra_hip_ctx* c, int k, int B, const float* d_feat, int nu
                       bool on_decode_stream = false) {
   hipStream_t st_ = on_decode_stream ? c->sd[k] : c->se[k];
   { ProfScope ps(c, K_RVQ_ENC, st_);
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, st_, c->model.cb, d_feat, B,
+    hipLaunchKernelGGL(c->rvq_wide ? rvq_encode_wide_kernel : rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, st_, c->model.cb, d_feat, B,
                        num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes); }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -571,6 +572,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     c->cw[K_ENC_SIDE] = code_warm_bytes("enc_side_dr_kernel"); c->cw[K_DEC_SIDE] = code_warm_bytes("dec_side_dr_kernel");
   }
   if (const char* f = getenv("LYRA_HIP_FUSED")) c->fused = atoi(f);
+  if (const char* f = getenv("LYRA_HIP_RVQ_WIDE")) c->rvq_wide = atoi(f);
   for (int k = 0; k < c->nsub; ++k)
     if (enc_side_done(c, k) != 0) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
   *out = c;

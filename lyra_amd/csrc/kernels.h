@@ -86,6 +86,8 @@ size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg(); int dec_s2_threads();
 // mask_ids (optional): frame i is skipped (empty packet, packet_bytes[i] = 0) where mask_ids[i] < 0
 __global__ void rvq_encode_kernel(const float* cb, const float* feats, int B, int num_stages, int32_t* indices,
                                   uint8_t* packets, const int32_t* mask_ids, int32_t* packet_bytes);
+__global__ void rvq_encode_wide_kernel(const float* cb, const float* feats, int B, int num_stages, int32_t* indices,
+                                  uint8_t* packets, const int32_t* mask_ids, int32_t* packet_bytes);
 __global__ void rvq_decode_kernel(const float* cb, const int32_t* indices, const uint8_t* packets, int num_stages,
                                   int B, float* feats);
 struct MelP { const double* hann; const double* tw_re; const double* tw_im; const int* band; const double* w;

@@ -52,13 +52,14 @@ __device__ __forceinline__ void rvq_terms(float& sum, float m0, float m1, float 
 //    ds_read_b128 across the 16 code lanes), three buffers deep, one barrier per window: window w+1 is already in
 //    LDS while window w computes (the cross-window prefetch needs it), window w+2 is in flight from L2.
 // =============================================================================================
-__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ cb,
-                                                          const float* __restrict__ feats, int B, int num_stages,
-                                                          int32_t* __restrict__ indices,
-                                                          uint8_t* __restrict__ packets,
-                                                          const int32_t* __restrict__ mask_ids,
-                                                          int32_t* __restrict__ packet_bytes) {
-  constexpr int W = 8, ROW = 68, WFLOATS = W * 16 * ROW;   // 3 x 34 KB of LDS: one workgroup per CU anyway
+// W: stages per codebook window; PREFETCH: fetch the next stage's codeword row into a second register set while the
+// current stage reduces (244 VGPRs) or read it at the start of its own stage (<= 128 VGPRs).
+template <int W, bool PREFETCH>
+__device__ __forceinline__ void rvq_encode_body(const float* __restrict__ cb, const float* __restrict__ feats, int B,
+                                                int num_stages, int32_t* __restrict__ indices,
+                                                uint8_t* __restrict__ packets, const int32_t* __restrict__ mask_ids,
+                                                int32_t* __restrict__ packet_bytes) {
+  constexpr int ROW = 68, WFLOATS = W * 16 * ROW;
   __shared__ __attribute__((aligned(16))) float cbs[3][WFLOATS];
   const int tid = threadIdx.x;
   const int j = tid & 15;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
 #pragma unroll
     for (int d4 = 0; d4 < 16; ++d4) row[d4] = *reinterpret_cast<const f32x4*>(&c[d4 * 4]);
   };
-  load_row(rowa, 0);
+  if (PREFETCH) load_row(rowa, 0);
   auto stage = [&](int k, const f32x4 (&row)[16], f32x4 (&next)[16]) {
     const int u = k & (W - 1), win = k / W;
     if (u == 0) {
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
       gload(win + 2);
       __syncthreads();
     }
+    if (!PREFETCH) load_row(next, k);   // (`row` and `next` are the same register set then)
     // residual dims 4*d4 .. 4*d4+3 live in lane d4 of the frame's 16-lane row: DPP row broadcast (row_newbcast, folded
     // into the subtraction's operand fetch) instead of a round trip through LDS
     float sum = 0.f;
@@ -110,12 +112,12 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
       // a DPP operand must not have been written by the two preceding VALU instructions (`mine` is updated at the end
       // of the previous stage); tied to the data so it cannot be scheduled away from between the two
       asm volatile("s_nop 1" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
-      rvq_terms<0>(sum, m0, m1, m2, m3, row);
+      rvq_terms<0>(sum, m0, m1, m2, m3, PREFETCH ? row : next);
     }
     // Off the critical path: issued after the chain and before the reduction, so the 16 reads drain while the DPP
     // steps run and the winner-row read below finds the LDS idle.
     __builtin_amdgcn_sched_barrier(0);
-    if (k + 1 < num_stages) load_row(next, k + 1);
+    if (PREFETCH && k + 1 < num_stages) load_row(next, k + 1);
     __builtin_amdgcn_sched_barrier(0);
     // ARG_MIN = first minimum, branch-free: the row minimum of the distance by a 16-lane all-reduce with DPP row
     // rotations (register-only, no LDS crossbar), then the lowest lane of the frame's 16-lane field that holds it
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
   };
 #pragma unroll 1
   for (int k = 0; k < num_stages; k += 2) {
-    stage(k, rowa, rowb);
-    if (k + 1 < num_stages) stage(k + 1, rowb, rowa);
+    stage(k, rowa, PREFETCH ? rowb : rowa);
+    if (k + 1 < num_stages) stage(k + 1, PREFETCH ? rowb : rowa, rowa);
   }
   if (j == 0 && frame < B && packet_bytes) packet_bytes[frame] = live ? nbytes : 0;
   if (j == 0 && live) {
@@ -156,6 +158,25 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
     if (indices)
       for (int k = num_stages; k < 46; ++k) indices[(size_t)frame * 46 + k] = -1;
   }
+}
+
+// The shipped form: windows of two stages (26 KB of LDS), one register set (<= 128 VGPRs): next to this kernel's one
+// wavefront per SIMD three wavefronts of a stage kernel still fit, and the other side's stage kernel keeps most of its
+// tiles resident while the quantizer runs (the 8-stage / two-register-set form is 104 KB and 244 VGPRs: faster alone,
+// but it evicts the co-running kernel).
+__global__ __launch_bounds__(256, 4) void rvq_encode_kernel(const float* __restrict__ cb, const float* __restrict__ feats,
+                                                            int B, int num_stages, int32_t* __restrict__ indices,
+                                                            uint8_t* __restrict__ packets,
+                                                            const int32_t* __restrict__ mask_ids,
+                                                            int32_t* __restrict__ packet_bytes) {
+  rvq_encode_body<2, false>(cb, feats, B, num_stages, indices, packets, mask_ids, packet_bytes);
+}
+__global__ __launch_bounds__(256) void rvq_encode_wide_kernel(const float* __restrict__ cb, const float* __restrict__ feats,
+                                                              int B, int num_stages, int32_t* __restrict__ indices,
+                                                              uint8_t* __restrict__ packets,
+                                                              const int32_t* __restrict__ mask_ids,
+                                                              int32_t* __restrict__ packet_bytes) {
+  rvq_encode_body<8, true>(cb, feats, B, num_stages, indices, packets, mask_ids, packet_bytes);
 }
 
 // RVQ decode: quantizer.tflite `decode` (233 ops) + the index extraction of DecodeToLossyFeatures
