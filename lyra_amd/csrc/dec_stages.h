@@ -79,6 +79,15 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     sids[tid] = id;
     sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::D0_BYTES + st::PHASE);
   }
+  // The packet bytes of this thread's stream (wave = stream) depend on nothing but the batch position: requested in the
+  // same round trip as the ids / ring phases, not after the barrier that publishes those.
+  int pkb[23];
+  if (!feats) {
+    const int nbytes = (num_stages + 1) >> 1;
+    const uint8_t* pk = packets + (size_t)min(b0 + (tid >> 6), B - 1) * nbytes;
+#pragma unroll
+    for (int i = 0; i < 23; ++i) pkb[i] = i < nbytes ? (int)pk[i] : 0;
+  }
   load_luts<NTD0>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NTD0, 1>(P.warm);
   const auto warm_code = code_warm<NTD0>(code_bytes);
@@ -94,12 +103,10 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     if (feats) {
       f = feats[(size_t)b * 64 + c];
     } else {
-      const int nbytes = (num_stages + 1) >> 1;
-      const uint8_t* pk = packets + (size_t)b * nbytes;
       f = 0.f;
-#pragma unroll 23
-      for (int k = 0; k < 46; ++k) {   // addresses depend only on the packet: 23 codebook loads in flight at a time
-        const int id = k < num_stages ? ((pk[k >> 1] >> ((k & 1) ? 0 : 4)) & 15) : -1;
+#pragma unroll
+      for (int k = 0; k < 46; ++k) {   // addresses depend only on the packet: all 46 codebook loads in flight at once
+        const int id = k < num_stages ? ((pkb[k >> 1] >> ((k & 1) ? 0 : 4)) & 15) : -1;
         const float mask = id != -1 ? 1.f : 0.f;
         const int i = id < 0 ? 0 : id;
         const float v = cb[((size_t)k * 16 + i) * 64 + c] * mask;
