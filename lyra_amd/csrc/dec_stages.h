@@ -94,6 +94,9 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   const auto warm_cb = l2_warm<NTD0, 1>(feats ? WarmRange{nullptr, 0} : WarmRange{reinterpret_cast<const uint8_t*>(cb), 46 * 16 * 64 * 4});
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0, st::D0_BYTES};
+  // overlap tails / carried rows read by dependent loads further down the chain (state_touch, resblocks.h)
+  const uint32_t touch0 = state_touch<SD0, NTD0>(cx, st::D_UP0, 4 * 2 * 64 * 4 + 2 * 256);   // D_UP0 .. D_R0_0
+  const uint32_t touch1 = state_touch<SD0, NTD0>(cx, st::D_UP1, 2 * 2 * 64 * 4);
 
   // ---- feature window [f-2, f-1, f] (history ring R=2, T=1); GEMM rows = streams, 16-row tile ----------
   {
@@ -343,6 +346,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   l2_warm_sink(warm_cb, state, B);
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);
+  state_touch_sink(touch0 ^ touch1, state, B);
 }
 
 // =============================================================================================

@@ -69,6 +69,10 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   __syncthreads();
   TileCtx cx{state, sids, sphase, B - b0, st::E2_BYTES};
   const RbqPre pre1 = resblock_q_prefetch<S2>(cx, 3, st::E_R2_1, P.dwq[0], P.pwq[0], P.cvq[0]);
+  // rows read by dependent loads further down the chain (depthwise history of block 0; strided-conv and bottleneck rows)
+  static_assert(S2 * ((st::E_R2_0 + 2048 - 1) / 128 + 1) <= NT2 && S2 * 13 <= NT2, "one touch per thread");
+  const uint32_t touch0 = state_touch<S2, NT2>(cx, st::E_R2_0, 2 * 256 * 4);
+  const uint32_t touch1 = state_touch<S2, NT2>(cx, st::E_D2, 2 * 256 + 2 * 512);
 
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
@@ -233,6 +237,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   }
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);
+  state_touch_sink(touch0 ^ touch1, state, B);
 }
 
 }  // namespace lyra
