@@ -51,7 +51,7 @@ SEED = 0x4C797261  # "Lyra"
 CONFIGS = {
     2: dict(streams=1024, bits=64, mode="encdec", scaling="weak"),
     3: dict(streams=4096, bits=184, mode="encdec", scaling="weak"),
-    4: dict(streams=8192, bits=184, mode="decode", scaling="weak"),
+    4: dict(streams=8192, bits=184, mode="decode", scaling="weak", sub_batches=2),   # one side only: two sub-batches
     5: dict(total_streams=32768, bits=120, mode="encdec", scaling="strong"),
 }
 
@@ -134,7 +134,8 @@ def resolve_workload(args, world):
     else:
         per = cfg["streams"]
         total = per * world
-    return dict(B=per, total=total, bits=cfg["bits"], mode=cfg["mode"], scaling=cfg["scaling"], config=args.config)
+    return dict(B=per, total=total, bits=cfg["bits"], mode=cfg["mode"], scaling=cfg["scaling"], config=args.config,
+                sub_batches=cfg.get("sub_batches"))
 
 
 def dist_env():
@@ -298,7 +299,8 @@ class Shard:
         self.dev = torch.device("cuda", device)
         self.wl, self.args = wl, args
         B, bits = wl["B"], wl["bits"]
-        self.ctx = lyra_amd.LyraHip(device=device, max_streams=B, requant="exact", weights_image=weights_image)
+        self.ctx = lyra_amd.LyraHip(device=device, max_streams=B, requant="exact", weights_image=weights_image,
+                                    sub_batches=wl.get("sub_batches"))
         self.ctx.torch_order = False   # this harness synchronises explicitly around every region it times
         gen = torch.Generator(device=self.dev)
         gen.manual_seed(SEED + first_id)
@@ -453,7 +455,7 @@ def result_line(args, wl, world, secs, frames, res, launcher):
                    "baseline_config": wl["config"], "streams_per_gpu": B, "total_streams": wl["total"],
                    "num_bits": bits,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective ({launcher})",
-                   "requant_mode": "exact"},
+                   "requant_mode": "exact", "sub_batches": wl.get("sub_batches") or 1},
         "xrt_per_stream": round(value / 50.0 / wl["total"], 3),
         "xrt_aggregate": round(value / 50.0, 1),
         "roofline": roof,

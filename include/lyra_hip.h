@@ -99,7 +99,10 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  * either way): LYRA_HIP_FUSED=<mask> -- bit 0: the encoder side
  * (lyra_hip_extract / lyra_hip_encode) as one launch instead of three, bit 1: the
  * decoder side likewise (slower at B = 4096; default 0);
- * LYRA_HIP_NO_CODE_WARM -- skip the stage kernels' instruction pre-fetch. */
+ * LYRA_HIP_NO_CODE_WARM -- skip the stage kernels' instruction pre-fetch;
+ * LYRA_HIP_SUBBATCHES=<n> -- split every `_dev` call into n sub-batches on
+ * stream pairs of their own (pays when only one side is driven: decode-only at
+ * B = 8192 +6 % with n = 2; default 1). */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
 /* The same from an in-memory lyra_v1.lyrapack image (e.g. read once by rank 0 and broadcast to the other GPUs' ranks
  * over RCCL); the image is copied, the caller keeps ownership. */

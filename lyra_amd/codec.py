@@ -129,10 +129,33 @@ def _np(a, dtype, shape):
 class LyraHip:
     """One GPU context: weights + per-stream state for `max_streams` streams."""
 
-    def __init__(self, model_dir=None, device=0, max_streams=4096, requant="exact", weights_image=None):
+    def __init__(self, model_dir=None, device=0, max_streams=4096, requant="exact", weights_image=None,
+                 sub_batches=None):
+        """sub_batches: split every `_dev` call into that many independent sub-batches on stream pairs of their own
+        (the library's LYRA_HIP_SUBBATCHES switch, read when the context is created).  Pays when only ONE side is
+        driven (decode-only at B = 8192: +6 %), not for interleaved encode + decode, where the two sides already
+        overlap."""
         self.L = _load()
         h = C.c_void_p()
         mode = {"exact": 0, "gemmlowp_double": 1}[requant]
+        saved = os.environ.get("LYRA_HIP_SUBBATCHES")
+        if sub_batches is not None:
+            os.environ["LYRA_HIP_SUBBATCHES"] = str(int(sub_batches))
+        try:
+            self._create(h, mode, model_dir, device, max_streams, weights_image)
+        finally:
+            if sub_batches is not None:
+                if saved is None:
+                    del os.environ["LYRA_HIP_SUBBATCHES"]
+                else:
+                    os.environ["LYRA_HIP_SUBBATCHES"] = saved
+        self.h = h
+        self.device = device
+        self.max_streams = max_streams
+        self.requant = requant
+        self.sub_batches = sub_batches
+
+    def _create(self, h, mode, model_dir, device, max_streams, weights_image):
         if weights_image is not None:   # bytes of a lyra_v1.lyrapack (lyra_hip_create_from_image)
             weights_image = bytes(weights_image)
             rc = self.L.lyra_hip_create_from_image(weights_image, len(weights_image), device, max_streams, mode,
@@ -142,10 +165,6 @@ class LyraHip:
                                         C.byref(h))
         if rc != 0:
             raise LyraHipError(f"lyra_hip_create failed ({rc}): {self.L.lyra_hip_last_error(None).decode()}")
-        self.h = h
-        self.device = device
-        self.max_streams = max_streams
-        self.requant = requant
 
     def close(self):
         if getattr(self, "h", None):
