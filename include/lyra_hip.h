@@ -29,14 +29,15 @@
  * H2D/D2H and synchronise); `_dev` variants take DEVICE pointers, enqueue and
  * do not synchronise.
  *
- * Streams: a context runs two HIP streams -- the ENCODE side (extract,
- * rvq_encode, the feature extractor of encode) and the DECODE side (rvq_decode,
+ * Streams: a context runs three HIP streams -- the ENCODE side (extract,
+ * rvq_encode, the feature extractor of encode), the DECODE side (rvq_decode,
  * generate, decode, logmel; the stateless helpers rvq_decode_dev / logmel_dev
- * count as decode-side calls too); encoder and decoder state are disjoint.
- * The quantizer of lyra_hip_encode_dev / lyra_hip_encode_dtx_dev runs on the
- * DECODE-side stream once the features are ready, i.e. in front of the
- * decode-side work enqueued next: the next call's feature extractor overlaps
- * it instead of queueing behind a kernel that leaves the chip nearly idle.
+ * count as decode-side calls too) and one for the quantizer of
+ * lyra_hip_encode_dev / lyra_hip_encode_dtx_dev, which starts once the call's
+ * features are ready and runs underneath the next call's feature extractor and
+ * the previous call's decoder (a 46-stage dependent chain that would leave the
+ * chip nearly idle if anything queued behind it).  Encoder and decoder state
+ * are disjoint.
  * What the library guarantees on the GPU, without any caller synchronisation:
  *   (1) a decode-side call is ordered after EVERY earlier encode-side call, so
  *       encode_dev -> decode_dev on the produced packets just works;
@@ -49,7 +50,7 @@
  * i+2 is ordered after the decode that read it at step i.  A caller that
  * reuses ONE buffer set must lyra_hip_synchronize() (or lyra_hip_set_serial)
  * between steps.
- * Both library streams are hipStreamNonBlocking: they do NOT order against the
+ * The library streams are hipStreamNonBlocking: they do NOT order against the
  * null stream or any stream of the caller.  A `_dev` caller that produces
  * inputs or consumes outputs on its own stream brackets the calls with
  * lyra_hip_wait_for_stream(ctx, s) (library work enqueued afterwards waits

@@ -1,12 +1,12 @@
 // api.hip -- the C ABI of include/lyra_hip.h: context, scratch, launches.  No CPU fallback anywhere:
 // every entry point either runs the gfx950 kernels or fails with an error code.
 //
-// Two HIP streams per context: the ENCODE side (extract, rvq_encode, the extractor of encode) and the DECODE side
-// (rvq_decode, generate, decode, logmel -- and the quantizer of the `_dev` encode calls, see encq_begin).  Encoder and
-// decoder state are disjoint, so decode of step i overlaps the extractor of step i+1; every stage kernel is a chain of
-// short dependent phases, and two chains in flight fill each other's bubbles.  Ordering: a decode-side call waits (on
-// the GPU) for every earlier encode-side call; encode-side outputs never overtake any decode-side call but the most
-// recent one (include/lyra_hip.h "Streams").
+// Three HIP streams per context: the ENCODE side (extract, rvq_encode, the extractor of encode), the DECODE side
+// (rvq_decode, generate, decode, logmel) and one for the quantizer of the `_dev` encode calls (see encq_begin).
+// Encoder and decoder state are disjoint, so decode of step i overlaps the extractor of step i+1; every stage kernel
+// is a chain of short dependent phases, and two chains in flight fill each other's bubbles.  Ordering: a decode-side
+// call waits (on the GPU) for every earlier encode-side call; encode-side outputs never overtake any decode-side call
+// but the most recent one (include/lyra_hip.h "Streams").
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -37,10 +37,10 @@ struct lyra_hip_ctx {
   int nsub = 1;                    // sub-batches a `_dev` call is split into (independent stream pairs)
   hipStream_t se[KMAX] = {};       // encode side
   hipStream_t sd[KMAX] = {};       // decode side
+  hipStream_t sq[KMAX] = {};       // the quantizer of the `_dev` encode calls (see encq_begin)
   hipEvent_t ev_enc[KMAX] = {};    // handle (not owned): end of the latest encode-side work of chunk k, one of ev_encs
-  hipEvent_t ev_encs[3][KMAX] = {};// [0], [1]: `_dev` encode calls by parity, recorded on sd[k] after the quantizer;
+  hipEvent_t ev_encs[3][KMAX] = {};// [0], [1]: `_dev` encode calls by parity, recorded on sq[k] after the quantizer;
                                    // [2]: every other encode-side call, recorded on se[k]
-  bool enc_on_sd[KMAX] = {};       // ev_enc[k] was recorded on sd[k] itself (a decode-side wait on it would be a no-op)
   hipEvent_t ev_feat[KMAX] = {};   // features of the current `_dev` encode call ready on se[k]
   long n_encq_calls = 0;           // `_dev` encode calls so far (parity selects the feature buffer and ev_encs slot)
   hipEvent_t ev_dec[2][KMAX] = {}; // end of the two latest decode-side calls on sd[k]
@@ -116,6 +116,7 @@ int sync_all(lyra_hip_ctx* c) {
   for (int k = 0; k < lyra_hip_ctx::KMAX; ++k) {
     if (c->se[k]) HIPCHK(c, hipStreamSynchronize(c->se[k]));
     if (c->sd[k]) HIPCHK(c, hipStreamSynchronize(c->sd[k]));
+    if (c->sq[k]) HIPCHK(c, hipStreamSynchronize(c->sq[k]));
   }
   return 0;
 }
@@ -259,16 +260,15 @@ int enc_side_begin(lyra_hip_ctx* c, int k) {
 int enc_side_done(lyra_hip_ctx* c, int k) {
   HIPCHK(c, hipEventRecord(c->ev_encs[2][k], c->se[k]));
   c->ev_enc[k] = c->ev_encs[2][k];
-  c->enc_on_sd[k] = false;
   return 0;
 }
 // The `_dev` encode calls (lyra_hip_encode_dev, lyra_hip_encode_dtx_dev) run the feature extractor on se[k] and the
-// quantizer on sd[k], in front of the decode-side work enqueued next: rvq_encode is a 46-stage dependent chain on one
-// wavefront per SIMD that leaves the chip nearly idle, and on se[k] it kept the next call's extractor waiting behind
-// it (rocprofv3 timeline: ~50 us of quantizer + ~12 us of cross-stream event latency per step with nothing else
-// running).  On sd[k] the next call's extractor overlaps it, the packets are written in decode-side stream order (so
-// they can never overtake a pending decode that still reads the caller's other buffer: no encode-side wait on the
-// decode side is needed at all), and the features travel through two alternating buffers.
+// quantizer on a third stream sq[k]: rvq_encode is a 46-stage dependent chain on one wavefront per SIMD that leaves
+// the chip nearly idle.  Behind the extractor on se[k] it kept the next call's extractor waiting (rocprofv3 timeline:
+// ~50 us of quantizer + ~12 us of cross-stream event latency per step with nothing else running); in front of the
+// decoder stages on sd[k] it lengthened the chain that paces the pipeline.  On its own stream it runs underneath the
+// next call's extractor and the previous call's decoder stages, which then are two chains of equal length that never
+// wait for each other (B = 4096: 0.338 -> 0.315 ms per step).  The features travel through two alternating buffers.
 int encq_begin(lyra_hip_ctx* c, int k) {
   if (c->serial && c->n_dec_calls >= 1)
     HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_dec[(c->n_dec_calls - 1) & 1][k], 0));
@@ -280,21 +280,23 @@ hipEvent_t encq_buffer_free(lyra_hip_ctx* c, int k) {
   return c->n_encq_calls >= 2 ? c->ev_encs[c->n_encq_calls & 1][k] : nullptr;
 }
 float* encq_features(lyra_hip_ctx* c) { return (c->n_encq_calls & 1) ? c->d_feat2 : c->d_feat; }
-int encq_handoff(lyra_hip_ctx* c, int k) {   // extractor done on se[k] -> quantizer may start on sd[k]
+int encq_handoff(lyra_hip_ctx* c, int k) {   // extractor done on se[k] -> quantizer may start on sq[k]
   HIPCHK(c, hipEventRecord(c->ev_feat[k], c->se[k]));
-  HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_feat[k], 0));
+  HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_feat[k], 0));
+  // the packets: the two-buffer rule of include/lyra_hip.h "Streams" (2), as enc_side_begin does it for se[k]
+  if (c->n_dec_calls >= 2) HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_dec[c->n_dec_calls & 1][k], 0));
+  if (c->serial && c->n_dec_calls >= 1)
+    HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_dec[(c->n_dec_calls - 1) & 1][k], 0));
   return 0;
 }
 int encq_done(lyra_hip_ctx* c, int k) {
   const int p = (int)(c->n_encq_calls & 1);
-  HIPCHK(c, hipEventRecord(c->ev_encs[p][k], c->sd[k]));
+  HIPCHK(c, hipEventRecord(c->ev_encs[p][k], c->sq[k]));
   c->ev_enc[k] = c->ev_encs[p][k];
-  c->enc_on_sd[k] = true;
   return 0;
 }
 int dec_side_begin(lyra_hip_ctx* c, int k) {
-  for (int j = 0; j < c->nsub; ++j)
-    if (!(j == k && c->enc_on_sd[j])) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0));
+  for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0));
   return 0;
 }
 int dec_side_done(lyra_hip_ctx* c, int k, int nk = 0) {
@@ -367,8 +369,8 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
 
 int launch_rvq_encode(lyra_hip_ctx* c, int k, int B, const float* d_feat, int num_stages, int32_t* d_idx,
                       uint8_t* d_pkt, const int32_t* d_mask_ids = nullptr, int32_t* d_pkt_bytes = nullptr,
-                      bool on_decode_stream = false) {
-  hipStream_t st_ = on_decode_stream ? c->sd[k] : c->se[k];
+                      bool on_quantizer_stream = false) {
+  hipStream_t st_ = on_quantizer_stream ? c->sq[k] : c->se[k];
   { ProfScope ps(c, K_RVQ_ENC, st_);
     hipLaunchKernelGGL(c->rvq_wide ? rvq_encode_wide_kernel : rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, st_, c->model.cb, d_feat, B,
                        num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes); }
@@ -541,6 +543,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   for (int k = 0; k < c->nsub; ++k)
     if (hipStreamCreateWithFlags(&c->se[k], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sd[k], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->sq[k], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[0][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[1][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[2][k], evflags) != hipSuccess ||
@@ -598,6 +601,7 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
     if (c->ev_dec[1][k]) (void)hipEventDestroy(c->ev_dec[1][k]);
     if (c->se[k]) (void)hipStreamDestroy(c->se[k]);
     if (c->sd[k]) (void)hipStreamDestroy(c->sd[k]);
+    if (c->sq[k]) (void)hipStreamDestroy(c->sq[k]);
   }
   if (c->d_state) (void)hipFree(c->d_state);
   free_model(&c->model);
@@ -1012,6 +1016,7 @@ int lyra_hip_wait_for_stream(lyra_hip_ctx* c, void* caller_stream) {
   for (int k = 0; k < c->nsub; ++k) {
     HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_caller, 0));
     HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_caller, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_caller, 0));
   }
   return 0;
 }
@@ -1025,6 +1030,8 @@ int lyra_hip_stream_wait(lyra_hip_ctx* c, void* caller_stream) {
     HIPCHK(c, hipEventRecord(c->ev_caller, c->se[k]));
     HIPCHK(c, hipStreamWaitEvent((hipStream_t)caller_stream, c->ev_caller, 0));
     HIPCHK(c, hipEventRecord(c->ev_caller, c->sd[k]));
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)caller_stream, c->ev_caller, 0));
+    HIPCHK(c, hipEventRecord(c->ev_caller, c->sq[k]));
     HIPCHK(c, hipStreamWaitEvent((hipStream_t)caller_stream, c->ev_caller, 0));
   }
   return 0;

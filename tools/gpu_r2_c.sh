@@ -1,10 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-b() { python bench.py --no-cpu-baseline --no-kernel-table --steps 200 "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d.get("secondary"))'; }
-echo "c4 nsub1: $(b --config 4)"
-echo "c4 nsub2: $(LYRA_HIP_SUBBATCHES=2 b --config 4)"
-echo "c3 nsub1: $(b)"
-echo "c3 nsub2: $(LYRA_HIP_SUBBATCHES=2 b)"
-echo "c5 nsub1: $(b --config 5)"
-echo "c5 nsub2: $(LYRA_HIP_SUBBATCHES=2 b --config 5)"
-echo "c2 nsub1: $(b --config 2)"
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+b() { python bench.py --no-cpu-baseline --no-kernel-table --steps 300 "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])'; }
+echo "bench: $(b)"; echo "bench: $(b)"
+echo "c2: $(b --config 2)"; echo "c5: $(b --config 5)"; echo "logmel: $(b --with-logmel)"
+echo "$(MODES=full python tools/pipeline_probe.py 2>&1 | grep '^full')"
