@@ -232,6 +232,10 @@ int lyra_hip_max_streams(const lyra_hip_ctx* ctx);
  * profile_read() synchronises, returns per-kernel total milliseconds and launch counts since the previous read
  * (arrays of lyra_hip_profile_kernel_count() entries) and clears them. */
 int lyra_hip_profile_enable(lyra_hip_ctx* ctx, unsigned kernel_mask);
+/* Bracket only every `every`-th launch of an enabled kernel (default 1): an event record is a packet of its own in the
+ * stream (~5 us of bubble on MI355X), so timing every launch of a kernel inside a throughput measurement slows the
+ * measured pipeline itself. */
+int lyra_hip_profile_sample(lyra_hip_ctx* ctx, int every);
 int lyra_hip_profile_kernel_count(void);
 const char* lyra_hip_profile_kernel_name(int i);
 int lyra_hip_profile_read(lyra_hip_ctx* ctx, double* total_ms, long* launches);

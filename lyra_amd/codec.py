@@ -112,6 +112,7 @@ def _load():
     L.lyra_hip_state_bytes_per_stream.restype = C.c_size_t
     L.lyra_hip_max_streams.argtypes = [vp]
     L.lyra_hip_profile_enable.argtypes = [vp, C.c_uint]
+    L.lyra_hip_profile_sample.argtypes = [vp, ci]
     L.lyra_hip_profile_kernel_name.restype = cp
     L.lyra_hip_profile_kernel_name.argtypes = [ci]
     L.lyra_hip_profile_read.argtypes = [vp, vp, vp]
@@ -330,8 +331,9 @@ class LyraHip:
         n = self.L.lyra_hip_profile_kernel_count()
         return [self.L.lyra_hip_profile_kernel_name(i).decode() for i in range(n)]
 
-    def profile_enable(self, on=True, only=None):
-        """Bracket kernel launches with HIP events: all kernels, or only the named one."""
+    def profile_enable(self, on=True, only=None, every=1):
+        """Bracket kernel launches with HIP events: all kernels, or only the named one; every `every`-th launch."""
+        self._chk(self.L.lyra_hip_profile_sample(self.h, int(every)))
         mask = 0
         if on:
             names = self.profile_kernel_names()

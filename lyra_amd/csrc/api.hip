@@ -82,6 +82,8 @@ struct lyra_hip_ctx {
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
   unsigned profiling = 0;  // bit i set: bracket launches of kernel i
+  int prof_every = 1;      // ... every prof_every-th launch of it (lyra_hip_profile_sample)
+  long prof_seen[16] = {};
   struct Span { int kid; hipEvent_t a, b; };
   std::vector<Span> spans;
   std::vector<hipEvent_t> event_pool;
@@ -231,7 +233,7 @@ hipEvent_t take_event(lyra_hip_ctx* c) {
 struct ProfScope {
   lyra_hip_ctx* c; int kid; hipStream_t s; hipEvent_t a = nullptr;
   ProfScope(lyra_hip_ctx* c_, int kid_, hipStream_t s_) : c(c_), kid(kid_), s(s_) {
-    if (c->profiling & (1u << kid)) {
+    if ((c->profiling & (1u << kid)) && (c->prof_seen[kid]++ % c->prof_every) == 0) {
       a = take_event(c);
       if (a && hipEventRecord(a, s) != hipSuccess) { c->event_pool.push_back(a); a = nullptr; }
     }
@@ -539,11 +541,18 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   }
   // The internal events only order work of this device's streams against each other: no system-scope fence (cache
   // write-back) when they are recorded -- a recorded event costs ~5.5 us of stream bubble with it (rocprofv3 timeline).
+  // The decoder chain (three kernels + two event packets per step) is the longest of the three streams' chains: its
+  // workgroups are dispatched first (highest stream priority), the extractor and the quantizer fill in.  With equal
+  // priorities the pipeline has two steady states, 0.315 and 0.33-0.355 ms per step at B = 4096 (in the slow one the
+  // quantizer runs beside decoder stage 0, both VALU-bound); with this it stays in the fast one.
+  int prio_lo = 0, prio_hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+  const int prio[3] = {prio_lo, getenv("LYRA_HIP_FLAT_PRIO") ? prio_lo : prio_hi, prio_lo};
   const unsigned evflags = hipEventDisableTiming | (getenv("LYRA_HIP_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
   for (int k = 0; k < c->nsub; ++k)
-    if (hipStreamCreateWithFlags(&c->se[k], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->sd[k], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->sq[k], hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&c->se[k], hipStreamNonBlocking, prio[0]) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->sd[k], hipStreamNonBlocking, prio[1]) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->sq[k], hipStreamNonBlocking, prio[2]) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[0][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[1][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[2][k], evflags) != hipSuccess ||
@@ -1149,6 +1158,12 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
 int lyra_hip_profile_enable(lyra_hip_ctx* c, unsigned kernel_mask) {
   if (!c) return LYRA_HIP_EINVAL;
   c->profiling = kernel_mask;
+  for (long& n : c->prof_seen) n = 0;
+  return 0;
+}
+int lyra_hip_profile_sample(lyra_hip_ctx* c, int every) {
+  if (!c || every < 1) return LYRA_HIP_EINVAL;
+  c->prof_every = every;
   return 0;
 }
 int lyra_hip_profile_kernel_count(void) { return K_COUNT; }
