@@ -1,7 +1,10 @@
 // lyra_hip_components.cc -- see lyra_hip_components.h.  Plain C++17 over the C ABI (include/lyra_hip.h); no HIP here.
 #include "lyra_hip_components.h"
 
+#include <atomic>
 #include <bitset>
+#include <condition_variable>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -15,6 +18,49 @@ namespace {
 constexpr int kNumFeatures = LYRA_HIP_NUM_FEATURES;
 constexpr int kHop = LYRA_HIP_HOP;
 constexpr int kMaxBits = 4 * LYRA_HIP_MAX_STAGES;
+
+// Call combining.  Every plugin object is one stream, and the reference calls its plugins one 20 ms hop at a time
+// (lyra_encoder.cc:143-155, lyra_decoder.cc:198-207): with many codec objects on many threads that is many B = 1 device
+// calls queueing on the context's call mutex.  A Combiner turns whatever calls of one kind are waiting into ONE batched
+// call of the C ABI: a caller appends its request; if nobody is executing it becomes the leader, takes everything that
+// is pending (its own request included), runs the batch and wakes the others; requests that arrive while a batch is on
+// the GPU form the next batch (group commit -- no timer, no added latency for a lone caller).  Results are per stream
+// and bit-identical to the B = 1 calls (the kernels are batch-invariant, tests/test_gpu_parity.py).
+struct CombinerStats { std::atomic<long> calls{0}, batches{0}, largest{0}; };
+template <class Req>
+class Combiner {
+ public:
+  template <class Exec>   // exec(std::vector<Req*>&): sets every request's rc
+  void Run(Req* r, Exec exec) {
+    std::unique_lock<std::mutex> l(mu_);
+    pending_.push_back(r);
+    while (!r->done) {
+      if (busy_) { cv_.wait(l); continue; }
+      busy_ = true;
+      std::vector<Req*> batch;
+      batch.swap(pending_);
+      l.unlock();
+      exec(batch);
+      stats.calls += (long)batch.size();
+      stats.batches += 1;
+      long big = stats.largest.load();
+      while ((long)batch.size() > big && !stats.largest.compare_exchange_weak(big, (long)batch.size())) {}
+      l.lock();
+      for (Req* q : batch) q->done = true;
+      busy_ = false;
+      cv_.notify_all();
+    }
+  }
+  CombinerStats stats;
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Req*> pending_;
+  bool busy_ = false;
+};
+struct HopReq {   // one hop in, one vector out, of one stream
+  int32_t id; const void* in; void* out; int arg; int rc; bool done;
+};
 
 // One GPU context per process, shared by all plugin objects; each object owns a stream id.
 class SharedContext {
@@ -62,7 +108,70 @@ class SharedContext {
   }
   std::mutex& call_mutex() { return call_mu_; }  // the C ABI wants calls on one context serialised
 
+  // ---- combined calls (see Combiner) ---------------------------------------------------------------------
+  enum Kind { kExtract, kLogMel, kGenerate, kQuantize, kDequantize, kKinds };
+  // in / out element counts and sizes per request of each kind
+  int Call(Kind kind, lyra_hip_ctx* ctx, int32_t id, const void* in, void* out, int arg = 0) {
+    HopReq r{id, in, out, arg, -1, false};
+    comb_[kind].Run(&r, [&](std::vector<HopReq*>& batch) { Execute(kind, ctx, batch); });
+    return r.rc;
+  }
+  const CombinerStats& stats(Kind kind) const { return comb_[kind].stats; }
+
  private:
+  void Execute(Kind kind, lyra_hip_ctx* ctx, std::vector<HopReq*>& batch) {
+    if (kind == kQuantize) {   // requests of different bit rates cannot share a call: one call per rate present
+      std::vector<HopReq*> todo(batch), same, rest;   // (the caller still needs `batch` to mark its requests done)
+      while (!todo.empty()) {
+        same.clear();
+        rest.clear();
+        for (HopReq* q : todo) (q->arg == todo[0]->arg ? same : rest).push_back(q);
+        ExecuteUniform(kind, ctx, same);
+        todo.swap(rest);
+      }
+      return;
+    }
+    ExecuteUniform(kind, ctx, batch);
+  }
+  void ExecuteUniform(Kind kind, lyra_hip_ctx* ctx, std::vector<HopReq*>& batch) {
+    static const size_t kIn[kKinds] = {kHop * sizeof(int16_t), kHop * sizeof(int16_t), kNumFeatures * sizeof(float),
+                                       kNumFeatures * sizeof(float), LYRA_HIP_MAX_STAGES * sizeof(int32_t)};
+    static const size_t kOut[kKinds] = {kNumFeatures * sizeof(float), LYRA_HIP_NUM_MEL * sizeof(float),
+                                        kHop * sizeof(int16_t), LYRA_HIP_MAX_STAGES * sizeof(int32_t),
+                                        kNumFeatures * sizeof(float)};
+    const int B = (int)batch.size();
+    int rc;
+    std::lock_guard<std::mutex> l(call_mu_);
+    if (B == 1) {   // the common uncontended case: no staging copies
+      HopReq* q = batch[0];
+      rc = Dispatch(kind, ctx, &q->id, 1, q->in, q->out, q->arg);
+    } else {
+      ids_.resize(B);
+      in_.resize((size_t)B * kIn[kind]);
+      out_.resize((size_t)B * kOut[kind]);
+      for (int i = 0; i < B; ++i) {
+        ids_[i] = batch[i]->id;
+        std::memcpy(in_.data() + (size_t)i * kIn[kind], batch[i]->in, kIn[kind]);
+      }
+      rc = Dispatch(kind, ctx, ids_.data(), B, in_.data(), out_.data(), batch[0]->arg);
+      if (rc == 0)
+        for (int i = 0; i < B; ++i) std::memcpy(batch[i]->out, out_.data() + (size_t)i * kOut[kind], kOut[kind]);
+    }
+    for (HopReq* q : batch) q->rc = rc;
+  }
+  static int Dispatch(Kind kind, lyra_hip_ctx* ctx, const int32_t* ids, int B, const void* in, void* out, int arg) {
+    switch (kind) {
+      case kExtract: return lyra_hip_extract(ctx, ids, B, static_cast<const int16_t*>(in), static_cast<float*>(out));
+      case kLogMel: return lyra_hip_logmel(ctx, ids, B, static_cast<const int16_t*>(in), static_cast<float*>(out));
+      case kGenerate: return lyra_hip_generate(ctx, ids, B, static_cast<const float*>(in), static_cast<int16_t*>(out));
+      case kQuantize: return lyra_hip_rvq_encode(ctx, B, static_cast<const float*>(in), arg, static_cast<int32_t*>(out));
+      case kDequantize: return lyra_hip_rvq_decode(ctx, B, static_cast<const int32_t*>(in), static_cast<float*>(out));
+      default: return LYRA_HIP_EINVAL;
+    }
+  }
+  Combiner<HopReq> comb_[kKinds];
+  std::vector<int32_t> ids_;        // staging of a combined call (guarded by call_mu_)
+  std::vector<uint8_t> in_, out_;
   std::mutex mu_, call_mu_;
   lyra_hip_ctx* ctx_ = nullptr;
   std::vector<int> free_;
@@ -93,9 +202,7 @@ class SoundStreamEncoderHip : public FeatureExtractorInterface {
       return std::nullopt;
     }
     std::vector<float> out(kNumFeatures);
-    int32_t id = h_.id();
-    std::lock_guard<std::mutex> l(SharedContext::Get().call_mutex());
-    if (lyra_hip_extract(h_.ctx(), &id, 1, audio.data(), out.data()) != 0) {
+    if (SharedContext::Get().Call(SharedContext::kExtract, h_.ctx(), h_.id(), audio.data(), out.data()) != 0) {
       LOG(ERROR) << "Unable to run the SoundStream encoder: " << lyra_hip_last_error(h_.ctx());
       return std::nullopt;
     }
@@ -115,9 +222,8 @@ class LogMelHip : public FeatureExtractorInterface {
       return std::nullopt;
     }
     std::vector<float> out(LYRA_HIP_NUM_MEL);
-    int32_t id = h_.id();
-    std::lock_guard<std::mutex> l(SharedContext::Get().call_mutex());
-    if (lyra_hip_logmel(h_.ctx(), &id, 1, audio.data(), out.data()) != 0) return std::nullopt;
+    if (SharedContext::Get().Call(SharedContext::kLogMel, h_.ctx(), h_.id(), audio.data(), out.data()) != 0)
+      return std::nullopt;
     return out;
   }
  private:
@@ -140,12 +246,9 @@ class ResidualVectorQuantizerHip : public VectorQuantizerInterface {
     if (static_cast<int>(features.size()) != kNumFeatures) return std::nullopt;
     if (num_bits == 0) return std::string();
     int32_t idx[LYRA_HIP_MAX_STAGES];
-    {
-      std::lock_guard<std::mutex> l(SharedContext::Get().call_mutex());
-      if (lyra_hip_rvq_encode(h_.ctx(), 1, features.data(), num_bits, idx) != 0) {
-        LOG(ERROR) << "Unable to invoke the quantize runner.";
-        return std::nullopt;
-      }
+    if (SharedContext::Get().Call(SharedContext::kQuantize, h_.ctx(), h_.id(), features.data(), idx, num_bits) != 0) {
+      LOG(ERROR) << "Unable to invoke the quantize runner.";
+      return std::nullopt;
     }
     std::string bits;
     bits.reserve(num_bits);
@@ -166,8 +269,7 @@ class ResidualVectorQuantizerHip : public VectorQuantizerInterface {
     for (int i = 0; i < LYRA_HIP_MAX_STAGES; ++i)
       idx[i] = i < num_bits / 4 ? static_cast<int32_t>(std::bitset<4>(quantized.substr(4 * i, 4)).to_ulong()) : -1;
     std::vector<float> out(kNumFeatures);
-    std::lock_guard<std::mutex> l(SharedContext::Get().call_mutex());
-    if (lyra_hip_rvq_decode(h_.ctx(), 1, idx, out.data()) != 0) {
+    if (SharedContext::Get().Call(SharedContext::kDequantize, h_.ctx(), h_.id(), idx, out.data()) != 0) {
       LOG(ERROR) << "Unable to invoke the decode runner.";
       return std::nullopt;
     }
@@ -184,9 +286,8 @@ class LyraGanModelHip : public GenerativeModel {
  protected:
   bool RunConditioning(const std::vector<float>& features) override {
     hop_.resize(kHop);
-    int32_t id = h_.id();
-    std::lock_guard<std::mutex> l(SharedContext::Get().call_mutex());
-    return lyra_hip_generate(h_.ctx(), &id, 1, features.data(), hop_.data()) == 0;
+    if (static_cast<int>(features.size()) != kNumFeatures) return false;
+    return SharedContext::Get().Call(SharedContext::kGenerate, h_.ctx(), h_.id(), features.data(), hop_.data()) == 0;
   }
   std::optional<std::vector<int16_t>> RunModel(int num_samples) override {
     return std::vector<int16_t>(hop_.begin() + next_sample_in_hop(), hop_.begin() + next_sample_in_hop() + num_samples);
@@ -205,6 +306,16 @@ std::unique_ptr<T> MakeOrNull(A&&... a) {
 
 }  // namespace
 
+HipCallStats GetHipCallStats() {
+  HipCallStats st;
+  for (int k = 0; k < SharedContext::kKinds; ++k) {
+    const CombinerStats& c = SharedContext::Get().stats(static_cast<SharedContext::Kind>(k));
+    st.calls += c.calls.load();
+    st.device_calls += c.batches.load();
+    if (c.largest.load() > st.largest_batch) st.largest_batch = c.largest.load();
+  }
+  return st;
+}
 void SetHipDevice(int device) { SharedContext::Get().device = device; }
 void SetMaxStreams(int n) { SharedContext::Get().max_streams = n; }
 

@@ -1,6 +1,9 @@
 // lyra_hip_components.h -- HIP-backed implementations of the reference's plugin interfaces and the factory
-// functions that replace lyra/lyra_components.cc:42-55.  Each object is ONE stream of the shared GPU context
-// (batch = 1 through the batched C ABI); for throughput use the batched C ABI / BatchCodec directly.
+// functions that replace lyra/lyra_components.cc:42-55.  Each object is ONE stream of the shared GPU context.  Objects
+// are used the way the reference's are (one hop per call, one thread per codec object); calls of the same kind that
+// are waiting at the same time -- many codec objects on many threads -- are combined into ONE batched call of the C ABI
+// (lyra_hip_components.cc "Call combining"), with results bit-identical to separate calls.  A caller that already holds
+// a batch of streams uses BatchLyraEncoder / BatchLyraDecoder or the C ABI directly.
 #ifndef LYRA_AMD_HOST_LYRA_HIP_COMPONENTS_H_
 #define LYRA_AMD_HOST_LYRA_HIP_COMPONENTS_H_
 #include <memory>
@@ -19,6 +22,11 @@ std::unique_ptr<GenerativeModelInterface> CreateGenerativeModel(int num_output_f
 std::unique_ptr<FeatureExtractorInterface> CreateFeatureExtractor(const ghc::filesystem::path& model_path);
 // The NoiseEstimator front end (lyra/noise_estimator.cc:157-160): 16 kHz / hop 320 / window 640 / 160 mel bins.
 std::unique_ptr<FeatureExtractorInterface> CreateLogMelExtractor(const ghc::filesystem::path& model_path);
+
+// How the plugin calls of this process were served so far: calls made by plugin objects, device calls they became, and
+// the largest number of streams one device call carried.
+struct HipCallStats { long calls = 0, device_calls = 0, largest_batch = 0; };
+HipCallStats GetHipCallStats();
 
 // Process-wide settings of the shared context (call before the first Create*).
 void SetHipDevice(int device);

@@ -22,7 +22,7 @@ def test_cpp_plugin_surface(oracle_exact, golden_dir, tmp_path, bits):
     pin, bits_out, pout = tmp_path / "in.s16", tmp_path / "bits.txt", tmp_path / "out.s16"
     pcm.tofile(pin)
     r = subprocess.run([demo, lyra_amd.default_model_dir(), str(pin), str(bits), str(bits_out), str(pout)],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     ref = lyra_oracle.run_batch(oracle_exact, pcm[:, None, :], bits // 4, do_decode=True)
     lines = open(bits_out).read().split()
@@ -32,6 +32,41 @@ def test_cpp_plugin_surface(oracle_exact, golden_dir, tmp_path, bits):
         assert l == want, f"bit string differs at hop {f}"
     out = np.fromfile(pout, np.int16).reshape(12, 320)
     assert np.array_equal(out, ref["pcm"][:, 0])
+
+
+@pytest.mark.gpu
+def test_cpp_plugins_many_threads_combined_calls(oracle_exact, golden_dir, tmp_path):
+    """48 codec objects (extractor + quantizer + generative model each) on 48 threads, every one used hop by hop as the
+    reference uses its plugins; the plugin layer combines calls that wait at the same time into batched device calls
+    (lyra_hip_components.cc "Call combining").  Bit strings and PCM of every stream must equal the oracle's, and
+    combining must actually have happened."""
+    import lyra_amd
+    from oracle import lyra_oracle
+    demo = os.path.join(ROOT, "lyra_amd", "plugin_mt_demo")
+    assert os.path.exists(demo), "lyra_amd/plugin_mt_demo not built (__graft_entry__.build())"
+    n, T, bits = 48, 10, 120
+    rng = np.random.Generator(np.random.PCG64(4242))
+    speech = np.load(os.path.join(golden_dir, "speech_sample1.npz"))["pcm_in"]      # [50][320]
+    pcm = rng.integers(-20000, 20000, size=(T, n, 320)).astype(np.int16)
+    pcm[:, 0] = speech[:T]
+    pcm[:, 1] = speech[20:20 + T]
+    pin, bits_out, pout = tmp_path / "in.s16", tmp_path / "bits.txt", tmp_path / "out.s16"
+    pcm.tofile(pin)
+    r = subprocess.run([demo, lyra_amd.default_model_dir(), str(pin), str(n), str(bits), str(bits_out), str(pout)],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    ref = lyra_oracle.run_batch(oracle_exact, pcm, bits // 4, do_decode=True, threads=8)
+    lines = open(bits_out).read().split()
+    assert len(lines) == T * n
+    for f in range(T):
+        for s_ in range(n):
+            want = "".join(format(int(b), "08b") for b in ref["packets"][f, s_])[:bits]
+            assert lines[f * n + s_] == want, f"bit string differs at hop {f}, stream {s_}"
+    out = np.fromfile(pout, np.int16).reshape(T, n, 320)
+    assert np.array_equal(out, ref["pcm"])
+    stats = dict(zip(r.stdout.split()[0::2], map(int, r.stdout.split()[1::2])))
+    assert stats["plugin_calls"] == 4 * T * n
+    assert stats["device_calls"] < stats["plugin_calls"] and stats["largest_batch"] >= 2, stats
 
 
 @pytest.mark.gpu
@@ -50,7 +85,7 @@ def test_cpp_batch_codec_twins(oracle_exact, golden_dir, tmp_path, bitrate):
     pin, pk, pout = tmp_path / "in.s16", tmp_path / "pk.bin", tmp_path / "out.s16"
     pcm.tofile(pin)
     r = subprocess.run([demo, lyra_amd.default_model_dir(), str(pin), str(n), str(bitrate), str(pk), str(pout)],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     bits = {3200: 64, 6000: 120, 9200: 184}[bitrate]
     ref = lyra_oracle.run_batch(oracle_exact, pcm, bits // 4, do_decode=True)
@@ -101,7 +136,7 @@ def test_cpp_file_transcode_ragged_batch(oracle_exact, golden_dir, tmp_path):
     out_dir = tmp_path / "out"
     out_dir.mkdir()
     r = subprocess.run([demo, lyra_amd.default_model_dir(), "6000", str(out_dir)] + wavs,
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     for name, pcm in files.items():
         hops = len(pcm) // 320
