@@ -110,6 +110,9 @@ def parse(argv=None):
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise the multi-rank plumbing (gloo) without touching a GPU")
+    ap.add_argument("--stub-context", action="store_true",
+                    help="CPU-only test hook: run main() itself -- process group (gloo), sharding, weight broadcast, "
+                         "barriers, reductions, result line -- with a stand-in for the GPU shard that only counts its calls")
     return ap.parse_args(argv)
 
 
@@ -397,6 +400,40 @@ class Shard:
         return t1 - t0, prof
 
 
+class StubShard:
+    """Stand-in for Shard under --stub-context (tests/test_abi_cpu.py): same interface, no GPU.  A "step" increments a
+    counter; timed() reports K * 0.1 ms * (1 + rank / 2), so the max over ranks is known to the test."""
+
+    def __init__(self, rank, first_id, wl, args, weights_image=None):
+        self.rank, self.first_id, self.wl, self.args = rank, first_id, wl, args
+        self.weights_bytes = len(weights_image) if weights_image is not None else 0
+        self.calls = {"encdec": 0, "generate": 0, "decode": 0, "sync": 0}
+
+    def step_encdec(self, i):
+        self.calls["encdec"] += 1
+
+    def step_generate(self, i):
+        self.calls["generate"] += 1
+
+    def step_decode(self, i):
+        self.calls["decode"] += 1
+
+    def sync(self):
+        self.calls["sync"] += 1
+
+    def kernel_table(self, step, first, nsteps):
+        for i in range(first, first + nsteps + 2):
+            step(i)
+        return None
+
+    def timed(self, step, first, K, barrier, only=None):
+        barrier()
+        for i in range(first, first + K):
+            step(i)
+        barrier()
+        return K * 1e-4 * (1.0 + 0.5 * self.rank), {}
+
+
 def run_shard(sh, args, wl, barrier):
     """Warm-up, serialised kernel table, timed region(s) of one shard -> dict of raw results."""
     K, W = args.steps, args.warmup
@@ -556,21 +593,29 @@ def main(argv=None):
         return selftest_dist(args)
     import torch
     rank, world, local = dist_env()
-    if not torch.cuda.is_available():
+    stub = args.stub_context
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback); use --selftest-dist for the plumbing test")
-    if world == 1 and args.gpus > 1:
+    if world == 1 and args.gpus > 1 and not stub:
         return main_single_process(args, args.gpus)
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", init_method="env://")
+        else:
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
     wl = resolve_workload(args, world)
     first_id, _ = shard_ids(wl["total"], rank, world)
     image = broadcast_weights(rank, dev) if (args.bcast_weights and world > 1) else None
-    sh = Shard(local, first_id, wl, args, weights_image=image)
+    sh = StubShard(rank, first_id, wl, args, weights_image=image) if stub else Shard(local, first_id, wl, args,
+                                                                                     weights_image=image)
 
     def barrier():
         if world > 1:
@@ -584,7 +629,9 @@ def main(argv=None):
     if rank == 0:
         out = result_line(args, wl, world, secs, frames, res, "one process per GPU, torch.distributed/RCCL for the "
                           "timing barrier and the result reduction only")
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            out["stub"] = {"calls": sh.calls, "first_id": first_id, "weights_bytes": sh.weights_bytes}
+        if world == 1 and not args.no_cpu_baseline and not stub:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl["bits"], wl["mode"])
             except Exception as e:  # the baseline leg must never take the GPU number down with it

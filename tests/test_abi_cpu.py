@@ -126,6 +126,29 @@ def test_bench_multi_rank_plumbing_gloo():
     assert r["per_rank"] == 4096 and r["first_id"] == 0
 
 
+def test_bench_main_two_ranks_with_stub_context_gloo():
+    """bench.main() itself on two CPU ranks (gloo) with a stand-in for the GPU shard: process group, strong-scaling
+    shard of config #5, weight-container broadcast from rank 0, barriers around the timed region, max-over-ranks time,
+    summed units, rank-0 result line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--stub-context", "--gpus", "2",
+           "--config", "5", "--steps", "6", "--warmup", "3", "--bcast-weights", "--no-kernel-table", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 6 and r["warmup"] == 3 and r["scaling"] == "strong"
+    assert r["config"]["streams_per_gpu"] == 16384 and r["config"]["total_streams"] == 32768
+    assert r["config"]["num_bits"] == 120
+    secs = 6 * 1e-4 * 1.5                      # the slower stub rank (rank 1) defines the time
+    assert abs(r["ms_per_step"] - secs / 6 * 1e3) < 1e-6
+    assert abs(r["value"] - 32768 * 6 / secs) < 1.0   # whole-job frames / max-over-ranks seconds
+    assert r["stub"]["first_id"] == 0 and r["stub"]["calls"]["encdec"] == 3 + 6
+    assert r["stub"]["weights_bytes"] == os.path.getsize(os.path.join(ROOT, "lyra_amd", "assets", "lyra_v1.lyrapack"))
+
+
 REF_MODEL_DIR = "/root/reference/lyra/model_coeffs"
 
 
