@@ -419,7 +419,7 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
   }
 }
 
-__host__ __device__ constexpr size_t dec_s1_lds() { return (size_t)(4 * SD1 * CS1 + 4 * SD1 * CS1 + 5 * SD1 * 72) * 4 + 2 * SD1 * 4; }
+__host__ __device__ constexpr size_t dec_s1_lds() { return (size_t)(4 * SD1 * CS1 + 4 * SD1 * CS1 + 4 * SD1 * CS1 + 5 * SD1 * 72) * 4 + 2 * SD1 * 4; }
 
 __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __restrict__ in0,
                                             const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
@@ -427,7 +427,8 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [4][S][136]: X[t]
   float* DB = XB + 4 * SD1 * CS1;       // [4][S][136]
-  float* SB = DB + 4 * SD1 * CS1;       // [5][S][72]: tail of the previous frame's transposed conv
+  float* PB = DB + 4 * SD1 * CS1;       // [4][S][136]
+  float* SB = PB + 4 * SD1 * CS1;       // [5][S][72]: tail of the previous frame's transposed conv
   int* sids = reinterpret_cast<int*>(SB + 5 * SD1 * 72);
   int* sphase = sids + SD1;
   wg_schedule_hint();
@@ -457,7 +458,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   }
   __syncthreads();
   LYRA_TSTAMP(51);
-  resblocks128<SD1, NTD1>(XB, DB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2, H0);
+  resblocks128<SD1, NTD1>(XB, DB, PB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2, H0);
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, rs = idx >> 5;
     f32x4* x = reinterpret_cast<f32x4*>(&XB[rs * CS1 + p4 * 4]);

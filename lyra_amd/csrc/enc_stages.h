@@ -29,7 +29,7 @@ constexpr int NW1 = NT1 / 64;
 }  // namespace
 
 __host__ __device__ constexpr size_t enc_s0_lds(int s0) { return (size_t)(25 * s0 * CS0) * 4 + 64; }
-__host__ __device__ constexpr size_t enc_s1_lds() { return (size_t)(6 * S1 * CS1 + 4 * S1 * CS1) * 4 + 2 * S1 * 4; }
+__host__ __device__ constexpr size_t enc_s1_lds() { return (size_t)(6 * S1 * CS1 + 4 * S1 * CS1 + 4 * S1 * CS1) * 4 + 2 * S1 * 4; }
 
 // =============================================================================================
 // stage 0: S0 streams per workgroup of 64 * S0 threads (4 / 256 or 8 / 512)
@@ -185,7 +185,8 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                    // [6][S1][CS1]: rows 0-1 strided-conv history, rows 2-5 X[t]
   float* DB = XB + 6 * S1 * CS1;       // [4][S1][CS1]
-  int* sids = reinterpret_cast<int*>(DB + 4 * S1 * CS1);
+  float* PB = DB + 4 * S1 * CS1;       // [4][S1][CS1]
+  int* sids = reinterpret_cast<int*>(PB + 4 * S1 * CS1);
   int* sphase = sids + S1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   __syncthreads();
 
   LYRA_TSTAMP(71);
-  resblocks128<S1, NT1>(XB + 2 * S1 * CS1, DB, cx, P.dw, P.pw, P.cv, st::E_R1_0, st::E_R1_1, st::E_R1_2, H0);
+  resblocks128<S1, NT1>(XB + 2 * S1 * CS1, DB, PB, cx, P.dw, P.pw, P.cv, st::E_R1_0, st::E_R1_1, st::E_R1_2, H0);
 
   LYRA_TSTAMP(72);
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {

@@ -128,17 +128,15 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     }
     LYRA_TSTAMP(10 + r * 8 + 2);
     __syncthreads();  // every thread has consumed its history rows and read A
-    for (int idx = tid; idx < R2 * S * 16; idx += NT) {  // new history = last R2 rows of a (T = 20 >= R2)
-      int c4 = idx & 15, s = (idx >> 4) & (S - 1), j = (idx >> 4) / S;
-      if (cx.valid(s))
-        *reinterpret_cast<f32x4*>(cx.sbase(s) + off + (j * 64 + c4 * 4) * 4) =
-            *reinterpret_cast<const f32x4*>(&A[((20 - R2 + j) * S + s) * CS + c4 * 4]);
-    }
-    __syncthreads();
-    LYRA_TSTAMP(10 + r * 8 + 3);
-    // 3. depthwise out -> A
+    // 3. new history = last R2 rows of a (T = 20 >= R2), and the depthwise output -> A: an item (row, channel quad) is
+    //    read and rewritten by its owner only, so the two need no barrier between them
 #pragma unroll
-    for (int k = 0; k < 5; ++k) *reinterpret_cast<f32x4*>(&A[(rq + k * RSTEP) * CS + p4 * 4]) = dreg[k];
+    for (int k = 0; k < 5; ++k) {
+      f32x4* item = reinterpret_cast<f32x4*>(&A[(rq + k * RSTEP) * CS + p4 * 4]);
+      const int j = tq + k * TSTEP - (20 - R2);
+      if (j >= 0 && cx.valid(sq)) *reinterpret_cast<f32x4*>(cx.sbase(sq) + off + (j * 64 + p4 * 4) * 4) = *item;
+      *item = dreg[k];
+    }
     __syncthreads();
     LYRA_TSTAMP(10 + r * 8 + 4);
     auto aoff = [&](int i, int c) { return ((wm * 5 + i) * 16 + m) * CS + c * 16 + q * 4; };
@@ -204,8 +202,10 @@ __device__ __forceinline__ Hist128<1024 / NT> hist128_prefetch(const TileCtx& cx
 }
 
 // H: hist128_prefetch(cx, 1, off0), requested by the caller together with the stage input.
+// P: a third [4][S][136] matrix for the pointwise output -- written while other waves may still read D in their GEMM,
+// so no barrier is needed between the two.
 template <int S, int NT>
-__device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& cx, const DwF* dws,
+__device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const TileCtx& cx, const DwF* dws,
                                              const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2,
                                              Hist128<1024 / NT> H) {
   static_assert(S == 8 && (NT == 256 || NT == 512), "thread <-> (stream, channel quad, row half) mapping");
@@ -272,7 +272,6 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
       // fetch of a GEMM issued right after them; here they have the two barriers and the LDS-only P write
       // (no younger global load) to land in.
       if (r < 2) H = hist128_prefetch<S, NT>(cx, r == 0 ? 3 : 9, r == 0 ? off1 : off2);
-      __syncthreads();
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int ncol = (wave * NTW + j) * 16 + (lane & 15);
@@ -281,7 +280,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) D[(i * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][j][e] + bias);
+          for (int e = 0; e < 4; ++e) P[(i * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][j][e] + bias);
       }
       __syncthreads();
       LYRA_TSTAMP(40 + r * 8 + 4);
@@ -293,7 +292,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, const TileCtx& 
       float biasv[NTW];
 #pragma unroll
       for (int j = 0; j < NTW; ++j) biasv[j] = as_global(cvs[r].b)[(wave * NTW + j) * 16 + (lane & 15)];
-      gemm_f32<MT, NTW, 4>(D, aoff, cvs[r].w + (wave * NTW) * 4 * 64, acc);
+      gemm_f32<MT, NTW, 4>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, acc);
       LYRA_TSTAMP(40 + r * 8 + 5);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
