@@ -13,19 +13,23 @@ extern "C" int lyra_hip_debug_wgtrace_d0(long long* out) {
 }
 #endif
 
+#ifndef LYRA_I8_WAVES
+#define LYRA_I8_WAVES 4   // waves per SIMD the int8 stage kernels are compiled for (5 -> at most 96 VGPRs)
+#endif
+
 namespace lyra {
 
 size_t dec_s0_lds_bytes() { return dec_s0_lds(); }
 int dec_s0_streams_per_wg() { return SD0; }
 
-__global__ __launch_bounds__(NTD0, 4) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+__global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                        const int32_t* __restrict__ ids, int B,
                                                        uint8_t* __restrict__ state, float* __restrict__ out0,
                                                        const uint8_t* __restrict__ packets, int num_stages,
                                                        const float* __restrict__ cb, int code_bytes) {
   dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
 }
-__global__ __launch_bounds__(NTD0, 4) void dec_s0_dr_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+__global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_dr_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                           const int32_t* __restrict__ ids, int B,
                                                           uint8_t* __restrict__ state, float* __restrict__ out0,
                                                           const uint8_t* __restrict__ packets, int num_stages,

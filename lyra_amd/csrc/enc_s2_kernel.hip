@@ -13,18 +13,22 @@ extern "C" int lyra_hip_debug_wgtrace_s2(long long* out) {
 }
 #endif
 
+#ifndef LYRA_I8_WAVES
+#define LYRA_I8_WAVES 4   // waves per SIMD the int8 stage kernels are compiled for (5 -> at most 96 VGPRs)
+#endif
+
 namespace lyra {
 
 size_t enc_s2_lds_bytes() { return enc_s2_lds(); }
 int enc_s2_streams_per_wg() { return S2; }
 
-__global__ __launch_bounds__(NT2, 4) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+__global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, float* __restrict__ feats,
                                                       float* __restrict__ codes_dbg, int code_bytes) {
   enc_s2_body<0>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes);
 }
-__global__ __launch_bounds__(NT2, 4) void enc_s2_dr_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+__global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_dr_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ feats,
                                                          float* __restrict__ codes_dbg, int code_bytes) {

@@ -149,6 +149,23 @@ def test_bench_main_two_ranks_with_stub_context_gloo():
     assert r["stub"]["weights_bytes"] == os.path.getsize(os.path.join(ROOT, "lyra_amd", "assets", "lyra_v1.lyrapack"))
 
 
+def test_cpp_plugin_layer_host_logic_against_fake_abi(tmp_path):
+    """lyra_amd/host/lyra_hip_components.cc (stream slots, call combining, per-call validation) compiled against a CPU
+    stand-in for the C ABI (tests/host_stub/fake_lyra_hip.cc): 24 threads x 20 hops x 5 plugin calls, three bit rates.
+    Every caller gets its own stream's result, device calls never overlap, and waiting calls were combined."""
+    host = os.path.join(ROOT, "lyra_amd", "host")
+    stub = os.path.join(ROOT, "tests", "host_stub")
+    exe = str(tmp_path / "combiner_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + host, "-I" + os.path.join(host, "shims"), "-I" + ROOT,
+                           "-o", exe, os.path.join(stub, "combiner_test.cc"), os.path.join(host, "lyra_hip_components.cc"),
+                           os.path.join(stub, "fake_lyra_hip.cc")])
+    r = subprocess.run([exe, "24", "20"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    st = dict(zip(r.stdout.split()[0::2], map(int, r.stdout.split()[1::2])))
+    assert st["plugin_calls"] == 24 * 20 * 5 == st["fake_rows"] and st["overlapping"] == 0
+    assert st["device_calls"] < st["plugin_calls"] and st["largest_batch"] >= 2, st
+
+
 REF_MODEL_DIR = "/root/reference/lyra/model_coeffs"
 
 
