@@ -378,6 +378,8 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
   };
   const f32x4* wfrag = P.up.w + tile0 * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 5..9, 8-15 taps 0..4
   gemm_f32<2, NTW, 8, 16>(XB, aoff, wfrag, acc);
+  LYRA_TSTAMP(54);
+  LYRA_WSTAMP(114);
   f32x4 tail[NTW];
   const bool lo = lane < 32;
 #pragma unroll
@@ -391,6 +393,8 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
       tail[j][e] = bb;                         // lanes 0-31: block 4 = Y(t3)
     }
   gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
+  LYRA_TSTAMP(55);
+  LYRA_WSTAMP(115);
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int n = (tile0 + j) * 16 + (lane & 15);
@@ -458,13 +462,18 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   }
   __syncthreads();
   LYRA_TSTAMP(51);
+  LYRA_WSTAMP(111);
   resblocks128<SD1, NTD1>(XB, DB, PB, cx, P.dw, P.pw, P.cv, st::D_R1_0, st::D_R1_1, st::D_R1_2, H0);
+  LYRA_TSTAMP(52);
+  LYRA_WSTAMP(112);
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, rs = idx >> 5;
     f32x4* x = reinterpret_cast<f32x4*>(&XB[rs * CS1 + p4 * 4]);
     *x = lrelu4(*x);
   }
   __syncthreads();
+  LYRA_TSTAMP(53);
+  LYRA_WSTAMP(113);
   // transposed conv k10/s5: 20 N tiles over the waves (5 each with 4 waves; 3,3,3,3,2,2,2,2 with 8)
   if (NTD1 == 256) dec_s1_tconv<5>(XB, SB, P, cx, b0, out1, wave * 5);
   else if (wave < 4) dec_s1_tconv<3>(XB, SB, P, cx, b0, out1, wave * 3);
@@ -526,6 +535,7 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   }
   LYRA_TSTAMP(61);
   resblocks64r<SD2, NTD2>(xr, XB + 3 * SD2 * CS0, cx, P.dw, P.pw, P.cv, st::D_R2_0, st::D_R2_1, st::D_R2_2);
+  LYRA_TSTAMP(62);
 #pragma unroll
   for (int i = 0; i < 5; ++i)
 #pragma unroll

@@ -1,9 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-R=$GRAFT_REPO_ROOT
-b() { python bench.py --no-cpu-baseline --no-kernel-table "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"])'; }
-for i in 1 2 3 4; do
-echo "base: $(b)   int8 stages at 96 VGPRs: $(LYRA_HIP_LIB=$R/lyra_amd/variants/i8w5.so b)"
+for v in timing te1 te3; do
+export LYRA_HIP_LIB=$GRAFT_REPO_ROOT/lyra_amd/variants/$v.so
+echo "== $v"
+EXIT_AT="d0:54,55,-1" python tools/pipeline_probe.py 2>&1 | grep exit_at | sed 's/full  *wall.step *//; s/enc_s0.*dec_s1/dec_s1/'
 done
-echo "base $(MODES=full python tools/pipeline_probe.py 2>&1 | grep '^full')"
-echo "i8w5 $(LYRA_HIP_LIB=$R/lyra_amd/variants/i8w5.so MODES=full python tools/pipeline_probe.py 2>&1 | grep '^full')"
