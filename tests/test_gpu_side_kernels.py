@@ -47,3 +47,44 @@ def test_side_kernels_equal_stage_kernels(requant, B, bits):
         for t in range(T):
             assert np.array_equal(outs[0][t][0], other[t][0]), f"packets differ at hop {t}"
             assert np.array_equal(outs[0][t][1], other[t][1]), f"PCM differs at hop {t}"
+
+
+@pytest.mark.parametrize("sub_batches", [None, 2])
+def test_async_pipeline_equals_serial_soak(sub_batches):
+    """The three-stream schedule of the `_dev` calls (extractor / quantizer / decoder streams, two alternating feature
+    buffers inside the library) with NO synchronisation of any kind for 120 steps at B = 4096, against the same calls
+    with the streams forced in call order (lyra_hip_set_serial).  The caller alternates TWO packet buffers (the
+    two-buffer rule of include/lyra_hip.h "Streams": an encode that overtook the decode of two steps earlier would tear
+    that decode's input) and keeps every step's PCM in a buffer of its own, so every step is checked: a missing
+    ordering edge anywhere shows up as a PCM difference at some step."""
+    import torch
+    import lyra_amd
+    B, T, bits = 4096, 120, 184
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    pcm = torch.randint(-32768, 32768, (8, B, 320), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
+    ids = torch.arange(B, device=dev, dtype=torch.int32)
+    nb = lyra_amd.packet_size(bits)
+
+    def run(serial):
+        ctx = lyra_amd.LyraHip(max_streams=B, sub_batches=sub_batches)
+        ctx.torch_order = False
+        ctx.set_serial(serial)
+        pk = [torch.empty((B, nb), device=dev, dtype=torch.uint8) for _ in range(2)]
+        out = torch.empty((T, B, 320), device=dev, dtype=torch.int16)
+        torch.cuda.synchronize()
+        try:
+            for t in range(T):
+                ctx.encode_dev(ids, pcm[t % 8], bits, pk[t & 1])
+                ctx.decode_dev(ids, pk[t & 1], bits, out[t])
+            ctx.synchronize()
+            return [p.cpu().numpy() for p in pk], out.cpu().numpy()
+        finally:
+            ctx.close()
+
+    a_pk, a_out = run(serial=False)
+    s_pk, s_out = run(serial=True)
+    for t in range(T):
+        assert np.array_equal(a_out[t], s_out[t]), f"PCM differs at step {t}"
+    assert np.array_equal(a_pk[0], s_pk[0]) and np.array_equal(a_pk[1], s_pk[1])
