@@ -97,13 +97,17 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  * layer shapes the kernels are specialised to): a truncated or foreign file
  * gives LYRA_HIP_EMODEL.
  * Developer switches read from the environment here (results are bit-identical
- * either way): LYRA_HIP_FUSED=<mask> -- bit 0: the encoder side
- * (lyra_hip_extract / lyra_hip_encode) as one launch instead of three, bit 1: the
- * decoder side likewise (slower at B = 4096; default 0);
- * LYRA_HIP_NO_CODE_WARM -- skip the stage kernels' instruction pre-fetch;
- * LYRA_HIP_SUBBATCHES=<n> -- split every `_dev` call into n sub-batches on
- * stream pairs of their own (pays when only one side is driven: decode-only at
- * B = 8192 +6 % with n = 2; default 1). */
+ * either way; each exists for an A/B recorded in DESIGN.md):
+ *   LYRA_HIP_SUBBATCHES=<n>  split every `_dev` call into n sub-batches on stream
+ *                            sets of their own (pays when only one side is driven:
+ *                            decode-only at B = 8192 +6 % with n = 2; default 1);
+ *   LYRA_HIP_FUSED=<mask>    bit 0: the encoder side (extract / encode) as one
+ *                            launch instead of three, bit 1: the decoder side
+ *                            likewise (slower at B = 4096; default 0);
+ *   LYRA_HIP_RVQ_WIDE=1      the 104 KB / 244-VGPR quantizer kernel;
+ *   LYRA_HIP_FLAT_PRIO=1     all library streams at the same priority;
+ *   LYRA_HIP_EVENT_FENCE=1   internal events with system-scope fences;
+ *   LYRA_HIP_NO_CODE_WARM=1  skip the stage kernels' instruction pre-fetch. */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
 /* The same from an in-memory lyra_v1.lyrapack image (e.g. read once by rank 0 and broadcast to the other GPUs' ranks
  * over RCCL); the image is copied, the caller keeps ownership. */
