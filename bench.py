@@ -29,7 +29,7 @@ One JSON line on rank 0:
   * `roofline` = the WHOLE STEP against its binding bound (fp32 MFMA for encode+decode: 5.43 MFLOP of fp32 MFMA work
     per stream-frame = 34.5 ns at 157.3 TFLOP/s, vs 13.4 ns of HBM time for the bytes the kernels move);
   * `kernels` = per-kernel durations measured live with HIP events on the library's own streams in a SERIALISED pass
-    (lyra_hip_set_serial: the two library streams strictly in call order, so no cross-stream contention), each with
+    (lyra_hip_set_serial: the library streams strictly in call order, so no cross-stream contention), each with
     its own binding bound computed from the bytes it actually moves (lyra_amd/csrc/state_layout.h);
   * `dominant_kernel` = the kernel with the largest serialised duration, bracketed by HIP events inside the timed
     region (i.e. under the two-stream overlap the step really runs with);
@@ -365,7 +365,7 @@ class Shard:
         self.torch.cuda.synchronize(self.dev)
 
     def kernel_table(self, step, first, nsteps):
-        """Serialised pass: every kernel bracketed by HIP events, the two library streams strictly in call order."""
+        """Serialised pass: every kernel bracketed by HIP events, the library streams strictly in call order."""
         ctx = self.ctx
         ctx.set_serial(True)
         ctx.profile_enable(True)

@@ -9,7 +9,7 @@
  * callers of these functions; INTEGRATION.md shows the binding a reference
  * maintainer would add in lyra/lyra_components.cc:42-65.
  *
- * Model: one context = one GPU + two HIP streams (encode side / decode side,
+ * Model: one context = one GPU + three HIP streams (encode side / decode side / quantizer,
  * see "Streams") + per-stream codec state for `max_streams` independent audio
  * streams.  A "frame" is one 20 ms hop of
  * 16 kHz audio (320 samples); the codec is streaming/causal, so stream `id`
@@ -223,7 +223,7 @@ int lyra_hip_synchronize(lyra_hip_ctx* ctx);
 /* Ordering against a caller-owned HIP stream (hipStream_t as void*, NULL = the null stream); see "Streams". */
 int lyra_hip_wait_for_stream(lyra_hip_ctx* ctx, void* caller_stream);
 int lyra_hip_stream_wait(lyra_hip_ctx* ctx, void* caller_stream);
-/* on != 0: encode-side calls also wait for the MOST RECENT decode-side call, i.e. the two library streams run
+/* on != 0: encode-side calls also wait for the MOST RECENT decode-side call, i.e. the library streams run
  * strictly in call order (one buffer set suffices; per-kernel timings are free of cross-stream contention). */
 int lyra_hip_set_serial(lyra_hip_ctx* ctx, int on);
 

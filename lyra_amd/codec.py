@@ -364,7 +364,7 @@ class LyraHip:
     torch_order = True
 
     def set_serial(self, on=True):
-        """Run the two library streams strictly in call order (lyra_hip_set_serial)."""
+        """Run the library streams strictly in call order (lyra_hip_set_serial)."""
         self._chk(self.L.lyra_hip_set_serial(self.h, 1 if on else 0))
 
     def _dev_ptr(self, t, dtype_name, shape, what):
