@@ -399,6 +399,15 @@ class LyraHip:
                        self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"), num_bits,
                        self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"))
 
+    def encode_dtx_dev(self, d_ids, d_pcm, num_bits, d_packets, d_packet_bytes):
+        """LyraEncoder::Encode with enable_dtx on device buffers: packets uint8 [B][nbytes] (rows of noise hops are
+        left untouched) and packet_bytes int32 [B] (0 = empty packet)."""
+        B = d_pcm.shape[0]
+        self._dev_call(self.L.lyra_hip_encode_dtx_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"), num_bits,
+                       self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"),
+                       self._dev_ptr(d_packet_bytes, "int32", (B,), "packet bytes"))
+
     def decode_dev(self, d_ids, d_packets, num_bits, d_pcm):
         B = d_pcm.shape[0]
         self._dev_call(self.L.lyra_hip_decode_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,

@@ -108,3 +108,46 @@ def test_gpu_dtx_encode(golden_dir, oracle_exact):
                 assert nbytes[b] == bits // 8 and np.array_equal(pk[b], want), (t, b)
     assert n_empty > 20      # the silence stream does go quiet; otherwise this test checks nothing
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_dtx_device_pipeline_equals_host_calls(golden_dir):
+    """lyra_hip_encode_dtx_dev in a loop with no synchronisation (noise estimator + extractor on the encode-side stream,
+    quantizer on its own stream with the live-stream mask of that call, the next call's noise kernel already running)
+    against the synchronous host-pointer lyra_hip_encode_dtx on a second context: packets of live hops and the
+    packet-length vector of every step identical.  Speech, late-starting speech, stationary noise and digital silence,
+    replicated to 64 streams with scattered ids."""
+    import torch
+    import lyra_amd
+    speech, noise, quiet = _speech_and_noise(golden_dir, 90)
+    silence = np.zeros_like(speech)
+    base = np.stack([speech, np.concatenate([silence[:40], speech[:50]]), noise, silence], axis=1)   # [T][4][320]
+    T, B, bits = base.shape[0], 64, 184
+    pcm = base[:, np.arange(B) % 4].copy()
+    ids = np.random.default_rng(3).permutation(200)[:B].astype(np.int32)
+    nb = lyra_amd.packet_size(bits)
+    host = lyra_amd.LyraHip(max_streams=256)
+    dev_ctx = lyra_amd.LyraHip(max_streams=256)
+    dev_ctx.torch_order = False
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    d_ids = torch.from_numpy(ids).to(dev)
+    d_pk = torch.zeros((T, B, nb), device=dev, dtype=torch.uint8)
+    d_len = torch.full((T, B), -1, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()
+    try:
+        for t in range(T):
+            dev_ctx.encode_dtx_dev(d_ids, d_pcm[t], bits, d_pk[t], d_len[t])
+        dev_ctx.synchronize()
+        got_pk, got_len = d_pk.cpu().numpy(), d_len.cpu().numpy()
+        n_empty = 0
+        for t in range(T):
+            pk, nbytes = host.encode_dtx(pcm[t], bits, ids)
+            assert np.array_equal(got_len[t], nbytes), f"packet lengths differ at step {t}"
+            live = nbytes > 0
+            assert np.array_equal(got_pk[t][live], pk[live]), f"packets differ at step {t}"
+            n_empty += int((~live).sum())
+        assert n_empty > 500      # silence and noise streams do go quiet
+    finally:
+        host.close()
+        dev_ctx.close()
