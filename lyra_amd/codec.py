@@ -408,6 +408,26 @@ class LyraHip:
                        self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"),
                        self._dev_ptr(d_packet_bytes, "int32", (B,), "packet bytes"))
 
+    def noise_receive_dev(self, d_ids, d_pcm, d_is_noise, side="decoder"):
+        """NoiseEstimator::ReceiveSamples on device buffers: pcm int16 [B][320] -> is_noise int32 [B]."""
+        B = d_pcm.shape[0]
+        self._dev_call(self.L.lyra_hip_noise_receive_dev, self._SIDES[side], self._dev_ptr(d_ids, "int32", (B,), "stream ids"),
+                       B, self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"), self._dev_ptr(d_is_noise, "int32", (B,), "is_noise"))
+
+    def resample_dev(self, d_ids, d_in, in_rate, out_rate, d_out, side="encoder"):
+        """Resampler::Resample per stream on device buffers: int16 [B][n_in] -> int16 [B][n_in * out_rate / in_rate]."""
+        B, n_in = d_in.shape
+        self._dev_call(self.L.lyra_hip_resample_dev, self._SIDES[side], self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_in, "int16", (B, n_in), "input audio"), n_in, in_rate, out_rate,
+                       self._dev_ptr(d_out, "int16", (B, n_in * out_rate // in_rate), "output audio"))
+
+    def comfort_noise_dev(self, d_ids, d_features, d_pcm):
+        """ComfortNoiseGenerator on device buffers; d_features float32 [B][160] or None (= decoder-side noise estimate)."""
+        B = d_pcm.shape[0]
+        self._dev_call(self.L.lyra_hip_comfort_noise_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_features, "float32", (B, NUM_MEL), "features") if d_features is not None else None,
+                       self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"))
+
     def decode_dev(self, d_ids, d_packets, num_bits, d_pcm):
         B = d_pcm.shape[0]
         self._dev_call(self.L.lyra_hip_decode_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,

@@ -175,3 +175,57 @@ def test_gpu_comfort_noise_from_noise_estimate(golden_dir, oracle_exact):
     assert np.array_equal(a, b)
     assert np.abs(a).max() > 50       # audible noise, not silence
     ctx.close(); ctx2.close()
+
+
+@pytest.mark.gpu
+def test_gpu_device_pointer_variants_equal_host_variants(golden_dir):
+    """lyra_hip_resample_dev / lyra_hip_noise_receive_dev / lyra_hip_comfort_noise_dev against the host-pointer entry
+    points on a second context fed the same hops: resampled audio, is_noise flags and comfort-noise hops identical
+    (the host variants are the ones pinned to the oracle above and in test_noise_estimator.py)."""
+    import torch
+    import lyra_amd
+    rng = np.random.Generator(np.random.PCG64(99))
+    B, T = 24, 40
+    ids = rng.permutation(100)[:B].astype(np.int32)
+    speech = np.load(os.path.join(golden_dir, "speech_sample1.npz"))["pcm_in"]          # [50][320]
+    hops = np.empty((T, B, 320), np.int16)
+    for b in range(B):
+        kind = b % 3
+        if kind == 0:
+            hops[:, b] = speech[(np.arange(T) + b) % 50]
+        elif kind == 1:
+            hops[:, b] = rng.normal(0, 300, size=(T, 320)).astype(np.int16)
+        else:
+            hops[:, b] = 0
+    audio48 = rng.integers(-20000, 20000, size=(T, B, 960)).astype(np.int16)
+    dev = torch.device("cuda", 0)
+    a, b_ = lyra_amd.LyraHip(max_streams=128), lyra_amd.LyraHip(max_streams=128)
+    a.set_cng_seed(1234); b_.set_cng_seed(1234)
+    d_ids = torch.from_numpy(ids).to(dev)
+    try:
+        for t in range(T):
+            # resampler 48 kHz -> 16 kHz (encoder side) and 16 -> 48 (decoder side)
+            want = a.resample(audio48[t], 48000, 16000, ids, side="encoder")
+            d_out = torch.empty((B, 320), device=dev, dtype=torch.int16)
+            b_.resample_dev(d_ids, torch.from_numpy(audio48[t]).to(dev), 48000, 16000, d_out, side="encoder")
+            b_.synchronize()
+            assert np.array_equal(d_out.cpu().numpy(), want), f"48->16 differs at hop {t}"
+            want = a.resample(hops[t], 16000, 48000, ids, side="decoder")
+            d_out = torch.empty((B, 960), device=dev, dtype=torch.int16)
+            b_.resample_dev(d_ids, torch.from_numpy(hops[t]).to(dev), 16000, 48000, d_out, side="decoder")
+            b_.synchronize()
+            assert np.array_equal(d_out.cpu().numpy(), want), f"16->48 differs at hop {t}"
+            # decoder-side noise estimator, then comfort noise from its estimate
+            want = a.noise_receive(hops[t], ids, side="decoder")
+            d_flag = torch.empty((B,), device=dev, dtype=torch.int32)
+            b_.noise_receive_dev(d_ids, torch.from_numpy(hops[t]).to(dev), d_flag, side="decoder")
+            b_.synchronize()
+            assert np.array_equal(d_flag.cpu().numpy(), want), f"is_noise differs at hop {t}"
+            want = a.comfort_noise(None, ids, B)
+            d_pcm = torch.empty((B, 320), device=dev, dtype=torch.int16)
+            b_.comfort_noise_dev(d_ids, None, d_pcm)
+            b_.synchronize()
+            assert np.array_equal(d_pcm.cpu().numpy(), want), f"comfort noise differs at hop {t}"
+    finally:
+        a.close()
+        b_.close()
