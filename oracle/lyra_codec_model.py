@@ -16,12 +16,43 @@ FADE = 640          # GetFadeDurationSamples (lyra_decoder.cc:53-62)
 TO_CNG, FROM_CNG = 1, -1
 
 
+class OracleKit:
+    """The components the two classes below are assembled from: the oracle's (default), or stand-ins with the same
+    interface (tests/host_stub/fake_kit.py, for the CPU test of the C++ twins' host logic)."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+        self.Resampler = lo.Resampler
+
+    def Stream(self):
+        return lo.Stream(self.o)
+
+    def NoiseEstimator(self, side):
+        return lo.NoiseEstimator(self.o)
+
+    def ComfortNoiseGenerator(self, seed):
+        return lo.ComfortNoiseGenerator(self.o, seed=seed)
+
+    def rvq_encode(self, feat, num_stages):
+        return self.o.rvq_encode(feat, num_stages)
+
+    def pack(self, idx, num_stages):
+        return self.o.pack(idx, num_stages)
+
+    def unpack(self, packets, num_stages):
+        return self.o.unpack(packets, num_stages)
+
+    def rvq_decode(self, idx):
+        return self.o.rvq_decode(idx)
+
+
 class RefLyraEncoder:
-    def __init__(self, oracle, sample_rate_hz, num_bits, enable_dtx):
-        self.o, self.rate, self.bits, self.dtx = oracle, sample_rate_hz, num_bits, enable_dtx
-        self.resampler = lo.Resampler(sample_rate_hz, 16000) if sample_rate_hz != 16000 else None
-        self.stream = lo.Stream(oracle)
-        self.noise = lo.NoiseEstimator(oracle) if enable_dtx else None
+    def __init__(self, oracle, sample_rate_hz, num_bits, enable_dtx, kit=None):
+        self.o = kit if kit is not None else OracleKit(oracle)
+        self.rate, self.bits, self.dtx = sample_rate_hz, num_bits, enable_dtx
+        self.resampler = self.o.Resampler(sample_rate_hz, 16000) if sample_rate_hz != 16000 else None
+        self.stream = self.o.Stream()
+        self.noise = self.o.NoiseEstimator(0) if enable_dtx else None
 
     def Encode(self, audio):
         audio = np.asarray(audio, np.int16)
@@ -65,14 +96,15 @@ class _Fifo:
 
 
 class RefLyraDecoder:
-    def __init__(self, oracle, sample_rate_hz, cng_seed):
-        self.o, self.rate = oracle, sample_rate_hz
-        self.stream = lo.Stream(oracle)
-        self.noise = lo.NoiseEstimator(oracle)
-        self.cng_gen = lo.ComfortNoiseGenerator(oracle, seed=cng_seed)
+    def __init__(self, oracle, sample_rate_hz, cng_seed, kit=None):
+        self.o = kit if kit is not None else OracleKit(oracle)
+        self.rate = sample_rate_hz
+        self.stream = self.o.Stream()
+        self.noise = self.o.NoiseEstimator(1)
+        self.cng_gen = self.o.ComfortNoiseGenerator(cng_seed)
         self.model = _Fifo(lambda f: self.stream.decode(f))
         self.cng = _Fifo(lambda f: self.cng_gen.generate(f))
-        self.resampler = lo.Resampler(16000, sample_rate_hz) if sample_rate_hz != 16000 else None
+        self.resampler = self.o.Resampler(16000, sample_rate_hz) if sample_rate_hz != 16000 else None
         self.leftover = np.zeros(0, np.int16)
         self.concealment, self.fade, self.fade_dir = 0, 0, FROM_CNG
         self.noise_buf = np.zeros(0, np.int16)

@@ -37,10 +37,11 @@ def test_reference_model_decoder_state_machine(oracle_exact):
     assert not dec.is_comfort_noise()
 
 
-def _run_session(tmp_path, oracle, rate, bitrate, dtx, pcm, script):
+def _run_session(tmp_path, oracle, rate, bitrate, dtx, pcm, script, demo=None):
     import lyra_amd
-    demo = os.path.join(ROOT, "lyra_amd", "decoder_demo")
-    assert os.path.exists(demo), "lyra_amd/decoder_demo not built (__graft_entry__.build())"
+    if demo is None:
+        demo = os.path.join(ROOT, "lyra_amd", "decoder_demo")
+        assert os.path.exists(demo), "lyra_amd/decoder_demo not built (__graft_entry__.build())"
     T, n, hop = pcm.shape
     pin, sc = tmp_path / "in.s16", tmp_path / "script.txt"
     pk, ln, pout = tmp_path / "pk.bin", tmp_path / "len.i32", tmp_path / "out.s16"
@@ -113,3 +114,65 @@ def test_batch_codec_session_vs_reference_model(tmp_path, golden_dir, oracle_exa
     assert saw_cng                      # the 9-packet burst takes stream 0 all the way into comfort noise
     if dtx:
         assert (lengths == 0).sum() > 5   # the silent stretch is sent as empty packets
+
+
+def _build_fake_demo(tmp_path):
+    """decoder_demo + lyra_batch_codec.cc against tests/host_stub/fake_lyra_hip_codec.cc (no GPU, no product library)."""
+    host = os.path.join(ROOT, "lyra_amd", "host")
+    exe = str(tmp_path / "decoder_demo_fake")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + host, "-I" + os.path.join(host, "shims"), "-I" + ROOT, "-o", exe,
+                           os.path.join(host, "decoder_demo.cc"), os.path.join(host, "lyra_batch_codec.cc"),
+                           os.path.join(ROOT, "tests", "host_stub", "fake_lyra_hip_codec.cc")])
+    return exe
+
+
+@pytest.mark.parametrize("rate,bitrate,dtx", [(16000, 6000, False), (48000, 3200, True), (8000, 9200, False),
+                                              (32000, 6000, True)])
+def test_batch_codec_host_logic_against_fake_abi(tmp_path, rate, bitrate, dtx):
+    """CPU: the C++ twins' host logic alone -- the C ABI underneath replaced by integer formulas with per-stream call
+    counters (tests/host_stub), the reference model assembled from the same formulas (fake_kit.py).  Everything the
+    twins do around the device calls is then checked EXACTLY, sample for sample: resampling bookkeeping and leftovers,
+    DTX empty packets, which streams are served by which call in which round, queueing, concealment, fades, comfort
+    noise, noise-estimator updates on received hops only."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "host_stub"))
+    from fake_kit import FakeKit
+    from oracle import lyra_codec_model as M
+    bits = {3200: 64, 6000: 120, 9200: 184}[bitrate]
+    T, n, hop = 60, 6, rate // 50
+    rng = np.random.default_rng(rate + bitrate)
+    loud = rng.integers(-12000, 12000, size=(T, n, hop)).astype(np.int16)
+    pcm = loud.copy()
+    pcm[15:30, 1] = rng.integers(-20, 20, size=(15, hop))      # a quiet stretch: DTX food
+    pcm[:, 4] = rng.integers(-30, 30, size=(T, hop))           # a stream that is noise throughout
+    script = []
+    for t in range(T):
+        mask = "".join(["0" if 12 <= t < 21 else "1", "1", "0" if t % 7 == 3 else "1", "1", "1",
+                        "0" if 40 <= t < 43 else "1"])
+        sizes = [hop] if t % 3 == 0 else ([hop // 4 + 3, hop - hop // 4 - 3] if t % 3 == 1 else [1, hop // 2, hop - hop // 2 - 1])
+        if t % 11 == 5:
+            sizes = [0] + sizes          # DecodeSamples(0) is legal
+        script.append((mask, sizes))
+    packets, lengths, out = _run_session(tmp_path, None, rate, bitrate, dtx, pcm, script, demo=_build_fake_demo(tmp_path))
+
+    encs = [M.RefLyraEncoder(None, rate, bits, dtx, kit=FakeKit()) for _ in range(n)]
+    decs = [M.RefLyraDecoder(None, rate, cng_seed=0, kit=FakeKit()) for _ in range(n)]
+    pos = 0
+    saw_cng = saw_empty = False
+    for t, (mask, sizes) in enumerate(script):
+        for s_ in range(n):
+            p = encs[s_].Encode(pcm[t, s_])
+            assert lengths[t, s_] == p.size, (t, s_)
+            saw_empty = saw_empty or p.size == 0
+            if p.size:
+                assert np.array_equal(packets[t, s_], p), (t, s_)
+                if mask[s_] == "1":
+                    decs[s_].SetEncodedPacket(p)
+        for k in sizes:
+            got = out[pos:pos + n * k].reshape(n, k)
+            pos += n * k
+            for s_ in range(n):
+                want = decs[s_].DecodeSamples(k)
+                assert np.array_equal(got[s_], want), f"tick {t}, stream {s_}, DecodeSamples({k})"
+                saw_cng = saw_cng or decs[s_].is_comfort_noise()
+    assert pos == out.size and saw_cng and (saw_empty == dtx)
