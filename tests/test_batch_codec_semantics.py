@@ -176,3 +176,47 @@ def test_batch_codec_host_logic_against_fake_abi(tmp_path, rate, bitrate, dtx):
                 assert np.array_equal(got[s_], want), f"tick {t}, stream {s_}, DecodeSamples({k})"
                 saw_cng = saw_cng or decs[s_].is_comfort_noise()
     assert pos == out.size and saw_cng and (saw_empty == dtx)
+
+
+def test_file_transcode_host_logic_against_fake_abi(tmp_path):
+    """CPU: EncodeFiles / DecodeFiles (lyra_file_codec.cc: WAV I/O, files of different lengths sharing one batch, files
+    leaving the batch as they end, trailing partial hops dropped) over the fake C ABI: every .lyra and every decoded WAV
+    must be what the reference model with the same fake components gives for that file alone."""
+    import sys
+    import wave
+    sys.path.insert(0, os.path.join(ROOT, "tests", "host_stub"))
+    from fake_kit import FakeKit
+    from oracle import lyra_codec_model as M
+    host = os.path.join(ROOT, "lyra_amd", "host")
+    exe = str(tmp_path / "file_demo_fake")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + host, "-I" + os.path.join(host, "shims"), "-I" + ROOT, "-o", exe,
+                           os.path.join(host, "file_demo.cc"), os.path.join(host, "lyra_file_codec.cc"),
+                           os.path.join(host, "lyra_batch_codec.cc"),
+                           os.path.join(ROOT, "tests", "host_stub", "fake_lyra_hip_codec.cc")])
+    rng = np.random.default_rng(5)
+    lengths = {"a": 320 * 17 + 111, "b": 320 * 5, "c": 320 * 6, "d": 320 * 11 - 7, "tiny": 100, "e": 320 * 17}
+    files = {k: rng.integers(-9000, 9000, n).astype(np.int16) for k, n in lengths.items()}
+    wavs = []
+    for name, pcm in files.items():
+        with wave.open(str(tmp_path / f"{name}.wav"), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(pcm.tobytes())
+        wavs.append(str(tmp_path / f"{name}.wav"))
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    r = subprocess.run([exe, "unused_model_dir", "9200", str(out_dir)] + wavs, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    for name, pcm in files.items():
+        hops = len(pcm) // 320
+        enc = np.fromfile(out_dir / f"{name}.lyra", np.uint8)
+        with wave.open(str(out_dir / f"{name}_decoded.wav"), "rb") as w:
+            assert w.getnchannels() == 1 and w.getframerate() == 16000
+            dec = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+        assert enc.size == hops * 23 and dec.size == hops * 320, name
+        e = M.RefLyraEncoder(None, 16000, 184, False, kit=FakeKit())
+        d = M.RefLyraDecoder(None, 16000, cng_seed=0, kit=FakeKit())
+        for h in range(hops):
+            p = e.Encode(pcm[h * 320:(h + 1) * 320])
+            assert np.array_equal(enc[h * 23:(h + 1) * 23], p), (name, h)
+            d.SetEncodedPacket(p)
+            assert np.array_equal(dec[h * 320:(h + 1) * 320], d.DecodeSamples(320)), (name, h)
