@@ -17,6 +17,10 @@ extern "C" int lyra_hip_debug_wgtrace_d0(long long* out) {
 #define LYRA_I8_WAVES 4   // waves per SIMD the int8 stage kernels are compiled for (5 -> at most 96 VGPRs)
 #endif
 
+#ifndef LYRA_C64_WAVES
+#define LYRA_C64_WAVES 4   // waves per SIMD the 64-channel stage kernels are compiled for (3 -> up to 168 VGPRs, no spills)
+#endif
+
 namespace lyra {
 
 size_t dec_s0_lds_bytes() { return dec_s0_lds(); }
@@ -159,7 +163,7 @@ size_t dec_s2_lds_bytes() { return dec_s2_lds(SD2); }
 int dec_s2_streams_per_wg() { return SD2; }
 int dec_s2_threads() { return 64 * SD2; }
 
-__global__ __launch_bounds__(64 * SD2, 4) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
+__global__ __launch_bounds__(64 * SD2, LYRA_C64_WAVES) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                             const int32_t* __restrict__ ids, int B,
                                                             uint8_t* __restrict__ state, int16_t* __restrict__ pcm,
                                                             int code_bytes) {

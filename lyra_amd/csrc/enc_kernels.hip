@@ -13,6 +13,10 @@ extern "C" int lyra_hip_debug_timing(long long* out) {
 }
 #endif
 
+#ifndef LYRA_C64_WAVES
+#define LYRA_C64_WAVES 4   // waves per SIMD the 64-channel stage kernels are compiled for (3 -> up to 168 VGPRs, no spills)
+#endif
+
 namespace lyra {
 
 namespace {
@@ -29,7 +33,7 @@ size_t enc_s1_lds_bytes() { return enc_s1_lds(); }
 int enc_s1_streams_per_wg() { return S1; }
 int enc_s1_threads() { return NT1; }
 
-__global__ __launch_bounds__(64 * S0, 4) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
+__global__ __launch_bounds__(64 * S0, LYRA_C64_WAVES) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                            const int32_t* __restrict__ ids, int B,
                                                            uint8_t* __restrict__ state, float* __restrict__ out0,
                                                            int code_bytes) {
