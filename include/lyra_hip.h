@@ -9,8 +9,8 @@
  * callers of these functions; INTEGRATION.md shows the binding a reference
  * maintainer would add in lyra/lyra_components.cc:42-65.
  *
- * Model: one context = one GPU + three HIP streams (encode side / decode side / quantizer,
- * see "Streams") + per-stream codec state for `max_streams` independent audio
+ * Model: one context = one GPU + four HIP streams (encode side / decode side / quantizer / decoder-side
+ * noise estimator, see "Streams") + per-stream codec state for `max_streams` independent audio
  * streams.  A "frame" is one 20 ms hop of
  * 16 kHz audio (320 samples); the codec is streaming/causal, so stream `id`
  * must be fed its frames in order (the reference keeps this state inside the
@@ -29,15 +29,16 @@
  * H2D/D2H and synchronise); `_dev` variants take DEVICE pointers, enqueue and
  * do not synchronise.
  *
- * Streams: a context runs three HIP streams -- the ENCODE side (extract,
+ * Streams: a context runs four HIP streams -- the ENCODE side (extract,
  * rvq_encode, the feature extractor of encode), the DECODE side (rvq_decode,
  * generate, decode, logmel; the stateless helpers rvq_decode_dev / logmel_dev
  * count as decode-side calls too) and one for the quantizer of
  * lyra_hip_encode_dev / lyra_hip_encode_dtx_dev, which starts once the call's
  * features are ready and runs underneath the next call's feature extractor and
  * the previous call's decoder (a 46-stage dependent chain that would leave the
- * chip nearly idle if anything queued behind it).  Encoder and decoder state
- * are disjoint.
+ * chip nearly idle if anything queued behind it), and one for the decoder-side
+ * NoiseEstimator of lyra_hip_noise_receive_dev, which runs behind the decoder's
+ * last stage underneath the next step.  Encoder and decoder state are disjoint.
  * What the library guarantees on the GPU, without any caller synchronisation:
  *   (1) a decode-side call is ordered after EVERY earlier encode-side call, so
  *       encode_dev -> decode_dev on the produced packets just works;
@@ -215,10 +216,43 @@ int lyra_hip_noise_receive_dev(lyra_hip_ctx* ctx, int side, const int32_t* d_str
 int lyra_hip_encode_dtx_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const int16_t* d_pcm, int num_bits,
                             uint8_t* d_packets, int32_t* d_packet_bytes);
 
-/* The context's HIP streams (hipStream_t as void*), for event timing / ordering by the caller:
- * encode side and decode side.  lyra_hip_synchronize() waits for both. */
+/* n_steps hops of B streams from ONE call (no host language in the loop): per hop what lyra_benchmark times
+ * (lyra_benchmark_lib.cc:121-160) and what LyraEncoder::Encode / LyraDecoder::DecodeSamples run around it.  Step i
+ * (absolute number first_step + i) reads input frame (first_step + i) % ring and uses buffer set (first_step + i) & 1
+ * of every two-element array (the two-buffer rule above).  Same results, hop for hop, as the individual `_dev` calls
+ * in the order resample -> encode[_dtx] -> decode | generate -> noise_receive -> resample. */
+#define LYRA_HIP_STEP_ENCODE 1u         /* lyra_hip_encode_dev (lyra_encoder.cc:143-155) */
+#define LYRA_HIP_STEP_DECODE 2u         /* lyra_hip_decode_dev on the packets of this step -- or, d_features != NULL,
+                                           lyra_hip_generate_dev on those features (lyra_gan_model path) */
+#define LYRA_HIP_STEP_DTX 4u            /* encode with enable_dtx: lyra_hip_encode_dtx_dev (lyra_encoder.cc:131-141) */
+#define LYRA_HIP_STEP_DECODER_NOISE 8u  /* NoiseEstimator::ReceiveSamples on every decoded hop (lyra_decoder.cc:304-311) */
+typedef struct lyra_hip_steps {
+  const int32_t* d_stream_ids;   /* [B] */
+  int B;
+  int num_bits;
+  unsigned flags;                /* LYRA_HIP_STEP_* */
+  long first_step;
+  int n_steps;
+  int ring;                      /* input frames in d_pcm_ring */
+  const int16_t* d_pcm_ring;     /* [ring][B][320 * external_rate / 16000] */
+  uint8_t* d_packets[2];         /* [B][num_bits / 8 rounded up] each */
+  int32_t* d_packet_bytes[2];    /* [B] each (DTX) */
+  int16_t* d_pcm_out[2];         /* [B][320] each: decoder output at 16 kHz */
+  const float* d_features;       /* [B][64] or NULL */
+  int32_t* d_is_noise;           /* [B] (DECODER_NOISE) */
+  int external_rate;             /* 0 / 16000: none; 8000 / 32000 / 48000: the encoder's and the decoder's resampler
+                                    (lyra_encoder.cc:119-122, lyra_decoder.cc:107-113) around the codec */
+  int16_t* d_ext_out[2];         /* [B][320 * external_rate / 16000] each: decoder output at the external rate */
+} lyra_hip_steps;
+int lyra_hip_run_steps_dev(lyra_hip_ctx* ctx, const lyra_hip_steps* steps);
+
+/* The context's HIP streams (hipStream_t as void*), for event timing / ordering by the caller: encode side, decode
+ * side, and the quantizer stream of lyra_hip_encode_dev / lyra_hip_encode_dtx_dev.  The packets of those two calls are
+ * written on the QUANTIZER stream: lyra_hip_stream() does not cover them (it covers every other encode-side output).
+ * lyra_hip_synchronize() waits for all three; lyra_hip_stream_wait() orders a caller's stream behind all three. */
 void* lyra_hip_stream(lyra_hip_ctx* ctx);
 void* lyra_hip_stream_decode(lyra_hip_ctx* ctx);
+void* lyra_hip_stream_quantizer(lyra_hip_ctx* ctx);
 int lyra_hip_synchronize(lyra_hip_ctx* ctx);
 /* Ordering against a caller-owned HIP stream (hipStream_t as void*, NULL = the null stream); see "Streams". */
 int lyra_hip_wait_for_stream(lyra_hip_ctx* ctx, void* caller_stream);

@@ -54,6 +54,18 @@ class LyraHipError(RuntimeError):
     pass
 
 
+class StepsDesc(C.Structure):
+    """lyra_hip_steps (include/lyra_hip.h): many hops of B streams from one call."""
+    _fields_ = [("d_stream_ids", C.c_void_p), ("B", C.c_int), ("num_bits", C.c_int), ("flags", C.c_uint),
+                ("first_step", C.c_long), ("n_steps", C.c_int), ("ring", C.c_int), ("d_pcm_ring", C.c_void_p),
+                ("d_packets", C.c_void_p * 2), ("d_packet_bytes", C.c_void_p * 2), ("d_pcm_out", C.c_void_p * 2),
+                ("d_features", C.c_void_p), ("d_is_noise", C.c_void_p), ("external_rate", C.c_int),
+                ("d_ext_out", C.c_void_p * 2)]
+
+
+STEP_ENCODE, STEP_DECODE, STEP_DTX, STEP_DECODER_NOISE = 1, 2, 4, 8
+
+
 _lib = None
 
 
@@ -105,6 +117,9 @@ def _load():
     L.lyra_hip_stream.argtypes = [vp]
     L.lyra_hip_stream_decode.restype = vp
     L.lyra_hip_stream_decode.argtypes = [vp]
+    L.lyra_hip_stream_quantizer.restype = vp
+    L.lyra_hip_stream_quantizer.argtypes = [vp]
+    L.lyra_hip_run_steps_dev.argtypes = [vp, C.POINTER(StepsDesc)]
     L.lyra_hip_synchronize.argtypes = [vp]
     L.lyra_hip_wait_for_stream.argtypes = [vp, vp]
     L.lyra_hip_stream_wait.argtypes = [vp, vp]
@@ -193,6 +208,10 @@ class LyraHip:
     def stream_handle_decode(self):
         """hipStream_t (int) of the decode side."""
         return self.L.lyra_hip_stream_decode(self.h)
+
+    def stream_handle_quantizer(self):
+        """hipStream_t (int) of the quantizer of encode_dev / encode_dtx_dev (their packets are written there)."""
+        return self.L.lyra_hip_stream_quantizer(self.h)
 
     def synchronize(self):
         self._chk(self.L.lyra_hip_synchronize(self.h))
@@ -427,6 +446,38 @@ class LyraHip:
         self._dev_call(self.L.lyra_hip_comfort_noise_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
                        self._dev_ptr(d_features, "float32", (B, NUM_MEL), "features") if d_features is not None else None,
                        self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"))
+
+    def run_steps_dev(self, d_ids, num_bits, n_steps, first_step=0, d_pcm_ring=None, d_packets=None, d_pcm_out=None,
+                      d_features=None, d_packet_bytes=None, d_is_noise=None, external_rate=16000, d_ext_out=None,
+                      encode=True, decode=True, dtx=False, decoder_noise=False):
+        """lyra_hip_run_steps_dev: n_steps hops of every stream from ONE C call.  d_pcm_ring int16
+        [ring][B][320 * external_rate / 16000]; d_packets / d_pcm_out / d_packet_bytes / d_ext_out: pairs of tensors
+        (step i uses element (first_step + i) & 1)."""
+        B = d_ids.shape[0]
+        n_ext = HOP * external_rate // 16000
+        S = StepsDesc()
+        S.d_stream_ids = self._dev_ptr(d_ids, "int32", (B,), "stream ids")
+        S.B, S.num_bits, S.first_step, S.n_steps = B, num_bits, first_step, n_steps
+        S.flags = (STEP_ENCODE if encode else 0) | (STEP_DECODE if decode else 0) | (STEP_DTX if dtx else 0) | \
+            (STEP_DECODER_NOISE if decoder_noise else 0)
+        S.external_rate = external_rate
+        if d_pcm_ring is not None:
+            S.ring = d_pcm_ring.shape[0]
+            S.d_pcm_ring = self._dev_ptr(d_pcm_ring, "int16", (S.ring, B, n_ext), "pcm ring")
+        for i in range(2):
+            if d_packets is not None:
+                S.d_packets[i] = self._dev_ptr(d_packets[i], "uint8", (B, packet_size(num_bits)), "packets")
+            if d_pcm_out is not None:
+                S.d_pcm_out[i] = self._dev_ptr(d_pcm_out[i], "int16", (B, HOP), "pcm out")
+            if d_packet_bytes is not None:
+                S.d_packet_bytes[i] = self._dev_ptr(d_packet_bytes[i], "int32", (B,), "packet bytes")
+            if d_ext_out is not None:
+                S.d_ext_out[i] = self._dev_ptr(d_ext_out[i], "int16", (B, n_ext), "external-rate out")
+        if d_features is not None:
+            S.d_features = self._dev_ptr(d_features, "float32", (B, NUM_FEATURES), "features")
+        if d_is_noise is not None:
+            S.d_is_noise = self._dev_ptr(d_is_noise, "int32", (B,), "is_noise")
+        self._dev_call(self.L.lyra_hip_run_steps_dev, C.byref(S))
 
     def decode_dev(self, d_ids, d_packets, num_bits, d_pcm):
         B = d_pcm.shape[0]

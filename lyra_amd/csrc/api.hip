@@ -1,8 +1,9 @@
 // api.hip -- the C ABI of include/lyra_hip.h: context, scratch, launches.  No CPU fallback anywhere:
 // every entry point either runs the gfx950 kernels or fails with an error code.
 //
-// Three HIP streams per context: the ENCODE side (extract, rvq_encode, the extractor of encode), the DECODE side
-// (rvq_decode, generate, decode, logmel) and one for the quantizer of the `_dev` encode calls (see encq_begin).
+// Four HIP streams per context: the ENCODE side (extract, rvq_encode, the extractor of encode), the DECODE side
+// (rvq_decode, generate, decode, logmel), one for the quantizer of the `_dev` encode calls (see encq_begin) and one for
+// the decoder-side NoiseEstimator of the `_dev` calls (see noise_dev_begin).
 // Encoder and decoder state are disjoint, so decode of step i overlaps the extractor of step i+1; every stage kernel
 // is a chain of short dependent phases, and two chains in flight fill each other's bubbles.  Ordering: a decode-side
 // call waits (on the GPU) for every earlier encode-side call; encode-side outputs never overtake any decode-side call
@@ -38,9 +39,20 @@ struct lyra_hip_ctx {
   hipStream_t se[KMAX] = {};       // encode side
   hipStream_t sd[KMAX] = {};       // decode side
   hipStream_t sq[KMAX] = {};       // the quantizer of the `_dev` encode calls (see encq_begin)
-  hipEvent_t ev_enc[KMAX] = {};    // handle (not owned): end of the latest encode-side work of chunk k, one of ev_encs
+  hipStream_t sn = nullptr;        // the decoder-side NoiseEstimator of lyra_hip_noise_receive_dev (see noise_dev_begin)
+  hipEvent_t ev_noise[2] = {};     // end of the two latest decoder-side `_dev` noise calls on sn, by parity
+  long n_noise_calls = 0;          // decoder-side `_dev` noise calls so far
+  long noise_done_dec = 0;         // the decode-side streams are ordered after this many of them ...
+  long cover_sq[KMAX] = {};        // ... and the latest quantizer record of chunk k after this many (see noise_dev_begin)
   hipEvent_t ev_encs[3][KMAX] = {};// [0], [1]: `_dev` encode calls by parity, recorded on sq[k] after the quantizer;
                                    // [2]: every other encode-side call, recorded on se[k]
+  // The decode side has to see BOTH kinds of encode-side work: what ran last on se[k] and the latest quantizer on sq[k]
+  // (an extract_dev after an encode_dev does not order the quantizer's packet writes).  Sequence numbers say which of
+  // the two a decode-side stream has not waited for yet, so the steady state still costs one wait per call.
+  long seq_se[KMAX] = {}, seq_sq[KMAX] = {};                 // records so far on se[k] (ev_encs[2][k]) / sq[k]
+  int sq_slot[KMAX] = {};                                     // ev_encs slot (0/1) of the latest quantizer of chunk k
+  long seen_se[KMAX + 1][KMAX] = {}, seen_sq[KMAX + 1][KMAX] = {};   // [decode stream (KMAX = sn)][chunk]: number already waited for
+  int encq_nk[2] = {1, 1};                                    // chunks of the `_dev` encode call of each parity
   hipEvent_t ev_feat[KMAX] = {};   // features of the current `_dev` encode call ready on se[k]
   long n_encq_calls = 0;           // `_dev` encode calls so far (parity selects the feature buffer and ev_encs slot)
   hipEvent_t ev_dec[2][KMAX] = {}; // end of the two latest decode-side calls on sd[k]
@@ -120,6 +132,7 @@ int sync_all(lyra_hip_ctx* c) {
     if (c->sd[k]) HIPCHK(c, hipStreamSynchronize(c->sd[k]));
     if (c->sq[k]) HIPCHK(c, hipStreamSynchronize(c->sq[k]));
   }
+  if (c->sn) HIPCHK(c, hipStreamSynchronize(c->sn));
   return 0;
 }
 
@@ -220,7 +233,7 @@ enum { K_ENC_S0, K_ENC_S1, K_ENC_S2, K_RVQ_ENC, K_RVQ_DEC, K_DEC_S0, K_DEC_S1, K
        K_CNG, K_ENC_SIDE, K_DEC_SIDE, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"enc_s0_kernel", "enc_s1_kernel", "enc_s2_kernel", "rvq_encode_kernel",
                                            "rvq_decode_kernel", "dec_s0_kernel", "dec_s1_kernel", "dec_s2_kernel",
-                                           "logmel_kernel", "noise_update_kernel", "resample_kernel", "cng_kernel",
+                                           "logmel_kernel", "logmel_noise_kernel", "resample_kernel", "cng_kernel",
                                            "enc_side_kernel", "dec_side_kernel"};
 
 hipEvent_t take_event(lyra_hip_ctx* c) {
@@ -261,7 +274,7 @@ int enc_side_begin(lyra_hip_ctx* c, int k) {
 }
 int enc_side_done(lyra_hip_ctx* c, int k) {
   HIPCHK(c, hipEventRecord(c->ev_encs[2][k], c->se[k]));
-  c->ev_enc[k] = c->ev_encs[2][k];
+  c->seq_se[k]++;
   return 0;
 }
 // The `_dev` encode calls (lyra_hip_encode_dev, lyra_hip_encode_dtx_dev) run the feature extractor on se[k] and the
@@ -277,9 +290,17 @@ int encq_begin(lyra_hip_ctx* c, int k) {
   return 0;
 }
 // The feature buffer of this call was last read by the quantizer of the call before the previous one: the extractor's
-// last stage (the only writer) waits for it, stages 0 and 1 do not.
-hipEvent_t encq_buffer_free(lyra_hip_ctx* c, int k) {
-  return c->n_encq_calls >= 2 ? c->ev_encs[c->n_encq_calls & 1][k] : nullptr;
+// last stage (the only writer) waits for it, stages 0 and 1 do not.  That call may have been split differently
+// (LYRA_HIP_SUBBATCHES > 1 and a batch below the split threshold, or the unsplit DTX path): then chunk k of this call
+// overlaps several of its chunks and waits for all of them.
+struct EventList { hipEvent_t e[lyra_hip_ctx::KMAX]; int n = 0; };
+EventList encq_buffer_free(lyra_hip_ctx* c, int k, int nk_now) {
+  EventList l;
+  if (c->n_encq_calls < 2) return l;
+  const int p = (int)(c->n_encq_calls & 1), nk_then = c->encq_nk[p];
+  if (nk_then == nk_now) { l.e[l.n++] = c->ev_encs[p][k]; return l; }
+  for (int j = 0; j < nk_then; ++j) l.e[l.n++] = c->ev_encs[p][j];
+  return l;
 }
 float* encq_features(lyra_hip_ctx* c) { return (c->n_encq_calls & 1) ? c->d_feat2 : c->d_feat; }
 int encq_handoff(lyra_hip_ctx* c, int k) {   // extractor done on se[k] -> quantizer may start on sq[k]
@@ -289,16 +310,70 @@ int encq_handoff(lyra_hip_ctx* c, int k) {   // extractor done on se[k] -> quant
   if (c->n_dec_calls >= 2) HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_dec[c->n_dec_calls & 1][k], 0));
   if (c->serial && c->n_dec_calls >= 1)
     HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_dec[(c->n_dec_calls - 1) & 1][k], 0));
+  if (c->n_noise_calls - 1 > std::max(c->cover_sq[k], c->noise_done_dec)) {   // see noise_dev_begin
+    HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_noise[(c->n_noise_calls - 2) & 1], 0));
+    c->cover_sq[k] = c->n_noise_calls - 1;
+  }
   return 0;
 }
 int encq_done(lyra_hip_ctx* c, int k) {
   const int p = (int)(c->n_encq_calls & 1);
   HIPCHK(c, hipEventRecord(c->ev_encs[p][k], c->sq[k]));
-  c->ev_enc[k] = c->ev_encs[p][k];
+  c->sq_slot[k] = p;
+  c->seq_sq[k]++;
   return 0;
 }
+// include/lyra_hip.h "Streams" (1): ordered after EVERY earlier encode-side call -- the latest record on se[j] and the
+// latest quantizer on sq[j] of every chunk (earlier records of a stream are implied by its latest one).
+// `who`: index of the waiting stream in seen_* (decode stream k, or KMAX for the noise stream).
+int wait_encode_side(lyra_hip_ctx* c, hipStream_t s, int who) {
+  for (int j = 0; j < c->nsub; ++j) {
+    if (c->seen_se[who][j] != c->seq_se[j]) {
+      HIPCHK(c, hipStreamWaitEvent(s, c->ev_encs[2][j], 0));
+      c->seen_se[who][j] = c->seq_se[j];
+    }
+    if (c->seen_sq[who][j] != c->seq_sq[j]) {
+      HIPCHK(c, hipStreamWaitEvent(s, c->ev_encs[c->sq_slot[j]][j], 0));
+      c->seen_sq[who][j] = c->seq_sq[j];
+    }
+  }
+  return 0;
+}
+// The decoder-side NoiseEstimator of the `_dev` path (lyra_decoder.cc:304-311 feeds it every decoded hop) runs on a
+// stream of its own, behind the decoder's last stage, underneath the next step -- on the decoder's stream it would
+// lengthen the chain that paces the pipeline (round 2: +68 us per step for a 33 us kernel).  What it reads is the
+// decoder's PCM buffer, which by the two-buffer rule is rewritten by the decode-side call after the next one: that
+// call has to be ordered after this kernel.  In the encode+decode pipeline the edge rides on the quantizer stream,
+// which has slack: the quantizer of a `_dev` encode call waits for all noise calls but the most recent one
+// (encq_handoff), and the decoder stages wait for that quantizer anyway; a decode-side call that is not covered that way
+// (decode-only loops, generate_dev) waits itself.  noise_done_dec / cover_sq[] do the bookkeeping.
 int dec_side_begin(lyra_hip_ctx* c, int k) {
-  for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_enc[j], 0));
+  int rc = wait_encode_side(c, c->sd[k], k);
+  if (rc) return rc;
+  const long required = c->n_noise_calls - 1;   // all decoder-side noise calls but the most recent one
+  if (required > c->noise_done_dec) {
+    long covered = 0;
+    for (int j = 0; j < c->nsub; ++j) covered = std::max(covered, c->cover_sq[j]);
+    if (covered < required) {
+      for (int kk = 0; kk < c->nsub; ++kk)
+        HIPCHK(c, hipStreamWaitEvent(c->sd[kk], c->ev_noise[(required - 1) & 1], 0));
+      covered = required;
+    }
+    // (covered through sq: every decode stream has waited for the latest quantizer record of every chunk above)
+    c->noise_done_dec = covered;
+  }
+  return 0;
+}
+int noise_dev_begin(lyra_hip_ctx* c) {   // sn: after the latest decode-side call of every chunk, and rule (1)
+  int rc = wait_encode_side(c, c->sn, lyra_hip_ctx::KMAX);
+  if (rc) return rc;
+  if (c->n_dec_calls >= 1)
+    for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipStreamWaitEvent(c->sn, c->ev_dec[(c->n_dec_calls - 1) & 1][j], 0));
+  return 0;
+}
+int noise_dev_done(lyra_hip_ctx* c) {
+  HIPCHK(c, hipEventRecord(c->ev_noise[c->n_noise_calls & 1], c->sn));
+  c->n_noise_calls++;
   return 0;
 }
 int dec_side_done(lyra_hip_ctx* c, int k, int nk = 0) {
@@ -337,14 +412,14 @@ int chunks_for(const lyra_hip_ctx* c, int B) { return (c->nsub > 1 && B >= 64 * 
 
 // before_s2: an event the LAST stage (the only one that writes d_feat) has to wait for -- the earlier stages run ahead.
 int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_feat,
-                   hipEvent_t before_s2 = nullptr) {
+                   const EventList& before_s2 = EventList()) {
   const Model& M = c->model;
   hipStream_t st_ = c->se[k];
   float* e0 = c->d_e0 + (size_t)lo * 512;
   float* e1 = c->d_e1 + (size_t)lo * 512;
   float* codes = c->d_codes + (size_t)lo * 64;
   if (c->fused & 1) {   // the whole side in one launch (enc_side_kernel.hip)
-    if (before_s2) HIPCHK(c, hipStreamWaitEvent(st_, before_s2, 0));
+    for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
     { ProfScope ps(c, K_ENC_SIDE, st_);
       hipLaunchKernelGGL(c->mode ? enc_side_dr_kernel : enc_side_kernel, dim3(cdiv(B, 8)), dim3(512), enc_side_lds_bytes(), st_,
                          M.d_enc0, M.d_enc1, M.d_enc2, d_pcm, d_ids, B, c->sm.base[st::R_E0], c->sm.base[st::R_E1],
@@ -359,7 +434,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   { ProfScope ps(c, K_ENC_S1, st_);
     hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes(), st_,
                        M.d_enc1, e0, d_ids, B, c->sm.base[st::R_E1], e1, c->cw[K_ENC_S1]); }
-  if (before_s2) HIPCHK(c, hipStreamWaitEvent(st_, before_s2, 0));
+  for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
   { ProfScope ps(c, K_ENC_S2, st_);
     hipLaunchKernelGGL(c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512),
                        enc_s2_lds_bytes(), st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
@@ -421,16 +496,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
   return 0;
 }
 
-int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
-  { ProfScope ps(c, K_LOGMEL, c->sd[0]);
-    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, d_pcm,
-                       d_ids, B, c->sm.base[st::R_MEL], (int)st::MEL_BYTES, (int)st::M_PREV, d_mel); }
-  HIPCHK(c, hipGetLastError());
-  return 0;
-}
-
-// NoiseEstimator::ReceiveSamples for one full hop of B streams (noise_estimator.cc:144-173): the estimator's own log-mel
-// front end, then the decision + recurrence.  side 0 = encoder (DTX) on the encode-side stream, 1 = decoder.
+// NoiseEstimator::Create's constants (noise_estimator.cc:96-124)
 NoiseP noise_params() {
   const float secs_per_hop = 320.f / 16000.f;
   NoiseP p;
@@ -439,17 +505,26 @@ NoiseP noise_params() {
   p.bound_decay = powf(0.5f, secs_per_hop / 1.f);
   return p;
 }
-int launch_noise(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_pcm, int32_t* d_is_noise,
-                 int32_t* d_masked_ids) {
-  hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
+
+int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm, float* d_mel) {
+  { ProfScope ps(c, K_LOGMEL, c->sd[0]);
+    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, d_pcm,
+                       d_ids, B, c->sm.base[st::R_MEL], (int)st::MEL_BYTES, (int)st::M_PREV, d_mel, 0, noise_params(),
+                       (int32_t*)nullptr, (int32_t*)nullptr); }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// NoiseEstimator::ReceiveSamples for one full hop of B streams (noise_estimator.cc:144-173) in ONE launch: the
+// estimator's own log-mel front end with the decision + recurrence as its tail (logmel_kernel, noise_tail = 1).
+// side 0 = encoder (DTX), 1 = decoder; the caller picks the stream.
+int launch_noise(lyra_hip_ctx* c, int side, hipStream_t st_, const int32_t* d_ids, int B, const int16_t* d_pcm,
+                 int32_t* d_is_noise, int32_t* d_masked_ids) {
   uint8_t* region = c->sm.base[side == 0 ? st::R_NOISE_E : st::R_NOISE_D];
-  float* mel = side == 0 ? c->d_mel_enc : c->d_mel;
-  { ProfScope ps(c, K_LOGMEL, st_);
-    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), st_, c->model.d_mel, d_pcm, d_ids,
-                       B, region, (int)st::NOISE_BYTES, (int)st::N_PREV, mel); }
   { ProfScope ps(c, K_NOISE, st_);
-    hipLaunchKernelGGL(noise_update_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st_, noise_params(), d_ids, B, region,
-                       (const float*)mel, d_is_noise, d_masked_ids); }
+    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), st_, c->model.d_mel, d_pcm, d_ids,
+                       B, region, (int)st::NOISE_BYTES, (int)st::N_PREV, (float*)nullptr, 1, noise_params(), d_is_noise,
+                       d_masked_ids); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -560,6 +635,10 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
         hipEventCreateWithFlags(&c->ev_dec[0][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_dec[1][k], evflags) != hipSuccess)
       return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
+  if (hipStreamCreateWithPriority(&c->sn, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_noise[0], evflags) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_noise[1], evflags) != hipSuccess)
+    return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
   {
@@ -612,6 +691,9 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
     if (c->sd[k]) (void)hipStreamDestroy(c->sd[k]);
     if (c->sq[k]) (void)hipStreamDestroy(c->sq[k]);
   }
+  for (hipEvent_t e : c->ev_noise)
+    if (e) (void)hipEventDestroy(e);
+  if (c->sn) (void)hipStreamDestroy(c->sn);
   if (c->d_state) (void)hipFree(c->d_state);
   free_model(&c->model);
   delete c;
@@ -625,6 +707,7 @@ const char* lyra_hip_last_error(const lyra_hip_ctx* c) {
 
 void* lyra_hip_stream(lyra_hip_ctx* c) { return c ? (void*)c->se[0] : nullptr; }
 void* lyra_hip_stream_decode(lyra_hip_ctx* c) { return c ? (void*)c->sd[0] : nullptr; }
+void* lyra_hip_stream_quantizer(lyra_hip_ctx* c) { return c ? (void*)c->sq[0] : nullptr; }
 int lyra_hip_synchronize(lyra_hip_ctx* c) {
   if (!c) return LYRA_HIP_EINVAL;
   return sync_all(c);
@@ -743,12 +826,13 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
     if (n <= 0) continue;
     if ((rc = encq_begin(c, k))) break;
     float* feat = encq_features(c) + (size_t)lo * 64;
-    rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, feat, encq_buffer_free(c, k));
+    rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, feat, encq_buffer_free(c, k, nk));
     if (!rc) rc = encq_handoff(c, k);
     if (!rc) rc = launch_rvq_encode(c, k, n, feat, num_bits / 4, nullptr, d_packets + (size_t)lo * nbytes, nullptr, nullptr,
                                     true);
     if (!rc) rc = encq_done(c, k);
   }
+  c->encq_nk[c->n_encq_calls & 1] = nk;
   c->n_encq_calls++;
   return rc;
 }
@@ -843,6 +927,11 @@ int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, cons
 }
 
 int launch_cng(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_features, int16_t* d_pcm) {
+  // reads the decoder-side noise estimate: after every decoder-side `_dev` noise call (they run on sn)
+  if (!d_features && c->n_noise_calls > c->noise_done_dec) {
+    HIPCHK(c, hipStreamWaitEvent(c->sd[0], c->ev_noise[(c->n_noise_calls - 1) & 1], 0));
+    if (c->nsub == 1) c->noise_done_dec = c->n_noise_calls;
+  }
   { ProfScope ps(c, K_CNG, c->sd[0]);
     hipLaunchKernelGGL(cng_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, c->cng_seed, d_ids, B,
                        c->sm.base[st::R_CNG], (const uint8_t*)c->sm.base[st::R_NOISE_D], d_features, d_pcm); }
@@ -928,14 +1017,13 @@ int lyra_hip_noise_receive_dev(lyra_hip_ctx* c, int side, const int32_t* d_ids, 
   if ((rc = ensure_scratch(c, B))) return rc;
   if (side == 0) {
     if ((rc = enc_side_begin(c, 0))) return rc;
-    rc = launch_noise(c, 0, d_ids, B, d_pcm, d_is_noise, nullptr);
+    rc = launch_noise(c, 0, c->se[0], d_ids, B, d_pcm, d_is_noise, nullptr);
     if (!rc) rc = enc_side_done(c, 0);
     return rc;
   }
-  if ((rc = dec_side_begin(c, 0))) return rc;
-  rc = launch_noise(c, 1, d_ids, B, d_pcm, d_is_noise, nullptr);
-  if (!rc) rc = dec_side_done(c, 0, 1);
-  c->n_dec_calls++;
+  if ((rc = noise_dev_begin(c))) return rc;
+  rc = launch_noise(c, 1, c->sn, d_ids, B, d_pcm, d_is_noise, nullptr);
+  if (!rc) rc = noise_dev_done(c);
   return rc;
 }
 
@@ -954,12 +1042,16 @@ int lyra_hip_encode_dtx_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const 
   // one only, so the mask travels with the features: one buffer per parity)
   float* feat = encq_features(c);
   int32_t* live = (c->n_encq_calls & 1) ? c->d_live_ids2 : c->d_live_ids;
-  if (hipEvent_t e = encq_buffer_free(c, 0)) HIPCHK(c, hipStreamWaitEvent(c->se[0], e, 0));   // `live` travels with the features
-  rc = launch_noise(c, 0, d_ids, B, d_pcm, c->d_flag_enc, live);
+  {   // `live` travels with the features: both were last read by the quantizer(s) of the call before the previous one
+    const EventList busy = encq_buffer_free(c, 0, 1);
+    for (int i = 0; i < busy.n; ++i) HIPCHK(c, hipStreamWaitEvent(c->se[0], busy.e[i], 0));
+  }
+  rc = launch_noise(c, 0, c->se[0], d_ids, B, d_pcm, c->d_flag_enc, live);
   if (!rc) rc = launch_extract(c, 0, 0, live, B, d_pcm, feat);
   if (!rc) rc = encq_handoff(c, 0);
   if (!rc) rc = launch_rvq_encode(c, 0, B, feat, num_bits / 4, nullptr, d_packets, live, d_packet_bytes, true);
   if (!rc) rc = encq_done(c, 0);
+  c->encq_nk[c->n_encq_calls & 1] = 1;
   c->n_encq_calls++;
   return rc;
 }
@@ -974,7 +1066,7 @@ int lyra_hip_noise_receive(lyra_hip_ctx* c, int side, const int32_t* ids, int B,
   int32_t* dflag = side == 0 ? c->d_flag_enc : c->d_flag_dec;
   HIPCHK(c, hipMemcpyAsync(dids, ids, (size_t)B * 4, hipMemcpyHostToDevice, st_));
   HIPCHK(c, hipMemcpyAsync(dpcm, pcm, (size_t)B * 640, hipMemcpyHostToDevice, st_));
-  if ((rc = launch_noise(c, side, dids, B, dpcm, dflag, nullptr))) return rc;
+  if ((rc = launch_noise(c, side, st_, dids, B, dpcm, dflag, nullptr))) return rc;
   HIPCHK(c, hipMemcpyAsync(is_noise, dflag, (size_t)B * 4, hipMemcpyDeviceToHost, st_));
   if (side == 0 && (rc = enc_side_done(c, 0))) return rc;
   HIPCHK(c, hipStreamSynchronize(st_));
@@ -1005,7 +1097,7 @@ int lyra_hip_encode_dtx(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_
   HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se[0]));
   HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se[0]));
   HIPCHK(c, hipMemsetAsync(c->d_pkt, 0, (size_t)B * nbytes, c->se[0]));   // empty packets read back as zeros
-  if ((rc = launch_noise(c, 0, c->d_ids, B, c->d_pcm_in, c->d_flag_enc, c->d_live_ids))) return rc;
+  if ((rc = launch_noise(c, 0, c->se[0], c->d_ids, B, c->d_pcm_in, c->d_flag_enc, c->d_live_ids))) return rc;
   if ((rc = launch_extract(c, 0, 0, c->d_live_ids, B, c->d_pcm_in, c->d_feat))) return rc;
   if ((rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, nullptr, c->d_pkt, c->d_live_ids, c->d_pkt_bytes))) return rc;
   HIPCHK(c, hipMemcpyAsync(packets, c->d_pkt, (size_t)B * nbytes, hipMemcpyDeviceToHost, c->se[0]));
@@ -1027,6 +1119,7 @@ int lyra_hip_wait_for_stream(lyra_hip_ctx* c, void* caller_stream) {
     HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_caller, 0));
     HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_caller, 0));
   }
+  HIPCHK(c, hipStreamWaitEvent(c->sn, c->ev_caller, 0));
   return 0;
 }
 
@@ -1043,6 +1136,8 @@ int lyra_hip_stream_wait(lyra_hip_ctx* c, void* caller_stream) {
     HIPCHK(c, hipEventRecord(c->ev_caller, c->sq[k]));
     HIPCHK(c, hipStreamWaitEvent((hipStream_t)caller_stream, c->ev_caller, 0));
   }
+  HIPCHK(c, hipEventRecord(c->ev_caller, c->sn));
+  HIPCHK(c, hipStreamWaitEvent((hipStream_t)caller_stream, c->ev_caller, 0));
   return 0;
 }
 
@@ -1152,6 +1247,64 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
   if ((rc = launch_generate(c, 0, 0, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
   HIPCHK(c, hipMemcpyAsync(pcm, c->d_pcm_out, (size_t)B * 640, hipMemcpyDeviceToHost, c->sd[0]));
   HIPCHK(c, hipStreamSynchronize(c->sd[0]));
+  return 0;
+}
+
+// ---- many steps from one call ---------------------------------------------------------------------------------------
+// What lyra_benchmark's loop does per hop (lyra_benchmark_lib.cc:121-160) and what LyraEncoder::Encode /
+// LyraDecoder::DecodeSamples do around it (lyra_encoder.cc:113-156, lyra_decoder.cc:284-326), for n_steps hops of B
+// streams, enqueued by one call: no host language in the loop.
+int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
+  if (!c || !S) return LYRA_HIP_EINVAL;
+  int rc = check_batch(c, S->B);
+  if (rc) return rc;
+  const unsigned F = S->flags;
+  const bool enc = F & LYRA_HIP_STEP_ENCODE, dec = F & LYRA_HIP_STEP_DECODE, feats = S->d_features != nullptr;
+  if (!enc && !dec) return fail(c, LYRA_HIP_EINVAL, "run_steps: neither ENCODE nor DECODE requested");
+  if ((enc || (dec && !feats)) && (rc = check_bits(c, S->num_bits))) return rc;
+  if (!S->d_stream_ids || S->n_steps < 0 || S->first_step < 0) return fail(c, LYRA_HIP_EINVAL, "run_steps: bad argument");
+  if (enc && (!S->d_pcm_ring || S->ring <= 0)) return fail(c, LYRA_HIP_EINVAL, "run_steps: ENCODE needs d_pcm_ring / ring");
+  if ((enc || (dec && !feats)) && (!S->d_packets[0] || !S->d_packets[1]))
+    return fail(c, LYRA_HIP_EINVAL, "run_steps: two packet buffers needed");
+  if (dec && (!S->d_pcm_out[0] || !S->d_pcm_out[1])) return fail(c, LYRA_HIP_EINVAL, "run_steps: two PCM output buffers needed");
+  if ((F & LYRA_HIP_STEP_DTX) && (!S->d_packet_bytes[0] || !S->d_packet_bytes[1]))
+    return fail(c, LYRA_HIP_EINVAL, "run_steps: DTX needs two packet_bytes buffers");
+  if ((F & LYRA_HIP_STEP_DECODER_NOISE) && (!dec || !S->d_is_noise))
+    return fail(c, LYRA_HIP_EINVAL, "run_steps: DECODER_NOISE needs DECODE and d_is_noise");
+  const int ext = S->external_rate ? S->external_rate : 16000;
+  const bool rs = ext != 16000;
+  const int n_ext = 320 * (ext / 1000) / 16;   // samples per 20 ms hop at the external rate
+  if (rs) {
+    if (ext != 8000 && ext != 32000 && ext != 48000) return fail(c, LYRA_HIP_EINVAL, "run_steps: external_rate %d", ext);
+    if (dec && (!S->d_ext_out[0] || !S->d_ext_out[1])) return fail(c, LYRA_HIP_EINVAL, "run_steps: two external-rate output buffers needed");
+    if ((rc = ensure_scratch(c, S->B))) return rc;
+  }
+  const size_t B = (size_t)S->B;
+  for (int i = 0; i < S->n_steps; ++i) {
+    const long step = S->first_step + i;
+    const int set = (int)(step & 1);
+    if (enc) {
+      const int16_t* in = S->d_pcm_ring + (size_t)(step % S->ring) * B * (size_t)n_ext;
+      if (rs) {   // lyra_encoder.cc:119-122: external rate -> 16 kHz, the encoder's own resampler
+        if ((rc = lyra_hip_resample_dev(c, LYRA_HIP_SIDE_ENCODER, S->d_stream_ids, S->B, in, n_ext, ext, 16000, c->d_pcm_in))) return rc;
+        in = c->d_pcm_in;
+      }
+      if (F & LYRA_HIP_STEP_DTX)
+        rc = lyra_hip_encode_dtx_dev(c, S->d_stream_ids, S->B, in, S->num_bits, S->d_packets[set], S->d_packet_bytes[set]);
+      else
+        rc = lyra_hip_encode_dev(c, S->d_stream_ids, S->B, in, S->num_bits, S->d_packets[set]);
+      if (rc) return rc;
+    }
+    if (dec) {
+      if (feats) rc = lyra_hip_generate_dev(c, S->d_stream_ids, S->B, S->d_features, S->d_pcm_out[set]);
+      else rc = lyra_hip_decode_dev(c, S->d_stream_ids, S->B, S->d_packets[set], S->num_bits, S->d_pcm_out[set]);
+      if (rc) return rc;
+      if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
+        if ((rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise))) return rc;
+      if (rs)     // lyra_decoder.cc:107-113 / buffered_resampler.cc: 16 kHz -> external rate
+        if ((rc = lyra_hip_resample_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set]))) return rc;
+    }
+  }
   return 0;
 }
 

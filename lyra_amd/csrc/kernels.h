@@ -94,10 +94,12 @@ struct MelP { const double* hann; const double* tw_re; const double* tw_im; cons
               const double* wsum;   // [160] total forward weight of every mel band (comfort-noise inverse mel)
               const double* tw4_re; const double* tw4_im;   // [768] W_1024^j, radix-4 log-mel FFT
               int start, end; };
-__global__ void logmel_kernel(const MelP* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, int stride,
-                              int prev_off, float* mel);
 // NoiseEstimator::Create's constants (noise_estimator.cc:96-124): round(1 s / 20 ms), 0.5^(20 ms / 0.7 s), 0.5^(20 ms / 1 s)
 struct NoiseP { int hops_per_update; float max_smoothing, bound_decay; };
+// noise_tail: continue with the NoiseEstimator update of the same hop (state must then be a NoiseEstimator region)
+__global__ void logmel_kernel(const MelP* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, int stride,
+                              int prev_off, float* mel, int noise_tail, NoiseP NP, int32_t* is_noise_out,
+                              int32_t* masked_ids);
 __global__ void noise_update_kernel(NoiseP P, const int32_t* ids, int B, uint8_t* state, const float* mel,
                                     int32_t* is_noise_out, int32_t* masked_ids);
 // Resampler (lyra/resampler.cc): out/in = up/down, coef[phase][tap] oldest tap first (oracle lo_resampler_design)

@@ -217,6 +217,11 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const float* __restrict
 // `state` / `stride` / `prev_off`: where the previous hop of each stream lives -- the plugin-level extractor's own
 // region (R_MEL) or the slot of one of the two NoiseEstimators (R_NOISE_E / R_NOISE_D own their extractor).
 // =============================================================================================
+// NoiseEstimator::ReceiveSamples' decision + recurrence for one stream per wavefront (defined below, next to its notes)
+template <int NW>
+__device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool on, int id, int out_index, uint8_t* state,
+                                                  const float* mel, int32_t* is_noise_out, int32_t* masked_ids);
+
 size_t logmel_lds_bytes() { return (size_t)(1024 * 2 + 160) * 8; }   // (+160: the comfort-noise kernel's mel vector)
 
 __device__ __forceinline__ int digit_reverse4_1024(int n) {   // reverse the five base-4 digits of n
@@ -224,16 +229,22 @@ __device__ __forceinline__ int digit_reverse4_1024(int n) {   // reverse the fiv
   return (int)(((r & 0x2AAu) >> 1) | ((r & 0x155u) << 1));
 }
 
+// noise_tail != 0: `state` is a NoiseEstimator region and the kernel goes on with NoiseEstimator::ReceiveSamples' second
+// half (noise_update_wave; wavefront f handles frame f) on the mel vector while it is still in LDS -- one launch and no
+// trip of the 160 bins through HBM (`mel` may then be null).
 __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, int stride, int prev_off,
-                                                      float* __restrict__ mel) {
+                                                      float* __restrict__ mel, int noise_tail, NoiseP NP,
+                                                      int32_t* __restrict__ is_noise_out,
+                                                      int32_t* __restrict__ masked_ids) {
   const MelP& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* re = dsm;
   double* im = dsm + 1024;
   double* mag0 = re;                  // |X_A[k]|, k = 0..512, written in place over Z (see below)
   double* mag1 = im;                  // |X_B[k]|
+  float* mel_lds = reinterpret_cast<float*>(dsm + 2048);   // [2][160] floats in the 160 spare doubles (noise tail)
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * 2, b1 = b0 + 1;
   const bool two = b1 < B;
@@ -325,8 +336,17 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
       float v = (float)acc;
       v = v > 500.f ? v : 500.f;
       // log evaluated in double and rounded once: identical on host and device (oracle/lyra_oracle.c log_f)
-      mel[(size_t)(b0 + f) * 160 + tid] = (float)log((double)v) / 10.f;
+      const float lm = (float)log((double)v) / 10.f;
+      if (mel) mel[(size_t)(b0 + f) * 160 + tid] = lm;
+      if (noise_tail) mel_lds[f * 160 + tid] = lm;
     }
+  }
+  if (noise_tail) {   // (uniform)
+    __syncthreads();
+    const int w = tid >> 6;
+    const bool on = w == 0 || (w == 1 && two);
+    noise_update_wave<2>(NP, w, on, ids[(w == 1 && two) ? b1 : b0], b0 + (w & 1), state, mel_lds + (w & 1) * 160,
+                         is_noise_out, masked_ids);
   }
 }
 
@@ -341,16 +361,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
 // =============================================================================================
 __device__ __forceinline__ float expf_via_double(float x) { return (float)exp((double)x); }
 
-__global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32_t* __restrict__ ids, int B,
-                                                            uint8_t* __restrict__ state, const float* __restrict__ mel,
-                                                            int32_t* __restrict__ is_noise_out,
-                                                            int32_t* __restrict__ masked_ids) {
-  __shared__ float sh[4][2][160];
-  __shared__ float avg[4][2];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + w;
-  const bool on = b < B;
-  const int id = ids[on ? b : B - 1];
+// One wavefront = one stream (slot w of the workgroup, NW slots); every thread of the workgroup calls this (two
+// workgroup barriers inside).  `mel`: the hop's 160 log-mel bins (LDS or global); `on`: the slot holds a real stream.
+template <int NW>
+__device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool on, int id, int out_index, uint8_t* state,
+                                                  const float* mel, int32_t* is_noise_out, int32_t* masked_ids) {
+  __shared__ float sh[NW][2][160];
+  __shared__ float avg[NW][2];
+  const int lane = threadIdx.x & 63;
+  const bool mine = w < NW;          // waves beyond the NW slots only take part in the barriers
+  const int ws = mine ? w : 0;
   uint8_t* base = state + (size_t)id * st::NOISE_BYTES;
   int* hdr = reinterpret_cast<int*>(base);
   float* f_smooth = reinterpret_cast<float*>(base + st::N_SMOOTH);
@@ -364,8 +384,8 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32
   for (int i = 0; i < 3; ++i) {
     const int bin = lane + 64 * i;
     cur[i] = est[i] = bound[i] = 0.f;
-    if (bin < 160) {
-      cur[i] = mel[(size_t)(on ? b : B - 1) * 160 + bin];
+    if (bin < 160 && mine) {
+      cur[i] = mel[bin];
       est[i] = f_est[bin];
       bound[i] = f_bound[bin];
       differs = differs || (__builtin_fabsf(cur[i] - est[i]) > bound[i]);
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32
   const int initialised = hdr[st::N_INIT / 4];
   const int hops = hdr[st::N_HOPS / 4];
   float sm[3], sq[3], tm[3];
-  if (!is_noise) {
+  if (!is_noise && mine) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int bin = lane + 64 * i;
@@ -383,19 +403,19 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32
       if (bin < 160) {
         if (initialised) { sm[i] = f_smooth[bin]; sq[i] = f_sq[bin]; tm[i] = f_tmp[bin]; }
         else { sm[i] = cur[i]; sq[i] = cur[i] * cur[i]; tm[i] = cur[i]; }   // first update (noise_estimator.cc:180-186)
-        sh[w][0][bin] = sm[i];
-        sh[w][1][bin] = cur[i];
+        sh[ws][0][bin] = sm[i];
+        sh[ws][1][bin] = cur[i];
       }
     }
   }
   __syncthreads();
-  if (!is_noise && lane < 2) {   // Average(): sequential float sum from 0.f, then / 160
+  if (!is_noise && mine && lane < 2) {   // Average(): sequential float sum from 0.f, then / 160
     float a = 0.f;
-    for (int i = 0; i < 160; ++i) a = a + sh[w][lane][i];
-    avg[w][lane] = a / 160.f;
+    for (int i = 0; i < 160; ++i) a = a + sh[ws][lane][i];
+    avg[ws][lane] = a / 160.f;
   }
   __syncthreads();
-  if (!on) return;
+  if (!on || !mine) return;
   if (is_noise) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -404,7 +424,7 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32
     }
   } else {
     const float kPowDiff = 0.3f;
-    const float dd = (avg[w][0] - avg[w][1]) / kPowDiff;
+    const float dd = (avg[ws][0] - avg[ws][1]) / kPowDiff;
     const float correction = expf_via_double(-(dd * dd));
     const double logn = 5.075173815233827;   // std::log(160) in double (noise_bound_.size())
 #pragma unroll
@@ -432,9 +452,21 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32
       hdr[st::N_HOPS / 4] = (hops + 1) % P.hops_per_update;
     }
     hdr[st::N_IS_NOISE / 4] = is_noise ? 1 : 0;
-    if (is_noise_out) is_noise_out[b] = is_noise ? 1 : 0;
-    if (masked_ids) masked_ids[b] = is_noise ? -1 : id;
+    if (is_noise_out) is_noise_out[out_index] = is_noise ? 1 : 0;
+    if (masked_ids) masked_ids[out_index] = is_noise ? -1 : id;
   }
+}
+
+// Stand-alone form (mel computed elsewhere): four streams per workgroup.
+__global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32_t* __restrict__ ids, int B,
+                                                            uint8_t* __restrict__ state, const float* __restrict__ mel,
+                                                            int32_t* __restrict__ is_noise_out,
+                                                            int32_t* __restrict__ masked_ids) {
+  const int w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + w;
+  const bool on = b < B;
+  const int bb = on ? b : B - 1;
+  noise_update_wave<4>(P, w, on, ids[bb], b, state, mel + (size_t)bb * 160, is_noise_out, masked_ids);
 }
 
 // noise_estimate() / noise_bound() of B streams -> dense [B][160] (NoiseEstimator::noise_estimate, :229-231)
@@ -479,7 +511,9 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleP P, const int32_
   }
   __syncthreads();
   for (int i = tid; i < H; i += 256) hist[i] = rsb[n_in + i];
-  if (tid == 0) *reinterpret_cast<int*>(slot + st::RS_IN_POS) = (in_pos + n_in) % (1 << 20);   // (multiple of every `down`)
+  // only the decimation phase is ever used: kept modulo 6 = lcm of the possible `down` factors (1, 2, 3), so the
+  // counter never wraps out of phase however long the stream runs (the oracle keeps an unbounded counter)
+  if (tid == 0) *reinterpret_cast<int*>(slot + st::RS_IN_POS) = (in_pos + n_in) % 6;
 }
 
 // =============================================================================================

@@ -8,7 +8,6 @@ line = [l for l in out.stdout.splitlines() if l.startswith("{")]
 if not line:
     print(out.stdout[-2000:], out.stderr[-3000:]); sys.exit(1)
 r = json.loads(line[-1])
-print("frames/s", r["value"], "ms/step", r["ms_per_step"], "roof", r["roofline"]["kernel"], r["roofline"]["frac"],
-      "path_frac", r["path_frac_of_f32_mfma_peak"])
+print("frames/s", r["value"], "ms/step", r["ms_per_step"], "frac", r["roofline"]["frac"], "serial_sum_us", r.get("serial_sum_us"))
 print("  ".join(f"{k.replace('_kernel','')}={v['avg_us']}" for k, v in r["kernels"].items()),
       " sum=", round(sum(v["avg_us"] for v in r["kernels"].values()), 1))
