@@ -71,22 +71,24 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   const int b0 = blockIdx.x * SD0;
   constexpr int mode = MODE;
   wg_schedule_hint();
-  LYRA_TSTAMP(40);
-  LYRA_WSTAMP(100);
+  LYRA_TSTAMP(80);
+  LYRA_WSTAMP(120);
   LYRA_WG_BEGIN();
   if (tid < SD0) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
     sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::D0_BYTES + st::PHASE);
   }
-  // The packet bytes of this thread's stream (wave = stream) depend on nothing but the batch position: requested in the
-  // same round trip as the ids / ring phases, not after the barrier that publishes those.
-  int pkb[23];
+  // The packet bytes of this wave's stream (wave = stream, lane = feature channel) depend on nothing but the batch
+  // position: requested in the same round trip as the ids / ring phases, not after the barrier that publishes those.
+  // Lane i holds byte i; every later use is a v_readlane into an SGPR, so nibble extraction and the codebook row
+  // address are scalar work and each of the 46 gathers is one global_load (scalar base + lane offset) and one fma.
+  int pkv = 0;
+  const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (!feats) {
     const int nbytes = (num_stages + 1) >> 1;
-    const uint8_t* pk = packets + (size_t)min(b0 + (tid >> 6), B - 1) * nbytes;
-#pragma unroll
-    for (int i = 0; i < 23; ++i) pkb[i] = i < nbytes ? (int)pk[i] : 0;
+    const uint8_t* pk = packets + (size_t)min(b0 + swave, B - 1) * nbytes;
+    if (lane < nbytes) pkv = (int)pk[lane];
   }
   load_luts<NTD0>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NTD0, 1>(P.warm);
@@ -107,13 +109,17 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       f = feats[(size_t)b * 64 + c];
     } else {
       f = 0.f;
+      // buffer addressing: resource = the codebook, voffset = this lane's channel, soffset = the row (scalar)
+      const __amdgpu_buffer_rsrc_t cbr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cb), 0, 46 * 16 * 64 * 4, 0x00020000);
 #pragma unroll
       for (int k = 0; k < 46; ++k) {   // addresses depend only on the packet: all 46 codebook loads in flight at once
-        const int id = k < num_stages ? ((pkb[k >> 1] >> ((k & 1) ? 0 : 4)) & 15) : -1;
-        const float mask = id != -1 ? 1.f : 0.f;
-        const int i = id < 0 ? 0 : id;
-        const float v = cb[((size_t)k * 16 + i) * 64 + c] * mask;
-        f = k == 0 ? v : f + v;
+        const int byte = __builtin_amdgcn_readlane(pkv, k >> 1);
+        const int used = (k - num_stages) >> 31;                       // all ones / zero, wave-uniform
+        const int i = (byte >> ((k & 1) ? 0 : 4)) & 15 & used;
+        const float mask = __builtin_bit_cast(float, used & 0x3f800000);   // 1.0f / 0.0f, kept in an SGPR
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cbr, c * 4, (k * 16 + i) * 256, 0));
+        // v * mask is exact (v or a signed zero), so fma(v, mask, f) rounds once, exactly like (v * mask) + f
+        f = k == 0 ? v * mask : __builtin_fmaf(v, mask, f);
       }
     }
     FB[(2 * 16 + s) * FS + at16(c)] = f;
@@ -132,7 +138,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       *reinterpret_cast<f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4) =
           *reinterpret_cast<const f32x4*>(&FB[(2 * 16 + s) * FS + p4 * 4]);
   }
-  LYRA_TSTAMP(41);
+  LYRA_TSTAMP(81);
   {  // conv k3 g4: per group [16 rows] x K=48 x N=128; LeakyReLU; QUANTIZE -> H8
     f32x4 acc[1][4];
     const int g = wave >> 1;
@@ -145,11 +151,11 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       float bias = as_global(P.head.b)[n];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        H8[((q & 1) * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0.s, P.q0.z);
+        H8[((q & 1) * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0);
     }
   }
   __syncthreads();
-  LYRA_TSTAMP(42);
+  LYRA_TSTAMP(82);
   {  // 4 grouped int8 transposed convs k4/s2 (one input row -> 4 output rows), carried tail of 2 rows
     i32x4 acc[1][8];
     const int g = wave >> 1;
@@ -195,7 +201,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     }
   }
   __syncthreads();
-  LYRA_TSTAMP(43);
+  LYRA_TSTAMP(83);
   // ---- a0 = QUANTIZE(lrelu(x164)); resblock 0 (int8 body, float skip) depthwise, dilation 1 --------------
   // Thread (s, w4) owns channels 4*w4 .. 4*w4+3 of stream s for both rows: quantize -> depthwise over
   // [a(t-2), a(t-1), a(t)] -> history (2 rows, replaced) stay in registers; no LDS round trip, one barrier.
@@ -217,7 +223,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       int c8[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        c8[e] = quantize_f(lrelu(XF[(t * SD0 + s) * CS2 + at16(w4 * 4 + e)]), P.q1.s, P.q1.z);
+        c8[e] = quantize_f(lrelu(XF[(t * SD0 + s) * CS2 + at16(w4 * 4 + e)]), P.q1);
       a[t] = pack8(c8[0], c8[1], c8[2], c8[3]);
     }
     const int x[2][3] = {{h0, h1, a[0]}, {h1, a[0], a[1]}};
@@ -235,7 +241,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       if (cx.valid(s)) *reinterpret_cast<int*>(hp + t * 256) = a[t];
     }
     __syncthreads();
-    LYRA_TSTAMP(44);
+    LYRA_TSTAMP(84);
     {
       i32x4 acc[MTD0][2];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
@@ -270,20 +276,20 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
           for (int e = 0; e < 4; ++e) {
             int row = i * 16 + q * 4 + e;
             int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.cvq[0].zout);
-            float v = dequantize_f(c8, P.dq_r0.s, P.dq_r0.z) + XF[row * CS2 + pc];
-            QX[row * QS + n] = (int8_t)quantize_f(v, P.q3.s, P.q3.z);
+            float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + pc];
+            QX[row * QS + n] = (int8_t)quantize_f(v, P.q3);
           }
       }
     }
     __syncthreads();
   }
-  LYRA_TSTAMP(45);
+  LYRA_TSTAMP(85);
   const RbqPre pre2 = resblock_q_prefetch<SD0>(cx, 9, st::D_R0_2, P.dwq[2], P.pwq[2], P.cvq[2]);
   resblock_q256<SD0>(QX, QD, QP, cx, 3, st::D_R0_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[1], P.pwq[1], P.cvq[1],
-                     P.add[0], LA, mode, pre1, 20);
+                     P.add[0], LA, mode, pre1, 90);
   resblock_q256<SD0>(QX, QD, QP, cx, 9, st::D_R0_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[2], P.pwq[2], P.cvq[2],
-                     P.add[1], LA + 512, mode, pre2, 30);
-  LYRA_TSTAMP(46);
+                     P.add[1], LA + 512, mode, pre2, 94);
+  LYRA_TSTAMP(86);
   // a = int8 LeakyReLU(X3), laid out for the up1 GEMM as [t][16 rows][QS] (rows s >= S are padding)
   for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
     int w4 = idx & 63, s = (idx >> 6) & (SD0 - 1), t = (idx >> 6) / SD0;
@@ -292,7 +298,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
         lut8w(LQ + 5 * 256, w);
   }
   __syncthreads();
-  LYRA_TSTAMP(47);
+  LYRA_TSTAMP(87);
   {  // 2 grouped int8 transposed convs k4/s2: rows t=0,1 -> 6 output rows (integer overlap-add), tail of 2
     i32x4 acc[2][4];
     const int g = wave >> 2, ct = wave & 3;
@@ -336,8 +342,8 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       }
     }
   }
-  LYRA_TSTAMP(48);
-  LYRA_WSTAMP(101);
+  LYRA_TSTAMP(88);
+  LYRA_WSTAMP(121);
   LYRA_WG_END();
   if (tid < SD0 && cx.valid(tid)) {   // this region's ring phase
     int ph = sphase[tid] + 1;

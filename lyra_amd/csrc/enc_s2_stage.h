@@ -118,7 +118,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
       for (int i = 0; i < MT2; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          int q8 = quantize_f(acc[i][j][e] + bias, P.q_r0.s, P.q_r0.z);
+          int q8 = quantize_f(acc[i][j][e] + bias, P.q_r0);
           QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lut8(LQ, q8);
         }
     }
@@ -141,8 +141,8 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
         for (int e = 0; e < 4; ++e) {
           int row = i * 16 + q * 4 + e;
           int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.r0b.zout);
-          float v = dequantize_f(c8, P.dq_r0.s, P.dq_r0.z) + XF[row * CS2 + pc];
-          QX[row * QS + n] = (int8_t)quantize_f(v, P.q_x1.s, P.q_x1.z);
+          float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + pc];
+          QX[row * QS + n] = (int8_t)quantize_f(v, P.q_x1);
         }
     }
   }
@@ -223,7 +223,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
       int s = q * 4 + e;
       int c8 = clamp8(requant(acc[0][0][e] + bias, M, sh, mode) + P.bott.zout);
       if (s < S2 && cx.valid(s)) {
-        feats[(size_t)(b0 + s) * 64 + n] = dequantize_f(c8, P.out.s, P.out.z);
+        feats[(size_t)(b0 + s) * 64 + n] = dequantize_f(c8, P.out);
         if (codes_dbg) codes_dbg[(size_t)(b0 + s) * 64 + n] = (float)c8;
       }
     }

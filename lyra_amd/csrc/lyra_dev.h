@@ -96,14 +96,25 @@ __device__ __forceinline__ int32_t requant(int32_t acc, int32_t M, int shift, in
 }
 __device__ __forceinline__ int32_t clamp8(int32_t v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
 
-// TFLite AffineQuantize: round-half-away(x / s) + z, clamped.  IEEE division (the build passes
-// -fhip-fp32-correctly-rounded-divide-sqrt) so this is bitwise the oracle's quantize_f.
-__device__ __forceinline__ int32_t quantize_f(float x, float s, int32_t z) {
-  float r = __builtin_roundf(x / s);
-  return clamp8((int32_t)r + z);
+// TFLite AffineQuantize: round-half-away(x / s) + z, clamped -- bitwise the oracle's quantize_f (roundf(x / s) with an
+// IEEE division), WITHOUT the division: an IEEE fp32 division is a ~14-instruction sequence on this ISA and the int8
+// stages quantize 24 (dec_s0) / 16 (enc_s2) activations per thread, 14 % / 16 % of all their VALU work.  With
+// rs = RN(1 / s) from the host (QP::rs), q1 = RN(x * rs) is within one ulp of x / s, the remainder x - q1 * s is exact
+// in one fma, and RN(q1 + rem * rs) is the correctly rounded quotient (Markstein's correction step).  x is first
+// clamped to +-lim = +-512 * s: beyond that the result is the clamp either way, and no intermediate can overflow.
+// Proved, not assumed: oracle/quantize_proof.c runs this sequence against roundf(x / s) over ALL 2^32 float inputs for
+// every scale the two graphs quantize with (tests/test_quantize_division_free.py).
+struct QP { float s; int32_t z; float rs, lim; };
+__device__ __forceinline__ int32_t quantize_f(float x, const QP& Q) {
+  x = __builtin_fminf(__builtin_fmaxf(x, -Q.lim), Q.lim);
+  const float q1 = x * Q.rs;
+  const float rem = __builtin_fmaf(-q1, Q.s, x);
+  const float q = __builtin_fmaf(rem, Q.rs, q1);
+  return clamp8((int32_t)__builtin_roundf(q) + Q.z);
 }
 // float(double(s) * (q - z)) == s * float(q - z) in fp32 (24-bit x 9-bit product is exact before the one rounding)
 __device__ __forceinline__ float dequantize_f(int32_t q, float s, int32_t z) { return s * (float)(q - z); }
+__device__ __forceinline__ float dequantize_f(int32_t q, const QP& Q) { return dequantize_f(q, Q.s, Q.z); }
 
 struct LreluQ { int32_t zin, zout, mpos, spos, mneg, sneg; };
 struct AddQ { int32_t z1, z2, zo, m1, s1, m2, s2, mo, so; };
@@ -280,7 +291,6 @@ struct ConvQ { const i32x4* w; const int32_t* b; const int32_t* M; const int32_t
 //   b already holds bias - zin * sum_k(w): the GEMM runs on raw int8 codes
 //   DwQ::b likewise holds bias - zin * sum_j(w[j][c])
 struct DwQ { const int8_t* w; const int32_t* b; const int32_t* M; const int32_t* sh; int32_t zin, zout; };
-struct QP { float s; int32_t z; };
 
 // ---------------------------------------------------------------------------------------------
 // L2 / TLB warm-up.  Kernel boundaries invalidate the XCD L2s, so every kernel starts with its weights cold

@@ -382,8 +382,10 @@ struct Builder {
   }
   QP qp(const char* pre, const char* kind, int idx) {
     const float* q = pk.f32(key(pre, kind, idx, "q"), {2});
-    QP r{1.f, 0};
+    QP r{1.f, 0, 1.f, 512.f};
     if (q) { r.s = q[0]; r.z = (int)q[1]; }
+    r.rs = 1.f / r.s;        // correctly rounded reciprocal: what quantize_f's division-free sequence is proved for
+    r.lim = 512.f * r.s;
     return r;
   }
 };

@@ -13,13 +13,13 @@ buf = (ctypes.c_longlong * 128)()
 ctx.L.lyra_hip_debug_timing_d0(buf)
 t = np.array(buf[:])
 names = ["", "ids+luts+feat window", "head conv+q", "up0 tconv", "a0 quantize", "resblock0", "resblock1+2", "lrelu", "up1 tconv+out"]
-print("dec_s0 total", t[48] - t[40])
-for i in range(41, 49):
-    print(f"  {names[i-40]:22s} {t[i] - t[i-1]:7d}")
-for base in (20, 30):
+print("dec_s0 total", t[88] - t[80])
+for i in range(81, 89):
+    print(f"  {names[i-80]:22s} {t[i] - t[i-1]:7d}")
+for base in (90, 94):
     print("  resblock@", base, " lrelu+dw+state", t[base+1]-t[base], " pw gemm+epi", t[base+2]-t[base+1], " cv gemm+add", t[base+3]-t[base+2])
-wall = (t[101] - t[100]) / 100.0
-print(f"  WG0 wall {wall:.1f} us  -> shader clock {(t[48]-t[40])/wall/1e3:.2f} GHz")
+wall = (t[121] - t[120]) / 100.0
+print(f"  WG0 wall {wall:.1f} us  -> shader clock {(t[88]-t[80])/wall/1e3:.2f} GHz")
 idx = [i for i in range(128) if t[i] != 0 and i < 100]
 idx.sort(key=lambda i: t[i])
 print("  stamps in time order (id:+delta):", " ".join(f"{i}:+{t[i]-t[idx[max(0,k-1)]]}" for k, i in enumerate(idx)))
