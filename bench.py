@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X-native Lyra encode/decode hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--with-logmel]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--full-decoder] [--dtx] [--rate HZ]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -20,9 +20,23 @@ from step to step -- frames of a stream are NOT independent):
         (strong scaling: N = 1 runs all 32768 streams on one GPU).  Same as --total-streams 32768 --bits 120.
   --streams / --bits / --total-streams override the above.
 
+Legs around the bare codec step (what LyraEncoder::Encode / LyraDecoder::DecodeSamples run per hop, SURVEY.md 8f):
+  --full-decoder   NoiseEstimator::ReceiveSamples (log-mel + recurrence, one kernel on a stream of its own) on every
+                   decoded hop (lyra_decoder.cc:304-311)
+  --dtx            encode with enable_dtx: encoder-side noise estimator, masked stream ids, empty packets
+                   (lyra_encoder.cc:131-156)
+  --rate HZ        8000 / 32000 / 48000: the encoder's and the decoder's resampler around the codec
+                   (lyra_encoder.cc:119-122, lyra_decoder.cc:107-113); the PCM ring and the output are at HZ
+  --with-logmel    (round-2 leg) the plain log-mel extractor behind every decoded hop, driven call by call from Python
+
+The timed region is ONE C call per rank (lyra_hip_run_steps_dev: K hops enqueued by the library, no host language in
+the loop); --per-call drives the individual `_dev` entry points from Python instead (the round-2 harness).
+
 Streams are sharded across GPUs with no data-path collective; the only collectives are the timing barrier and the
 max / sum reductions of the result (plus, with --bcast-weights, one RCCL broadcast of the packed weights at init).
-Launched WITHOUT torch.distributed but with --gpus N > 1, one process drives N contexts from N threads.
+`python bench.py --gpus N` (N > 1) without a launcher re-executes itself under torch.distributed.run with N ranks, one
+per GPU, RCCL process group; --single-process keeps everything in one process (one host thread and one context per GPU,
+no process group) for boxes where spawning is not possible.
 
 One JSON line on rank 0:
   * `value` = whole-job frames/s with inputs resident in HBM;
@@ -33,11 +47,16 @@ One JSON line on rank 0:
     its own binding bound computed from the bytes it actually moves (lyra_amd/csrc/state_layout.h);
   * `dominant_kernel` = the kernel with the largest serialised duration, bracketed by HIP events inside the timed
     region (i.e. under the two-stream overlap the step really runs with);
+  * `step_latency_us` = distribution of ONE isolated step (enqueue -> all outputs complete, nothing else in flight):
+    min / mean / p50 / p99 / max / stddev over --latency-steps steps (lyra_benchmark_lib.cc:164-182 prints the same
+    statistics per stage; a 20 ms-deadline codec cares about the tail, not the mean);
   * `cpu_baseline` = the CPU oracle (a port, not the TFLite binary) on this box's host cores, bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -81,14 +100,24 @@ KERNEL_WORK = {
                           ref_bytes=4 * 128 * 4 + 2 * (26 * 128 + 5 * 64) * 4 + 20 * 64 * 4),
     "dec_s2_kernel": dict(f32=584960, i8=0, moved=5120 + 2 * (26 * 64) * 4 + 2 * 48 * 4 + 640 + 8,
                           ref_bytes=20 * 64 * 4 + 2 * (26 * 64 + 48) * 4 + 640),
+    # fp64 per frame: half of a complex radix-4 FFT-1024 (5 passes x 256 butterflies x 34 flops, two real frames per
+    # transform), the split by conjugate symmetry + |X| (513 bins x ~8), the sparse mel weights (2 x 1026 MAC)
     "logmel_kernel": dict(f32=0, i8=0, moved=640 + 640 + 640 + 640, ref_bytes=640 + 2 * 640 + 640,
-                          flops64=10 * 512 * 10 + 513 * 5 + 1024 * 3),   # fp64: radix-2 FFT-1024 + |X| + mel
+                          flops64=5 * 256 * 34 // 2 + 513 * 8 + 2 * 2 * 1026),
+    # NoiseEstimator::ReceiveSamples in one launch: the log-mel front end + the recurrence over 5 x 160 floats of state
+    "logmel_noise_kernel": dict(f32=0, i8=0, moved=640 + 640 + 640 + 2 * 5 * 640 + 16, ref_bytes=640 + 2 * 640 + 2 * 5 * 640,
+                                flops64=5 * 256 * 34 // 2 + 513 * 8 + 2 * 2 * 1026, flops=160 * 30),
+    # polyphase FIR: 48 kHz <-> 16 kHz, 960 + 320 samples of int16 in/out + the tap history; ~24 taps per output
+    "resample_kernel": dict(f32=0, i8=0, moved=(960 + 320) * 2 + 2 * 256, ref_bytes=(960 + 320) * 2 + 2 * 256, flops=2 * 24 * 640),
 }
 ENCODE_KERNELS = ("enc_s0_kernel", "enc_s1_kernel", "enc_s2_kernel", "rvq_encode_kernel")
 DECODE_KERNELS = ("dec_s0_kernel", "dec_s1_kernel", "dec_s2_kernel")
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_I8_MFMA_TOPS = 3944.0      # same guide: v_mfma_i32_16x16x64_i8, dense
-PEAK_F32_VALU_TFLOPS = 157.3    # same guide: FP32 vector
+PEAK_F32_VALU_TFLOPS = 157.3    # same guide: FP32 vector, counted as FMA (2 flops per lane-instruction)
+PEAK_F32_VALU_TOPS = 78.65      # the same issue rate for non-FMA vector work (sub / mul / add, one flop each): what the
+                                # quantizer's distance search consists of (profiles/r03_valu_probe.txt: v_pk_*_f32 do
+                                # not double it on this part)
 PEAK_F64_VALU_TFLOPS = 78.6     # CDNA4 FP64 vector (half the fp32 rate)
 PEAK_HBM_GBS = 8000.0
 
@@ -103,7 +132,17 @@ def parse(argv=None):
     ap.add_argument("--total-streams", type=int, default=None, help="streams in the whole job (strong scaling)")
     ap.add_argument("--bits", type=int, default=None)
     ap.add_argument("--with-logmel", action="store_true",
-                    help="run the log-mel front end on every decoded hop (lyra_decoder.cc:304-311) inside the step")
+                    help="run the plain log-mel extractor on every decoded hop inside the step (implies --per-call)")
+    ap.add_argument("--full-decoder", action="store_true",
+                    help="NoiseEstimator::ReceiveSamples on every decoded hop (lyra_decoder.cc:304-311)")
+    ap.add_argument("--dtx", action="store_true", help="encode with enable_dtx (lyra_encoder.cc:131-156)")
+    ap.add_argument("--rate", type=int, default=16000, choices=[8000, 16000, 32000, 48000],
+                    help="external sample rate: both resamplers around the codec when it is not 16000")
+    ap.add_argument("--per-call", action="store_true",
+                    help="drive the individual `_dev` entry points from Python instead of lyra_hip_run_steps_dev")
+    ap.add_argument("--latency-steps", type=int, default=200, help="isolated steps for the latency distribution (0: skip)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N in ONE process: a host thread and a context per GPU, no process group")
     ap.add_argument("--bcast-weights", action="store_true",
                     help="rank 0 reads the weight container, RCCL-broadcasts it, every rank builds from the image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -215,7 +254,7 @@ def kernel_bound(name):
     w = KERNEL_WORK[name]
     t = {"mfma": (2 * w["f32"] / (PEAK_F32_MFMA_TFLOPS * 1e12) + 2 * w["i8"] / (PEAK_I8_MFMA_TOPS * 1e12)) * 1e9,
          "hbm": w["moved"] / (PEAK_HBM_GBS * 1e9) * 1e9,
-         "valu": (w.get("flops", 0) / (PEAK_F32_VALU_TFLOPS * 1e12) + w.get("flops64", 0) / (PEAK_F64_VALU_TFLOPS * 1e12)) * 1e9}
+         "valu": (w.get("flops", 0) / (PEAK_F32_VALU_TOPS * 1e12) + w.get("flops64", 0) / (PEAK_F64_VALU_TFLOPS * 1e12)) * 1e9}
     b = max(t, key=lambda k: t[k])
     return b, t[b], t
 
@@ -233,10 +272,17 @@ def kernel_row(name, total_ms, launches, B):
             "frac": round(t_ns * 1e-9 * B / dur, 4)}
 
 
-def step_work(mode, with_logmel):
+def step_work(mode, legs):
+    """legs: dict(with_logmel, full_decoder, dtx, rate) -> kernels of one step and their summed work."""
     names = list(DECODE_KERNELS) if mode == "decode" else list(ENCODE_KERNELS + DECODE_KERNELS)
-    if with_logmel:
+    if legs.get("with_logmel"):
         names.append("logmel_kernel")
+    if legs.get("full_decoder"):
+        names.append("logmel_noise_kernel")
+    if legs.get("dtx") and mode != "decode":
+        names.append("logmel_noise_kernel")
+    if legs.get("rate", 16000) != 16000:
+        names += ["resample_kernel"] * (1 if mode == "decode" else 2)
     f32 = sum(KERNEL_WORK[k]["f32"] for k in names)
     i8 = sum(KERNEL_WORK[k]["i8"] for k in names)
     moved = sum(KERNEL_WORK[k]["moved"] for k in names)
@@ -244,9 +290,13 @@ def step_work(mode, with_logmel):
     return names, f32, i8, moved, ref_bytes
 
 
-def step_roofline(mode, with_logmel, frames_per_s_per_gpu, traffic_table):
+def legs_of(args):
+    return dict(with_logmel=args.with_logmel, full_decoder=args.full_decoder, dtx=args.dtx, rate=args.rate)
+
+
+def step_roofline(mode, legs, frames_per_s_per_gpu, traffic_table):
     """The whole step against its binding bound."""
-    names, f32, i8, moved, ref_bytes = step_work(mode, with_logmel)
+    names, f32, i8, moved, ref_bytes = step_work(mode, legs)
     t_mfma = 2 * f32 / (PEAK_F32_MFMA_TFLOPS * 1e12) + 2 * i8 / (PEAK_I8_MFMA_TOPS * 1e12)
     t_hbm = moved / (PEAK_HBM_GBS * 1e9)
     traffic = None
@@ -308,15 +358,25 @@ class Shard:
         gen = torch.Generator(device=self.dev)
         gen.manual_seed(SEED + first_id)
         n = min(self.RING, args.warmup + args.steps)
-        # UnitToInt16Scalar(U(-1,1)) i.i.d. (lyra_benchmark_lib.cc:233-239): full-scale uniform int16
-        self.pcm_in = torch.randint(-32768, 32768, (n, B, 320), generator=gen, device=self.dev,
+        self.rate = args.rate
+        self.n_ext = 320 * args.rate // 16000
+        # UnitToInt16Scalar(U(-1,1)) i.i.d. (lyra_benchmark_lib.cc:233-239): full-scale uniform int16, at the external rate
+        self.pcm_in = torch.randint(-32768, 32768, (n, B, self.n_ext), generator=gen, device=self.dev,
                                     dtype=torch.int32).to(torch.int16)
+        if args.dtx:   # every fourth stream idles (digital silence) so that the DTX branch is actually taken
+            self.pcm_in[:, 3::4] = 0
         self.ids = torch.arange(B, device=self.dev, dtype=torch.int32)  # local stream slots of this shard
         nb = lyra_amd.packet_size(bits)
         # two packet / PCM buffer sets, alternated (include/lyra_hip.h "Streams": the two-buffer rule)
-        self.packets = [torch.empty((B, nb), device=self.dev, dtype=torch.uint8) for _ in range(2)]
+        self.packets = [torch.zeros((B, nb), device=self.dev, dtype=torch.uint8) for _ in range(2)]
         self.pcm_out = [torch.empty((B, 320), device=self.dev, dtype=torch.int16) for _ in range(2)]
+        self.packet_bytes = [torch.zeros((B,), device=self.dev, dtype=torch.int32) for _ in range(2)] if args.dtx else None
+        self.ext_out = [torch.empty((B, self.n_ext), device=self.dev, dtype=torch.int16) for _ in range(2)] \
+            if args.rate != 16000 else None
+        self.in16 = torch.empty((B, 320), device=self.dev, dtype=torch.int16) if args.rate != 16000 else None
+        self.is_noise = torch.zeros((B,), device=self.dev, dtype=torch.int32) if args.full_decoder else None
         self.mel = torch.empty((B, 160), device=self.dev, dtype=torch.float32) if args.with_logmel else None
+        self.per_call = args.per_call or args.with_logmel
         self.feats = self.pk_seq = None
         if wl["mode"] == "decode":
             self._prepare_decode_inputs(n)
@@ -332,7 +392,11 @@ class Shard:
         feat = torch.empty((B, 64), device=self.dev, dtype=torch.float32)
         idx = torch.empty((B, 46), device=self.dev, dtype=torch.int32)
         for i in range(n):
-            ctx.extract_dev(self.ids, self.pcm_in[i], feat)
+            x = self.pcm_in[i]
+            if self.rate != 16000:
+                ctx.resample_dev(self.ids, x, self.rate, 16000, self.in16, side="encoder")
+                x = self.in16
+            ctx.extract_dev(self.ids, x, feat)
             ctx.rvq_encode_dev(feat, bits, idx)
             ctx.rvq_decode_dev(idx, self.feats[i])      # decode side: ordered after the encode side by the library
             ctx.synchronize()
@@ -343,38 +407,61 @@ class Shard:
         ctx.reset()
 
     # -- steps --------------------------------------------------------------------------------------------------
-    def step_encdec(self, i):
-        ctx, bits, j = self.ctx, self.wl["bits"], i % self.pcm_in.shape[0]
-        ctx.encode_dev(self.ids, self.pcm_in[j], bits, self.packets[i & 1])
-        ctx.decode_dev(self.ids, self.packets[i & 1], bits, self.pcm_out[i & 1])
-        if self.mel is not None:
-            ctx.logmel_dev(self.ids, self.pcm_out[i & 1], self.mel)
+    # kind: "encdec" (encode + decode of every hop), "generate" (features -> PCM), "decode" (packets -> PCM)
+    def steps(self, kind, first, n):
+        """n consecutive steps starting at absolute step `first`: ONE library call (lyra_hip_run_steps_dev)."""
+        if self.per_call:
+            for i in range(first, first + n):
+                self._step_per_call(kind, i)
+            return
+        a = self.args
+        self.ctx.run_steps_dev(
+            self.ids, self.wl["bits"], n, first_step=first,
+            d_pcm_ring=self.pcm_in if kind == "encdec" else None,
+            d_packets=self.packets, d_pcm_out=self.pcm_out,
+            d_features=self.feats if kind == "generate" else None,
+            d_packet_ring=self.pk_seq if kind == "decode" else None,
+            d_packet_bytes=self.packet_bytes if (a.dtx and kind == "encdec") else None,
+            d_is_noise=self.is_noise if a.full_decoder else None,
+            external_rate=self.rate, d_ext_out=self.ext_out,
+            encode=kind == "encdec", decode=True, dtx=a.dtx and kind == "encdec", decoder_noise=a.full_decoder)
 
-    def step_generate(self, i):
-        self.ctx.generate_dev(self.ids, self.feats[i % self.feats.shape[0]], self.pcm_out[i & 1])
+    def _step_per_call(self, kind, i):
+        ctx, bits, a, s = self.ctx, self.wl["bits"], self.args, i & 1
+        if kind == "encdec":
+            x = self.pcm_in[i % self.pcm_in.shape[0]]
+            if self.rate != 16000:
+                ctx.resample_dev(self.ids, x, self.rate, 16000, self.in16, side="encoder")
+                x = self.in16
+            if a.dtx:
+                ctx.encode_dtx_dev(self.ids, x, bits, self.packets[s], self.packet_bytes[s])
+            else:
+                ctx.encode_dev(self.ids, x, bits, self.packets[s])
+            ctx.decode_dev(self.ids, self.packets[s], bits, self.pcm_out[s])
+        elif kind == "generate":
+            ctx.generate_dev(self.ids, self.feats[i % self.feats.shape[0]], self.pcm_out[s])
+        else:
+            ctx.decode_dev(self.ids, self.pk_seq[i % self.pk_seq.shape[0]], bits, self.pcm_out[s])
+        if a.full_decoder:
+            ctx.noise_receive_dev(self.ids, self.pcm_out[s], self.is_noise, side="decoder")
         if self.mel is not None:
-            self.ctx.logmel_dev(self.ids, self.pcm_out[i & 1], self.mel)
-
-    def step_decode(self, i):
-        self.ctx.decode_dev(self.ids, self.pk_seq[i % self.pk_seq.shape[0]], self.wl["bits"], self.pcm_out[i & 1])
-        if self.mel is not None:
-            self.ctx.logmel_dev(self.ids, self.pcm_out[i & 1], self.mel)
+            ctx.logmel_dev(self.ids, self.pcm_out[s], self.mel)
+        if self.rate != 16000:
+            ctx.resample_dev(self.ids, self.pcm_out[s], 16000, self.rate, self.ext_out[s], side="decoder")
 
     def sync(self):
         self.ctx.synchronize()
         self.torch.cuda.synchronize(self.dev)
 
-    def kernel_table(self, step, first, nsteps):
+    def kernel_table(self, kind, first, nsteps):
         """Serialised pass: every kernel bracketed by HIP events, the library streams strictly in call order."""
         ctx = self.ctx
         ctx.set_serial(True)
         ctx.profile_enable(True)
-        for i in range(first, first + 2):   # first launches after the mode switch: not representative
-            step(i)
+        self.steps(kind, first, 2)   # first launches after the mode switch: not representative
         ctx.synchronize()
         ctx.profile_read()
-        for i in range(first + 2, first + 2 + nsteps):
-            step(i)
+        self.steps(kind, first + 2, nsteps)
         ctx.synchronize()
         prof = ctx.profile_read()
         ctx.profile_enable(False)
@@ -382,22 +469,33 @@ class Shard:
         B = self.wl["B"]
         return {k: kernel_row(k, ms, n, B) for k, (ms, n) in prof.items() if n and k in KERNEL_WORK}
 
-    def timed(self, step, first, K, barrier, only=None):
+    def timed(self, kind, first, K, barrier, only=None):
         """K steps between barriers + synchronises -> (seconds, dominant-kernel profile)."""
         ctx = self.ctx
-        if only:
-            ctx.profile_enable(True, only=only, every=8)   # a sample of the launches: events are stream packets too
+        if only:   # a sample of the launches (an event record is a stream packet of its own, ~5 us of bubble each)
+            ctx.profile_enable(True, only=only, every=dominant_sample_every(K))
         barrier()
         self.sync()
         t0 = time.perf_counter()
-        for i in range(first, first + K):
-            step(i)
+        self.steps(kind, first, K)
+        self.enqueue_seconds = time.perf_counter() - t0     # host time to enqueue the whole region
         self.sync()
         barrier()
         t1 = time.perf_counter()
         prof = ctx.profile_read() if only else {}
         ctx.profile_enable(False)
         return t1 - t0, prof
+
+    def latency(self, kind, first, M):
+        """M isolated steps: enqueue one step, wait until every output of it is complete.  -> list of seconds."""
+        out = []
+        self.sync()
+        for i in range(first, first + M):
+            t0 = time.perf_counter()
+            self.steps(kind, i, 1)
+            self.ctx.synchronize()
+            out.append(time.perf_counter() - t0)
+        return out
 
 
 class StubShard:
@@ -409,60 +507,75 @@ class StubShard:
         self.weights_bytes = len(weights_image) if weights_image is not None else 0
         self.calls = {"encdec": 0, "generate": 0, "decode": 0, "sync": 0}
 
-    def step_encdec(self, i):
-        self.calls["encdec"] += 1
-
-    def step_generate(self, i):
-        self.calls["generate"] += 1
-
-    def step_decode(self, i):
-        self.calls["decode"] += 1
+    def steps(self, kind, first, n):
+        self.calls[kind] += n
 
     def sync(self):
         self.calls["sync"] += 1
 
-    def kernel_table(self, step, first, nsteps):
-        for i in range(first, first + nsteps + 2):
-            step(i)
+    def kernel_table(self, kind, first, nsteps):
+        self.steps(kind, first, nsteps + 2)
         return None
 
-    def timed(self, step, first, K, barrier, only=None):
+    def timed(self, kind, first, K, barrier, only=None):
         barrier()
-        for i in range(first, first + K):
-            step(i)
+        self.steps(kind, first, K)
         barrier()
         return K * 1e-4 * (1.0 + 0.5 * self.rank), {}
 
+    def latency(self, kind, first, M):
+        self.steps(kind, first, M)
+        return [1e-4 * (1 + (i % 5 == 4)) for i in range(M)]
+
+
+def dominant_sample_every(K):
+    """Every how-many-th launch of the dominant kernel is bracketed inside the timed region: ~32 samples of a long run,
+    every second launch of a 20-step driver run (10 samples; bracketing all 20 would cost the headline ~3 %)."""
+    return max(2, K // 32) if K >= 4 else 1
+
+
+def latency_stats(samples):
+    """min / mean / p50 / p99 / max / stddev in microseconds (lyra_benchmark_lib.cc:164-182 prints these per stage)."""
+    if not samples:
+        return None
+    a = np.sort(np.asarray(samples, np.float64)) * 1e6
+    pick = lambda q: float(a[min(len(a) - 1, int(np.ceil(q * len(a))) - 1)])
+    return {"n": int(len(a)), "min": round(float(a[0]), 1), "mean": round(float(a.mean()), 1), "p50": round(pick(0.5), 1),
+            "p99": round(pick(0.99), 1), "max": round(float(a[-1]), 1), "stddev": round(float(a.std()), 1)}
+
 
 def run_shard(sh, args, wl, barrier):
-    """Warm-up, serialised kernel table, timed region(s) of one shard -> dict of raw results."""
+    """Warm-up, serialised kernel table, timed region(s), latency leg of one shard -> dict of raw results."""
     K, W = args.steps, args.warmup
-    step = sh.step_encdec if wl["mode"] == "encdec" else sh.step_generate
-    for i in range(W):
-        step(i)
+    kind = "encdec" if wl["mode"] == "encdec" else "generate"
+    sh.steps(kind, 0, W)
     sh.sync()
     table = None
     cursor = W
     if not args.no_kernel_table:
-        table = sh.kernel_table(step, cursor, 8)
+        table = sh.kernel_table(kind, cursor, 8)
         cursor += 10
-        for i in range(cursor, cursor + 2):   # back to the overlapped regime before timing
-            step(i)
+        sh.steps(kind, cursor, 2)   # back to the overlapped regime before timing
         cursor += 2
         sh.sync()
     dom = max(table, key=lambda k: table[k]["avg_us"]) if table else None
-    secs, prof = sh.timed(step, cursor, K, barrier, only=dom)
-    res = {"seconds": secs, "table": table, "dom": dom, "dom_prof": prof.get(dom) if dom else None}
+    secs, prof = sh.timed(kind, cursor, K, barrier, only=dom)
+    cursor += K
+    res = {"seconds": secs, "table": table, "dom": dom, "dom_prof": prof.get(dom) if dom else None,
+           "enqueue_seconds": getattr(sh, "enqueue_seconds", None)}
+    if args.latency_steps > 0:
+        res["latency"] = sh.latency(kind, cursor, args.latency_steps)
+        cursor += args.latency_steps
     if wl["mode"] == "decode":
-        cursor += K
-        for i in range(cursor, cursor + 3):
-            sh.step_decode(i)
+        sh.steps("decode", cursor, 3)
         sh.sync()
+        cursor += 3
         table2 = None
         if not args.no_kernel_table:
-            table2 = sh.kernel_table(sh.step_decode, cursor + 3, 8)
+            table2 = sh.kernel_table("decode", cursor, 8)
+            cursor += 10
             sh.sync()
-        secs2, _ = sh.timed(sh.step_decode, cursor + 13, K, barrier)
+        secs2, _ = sh.timed("decode", cursor, K, barrier)
         res["secondary_seconds"] = secs2
         res["secondary_table"] = table2
     return res
@@ -476,8 +589,8 @@ def result_line(args, wl, world, secs, frames, res, launcher):
     value = frames / secs
     per_gpu = value / world
     traffic_table = load_traffic()
-    roof = step_roofline(mode, args.with_logmel, per_gpu, traffic_table)
-    names, f32, i8, moved, _ = step_work(mode, args.with_logmel)
+    roof = step_roofline(mode, legs_of(args), per_gpu, traffic_table)
+    names, f32, i8, moved, _ = step_work(mode, legs_of(args))
     what = "encode+decode" if mode == "encdec" else "decode only (lyra_hip_generate_dev: features -> PCM)"
     out = {
         "metric": "20ms 16kHz frames/sec encode+decode (whole node) at batch 4096; xRT/stream",
@@ -488,11 +601,16 @@ def result_line(args, wl, world, secs, frames, res, launcher):
         "config": {"workload": f"BASELINE config #{wl['config']}: batch={B} streams/GPU x 1 frame(20 ms, 320 samples)"
                                f"/step, {bits} bits ({bits // 4}-stage RVQ, {bits * 50} bps), {what}"
                                + (", log-mel front end on every decoded hop" if args.with_logmel else "")
+                               + (", NoiseEstimator on every decoded hop" if args.full_decoder else "")
+                               + (", DTX encoder (every 4th stream silent)" if args.dtx else "")
+                               + (f", {args.rate} Hz external rate (both resamplers)" if args.rate != 16000 else "")
                                + ", state carried across steps",
                    "baseline_config": wl["config"], "streams_per_gpu": B, "total_streams": wl["total"],
                    "num_bits": bits,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective ({launcher})",
-                   "requant_mode": "exact", "sub_batches": wl.get("sub_batches") or 1},
+                   "requant_mode": "exact", "sub_batches": wl.get("sub_batches") or 1,
+                   "driver": "python, one `_dev` call per codec call" if (args.per_call or args.with_logmel)
+                   else "lyra_hip_run_steps_dev: one C call per timed region"},
         "xrt_per_stream": round(value / 50.0 / wl["total"], 3),
         "xrt_aggregate": round(value / 50.0, 1),
         "roofline": roof,
@@ -505,10 +623,17 @@ def result_line(args, wl, world, secs, frames, res, launcher):
     if res.get("dom") and res.get("dom_prof") and res["dom_prof"][1]:
         ms, n = res["dom_prof"]
         row = kernel_row(res["dom"], ms, n, B)
-        row.update(kernel=res["dom"], measured_in="timed region (library streams overlapping), every 8th launch")
+        row.update(kernel=res["dom"], measured_in=f"timed region (library streams overlapping), every "
+                                                  f"{dominant_sample_every(K)}th launch bracketed by HIP events on its own stream")
         if traffic_table and res["dom"] in traffic_table:
             row["traffic_bytes_per_launch_at_B4096"] = traffic_table[res["dom"]].get("hbm_bytes_per_launch")
         out["dominant_kernel"] = row
+    if res.get("enqueue_seconds") is not None:
+        out["host_enqueue_ms"] = round(res["enqueue_seconds"] * 1e3, 3)    # of the whole timed region (rank 0)
+    if res.get("latency"):
+        out["step_latency_us"] = dict(latency_stats(res["latency"]),
+                                      what="one isolated step of this rank: enqueue -> every output complete "
+                                           "(host clock around lyra_hip_run_steps_dev(n=1) + lyra_hip_synchronize)")
     if mode == "decode":
         s2 = res["secondary_seconds"]
         v2 = frames / s2
@@ -587,7 +712,25 @@ def main_single_process(args, ngpu):
     print(json.dumps(out))
 
 
+def free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def respawn_under_launcher(argv, ngpu):
+    """`python bench.py --gpus N` as the driver types it, N > 1, no launcher: re-execute under torch.distributed.run so
+    that the job really is one process per GPU with a process group (RCCL on the GPU box, gloo under --stub-context) --
+    the same command line the launcher form documents.  Rank 0's JSON line is this process's output."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpu}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", LYRA_BENCH_RESPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = parse(argv)
     if args.selftest_dist:
         return selftest_dist(args)
@@ -596,8 +739,15 @@ def main(argv=None):
     stub = args.stub_context
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback); use --selftest-dist for the plumbing test")
-    if world == 1 and args.gpus > 1 and not stub:
-        return main_single_process(args, args.gpus)
+    if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.single_process and not stub:
+            return main_single_process(args, args.gpus)
+        if not stub and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
+        rc = respawn_under_launcher(argv, args.gpus)
+        if rc:
+            raise SystemExit(rc)
+        return
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if stub:
@@ -627,8 +777,12 @@ def main(argv=None):
     if wl["mode"] == "decode":
         res["secondary_seconds"], _ = reduce_job(res["secondary_seconds"], 0, world, dev)
     if rank == 0:
-        out = result_line(args, wl, world, secs, frames, res, "one process per GPU, torch.distributed/RCCL for the "
-                          "timing barrier and the result reduction only")
+        backend = "gloo (stub)" if stub else "RCCL"
+        out = result_line(args, wl, world, secs, frames, res,
+                          f"one process per GPU, torch.distributed/{backend}: {world} rank(s), process group used for the "
+                          "timing barrier and the result reduction only"
+                          + (", self-spawned from `python bench.py --gpus N`" if os.environ.get("LYRA_BENCH_RESPAWNED") else ""))
+        out["ranks"] = world
         if stub:
             out["stub"] = {"calls": sh.calls, "first_id": first_id, "weights_bytes": sh.weights_bytes}
         if world == 1 and not args.no_cpu_baseline and not stub:

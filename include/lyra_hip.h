@@ -173,6 +173,12 @@ int lyra_hip_resample(lyra_hip_ctx* ctx, int side, const int32_t* stream_ids, in
  * counter-based generator (seed, stream id, hop, bin) instead of the reference's non-deterministic absl::BitGen. */
 int lyra_hip_comfort_noise(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const float* features, int16_t* pcm);
 int lyra_hip_set_cng_seed(lyra_hip_ctx* ctx, uint64_t seed);
+/* The sample rate LyraEncoder::Create was called with, for the ENCODER-side noise estimator of the calls that follow
+ * (lyra_hip_encode_dtx[_dev], lyra_hip_noise_receive[_dev] side ENCODER): the reference hands NoiseEstimator::Create
+ * its external rate together with the internal 320-sample hop (lyra_encoder.cc:82-85), so the estimator's update period
+ * and half-lives, counted in hops, depend on it (noise_estimator.cc:96-124).  8000 / 16000 (default) / 32000 / 48000.
+ * A host-side setting read at enqueue time: set it before each call when encoders of different rates share a context. */
+int lyra_hip_set_encoder_sample_rate(lyra_hip_ctx* ctx, int sample_rate_hz);
 
 /* ---- fused paths -------------------------------------------------------------------------------- */
 
@@ -238,7 +244,11 @@ typedef struct lyra_hip_steps {
   uint8_t* d_packets[2];         /* [B][num_bits / 8 rounded up] each */
   int32_t* d_packet_bytes[2];    /* [B] each (DTX) */
   int16_t* d_pcm_out[2];         /* [B][320] each: decoder output at 16 kHz */
-  const float* d_features;       /* [B][64] or NULL */
+  const float* d_features;       /* [n_features][B][64] or NULL: step `step` generates from frame step % n_features */
+  int n_features;                /* frames in d_features (0 is read as 1) */
+  const uint8_t* d_packet_ring;  /* DECODE without ENCODE: [n_packet_ring][B][bytes] received packets, or NULL (then
+                                    d_packets[step & 1] is decoded as it stands) */
+  int n_packet_ring;
   int32_t* d_is_noise;           /* [B] (DECODER_NOISE) */
   int external_rate;             /* 0 / 16000: none; 8000 / 32000 / 48000: the encoder's and the decoder's resampler
                                     (lyra_encoder.cc:119-122, lyra_decoder.cc:107-113) around the codec */

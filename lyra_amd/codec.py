@@ -59,7 +59,7 @@ class StepsDesc(C.Structure):
     _fields_ = [("d_stream_ids", C.c_void_p), ("B", C.c_int), ("num_bits", C.c_int), ("flags", C.c_uint),
                 ("first_step", C.c_long), ("n_steps", C.c_int), ("ring", C.c_int), ("d_pcm_ring", C.c_void_p),
                 ("d_packets", C.c_void_p * 2), ("d_packet_bytes", C.c_void_p * 2), ("d_pcm_out", C.c_void_p * 2),
-                ("d_features", C.c_void_p), ("d_is_noise", C.c_void_p), ("external_rate", C.c_int),
+                ("d_features", C.c_void_p), ("n_features", C.c_int), ("d_packet_ring", C.c_void_p), ("n_packet_ring", C.c_int), ("d_is_noise", C.c_void_p), ("external_rate", C.c_int),
                 ("d_ext_out", C.c_void_p * 2)]
 
 
@@ -113,6 +113,7 @@ def _load():
         getattr(L, f"lyra_hip_resample{suf}").argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
         getattr(L, f"lyra_hip_comfort_noise{suf}").argtypes = [vp, vp, ci, vp, vp]
     L.lyra_hip_set_cng_seed.argtypes = [vp, C.c_uint64]
+    L.lyra_hip_set_encoder_sample_rate.argtypes = [vp, C.c_int]
     L.lyra_hip_stream.restype = vp
     L.lyra_hip_stream.argtypes = [vp]
     L.lyra_hip_stream_decode.restype = vp
@@ -343,6 +344,11 @@ class LyraHip:
                                                 features.ctypes.data if features is not None else None, out.ctypes.data))
         return out
 
+    def set_encoder_sample_rate(self, sample_rate_hz):
+        """The rate a DTX LyraEncoder was created with: time constants of the encoder-side noise estimator
+        (lyra_encoder.cc:82-85, noise_estimator.cc:96-124)."""
+        self._chk(self.L.lyra_hip_set_encoder_sample_rate(self.h, sample_rate_hz))
+
     def set_cng_seed(self, seed):
         self._chk(self.L.lyra_hip_set_cng_seed(self.h, seed))
 
@@ -449,7 +455,7 @@ class LyraHip:
 
     def run_steps_dev(self, d_ids, num_bits, n_steps, first_step=0, d_pcm_ring=None, d_packets=None, d_pcm_out=None,
                       d_features=None, d_packet_bytes=None, d_is_noise=None, external_rate=16000, d_ext_out=None,
-                      encode=True, decode=True, dtx=False, decoder_noise=False):
+                      encode=True, decode=True, dtx=False, decoder_noise=False, d_packet_ring=None):
         """lyra_hip_run_steps_dev: n_steps hops of every stream from ONE C call.  d_pcm_ring int16
         [ring][B][320 * external_rate / 16000]; d_packets / d_pcm_out / d_packet_bytes / d_ext_out: pairs of tensors
         (step i uses element (first_step + i) & 1)."""
@@ -473,8 +479,13 @@ class LyraHip:
                 S.d_packet_bytes[i] = self._dev_ptr(d_packet_bytes[i], "int32", (B,), "packet bytes")
             if d_ext_out is not None:
                 S.d_ext_out[i] = self._dev_ptr(d_ext_out[i], "int16", (B, n_ext), "external-rate out")
-        if d_features is not None:
-            S.d_features = self._dev_ptr(d_features, "float32", (B, NUM_FEATURES), "features")
+        if d_features is not None:     # [B][64], or [n][B][64]: step i generates from frame (first_step + i) % n
+            S.n_features = d_features.shape[0] if d_features.dim() == 3 else 1
+            S.d_features = self._dev_ptr(d_features, "float32", (S.n_features, B, NUM_FEATURES) if d_features.dim() == 3
+                                         else (B, NUM_FEATURES), "features")
+        if d_packet_ring is not None:  # decode-only: received packets [n][B][bytes], step i decodes frame (first_step + i) % n
+            S.n_packet_ring = d_packet_ring.shape[0]
+            S.d_packet_ring = self._dev_ptr(d_packet_ring, "uint8", (S.n_packet_ring, B, packet_size(num_bits)), "packet ring")
         if d_is_noise is not None:
             S.d_is_noise = self._dev_ptr(d_is_noise, "int32", (B,), "is_noise")
         self._dev_call(self.L.lyra_hip_run_steps_dev, C.byref(S))

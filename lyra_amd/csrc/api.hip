@@ -91,6 +91,7 @@ struct lyra_hip_ctx {
   int16_t* d_rs_in = nullptr;     // [cap][960] resampler staging (host-pointer entry points)
   int16_t* d_rs_out = nullptr;    // [cap][960]
   unsigned long long cng_seed = 0x4C797261ull;   // comfort-noise phase generator seed (lyra_hip_set_cng_seed)
+  int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
   unsigned profiling = 0;  // bit i set: bracket launches of kernel i
@@ -496,9 +497,12 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
   return 0;
 }
 
-// NoiseEstimator::Create's constants (noise_estimator.cc:96-124)
-NoiseP noise_params() {
-  const float secs_per_hop = 320.f / 16000.f;
+// NoiseEstimator::Create's constants (noise_estimator.cc:96-124).  The hop duration is derived from the sample rate the
+// CALLER passes: 16 kHz by the decoder (lyra_decoder.cc:129-131), the EXTERNAL rate -- with the internal hop of 320
+// samples -- by a DTX encoder (lyra_encoder.cc:82-85), so an 8 / 32 / 48 kHz encoder updates its noise estimate every
+// 25 / 100 / 150 hops and decays its bounds accordingly.  (Found by running the reference's own classes, oracle/_ref.)
+NoiseP noise_params(int sample_rate_hz = 16000) {
+  const float secs_per_hop = 320.f / sample_rate_hz;
   NoiseP p;
   p.hops_per_update = (int)roundf(1.f / secs_per_hop);
   p.max_smoothing = powf(0.5f, secs_per_hop / 0.7f);
@@ -523,8 +527,8 @@ int launch_noise(lyra_hip_ctx* c, int side, hipStream_t st_, const int32_t* d_id
   uint8_t* region = c->sm.base[side == 0 ? st::R_NOISE_E : st::R_NOISE_D];
   { ProfScope ps(c, K_NOISE, st_);
     hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), st_, c->model.d_mel, d_pcm, d_ids,
-                       B, region, (int)st::NOISE_BYTES, (int)st::N_PREV, (float*)nullptr, 1, noise_params(), d_is_noise,
-                       d_masked_ids); }
+                       B, region, (int)st::NOISE_BYTES, (int)st::N_PREV, (float*)nullptr, 1,
+                       noise_params(side == 0 ? c->enc_noise_rate : 16000), d_is_noise, d_masked_ids); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1001,6 +1005,14 @@ int lyra_hip_comfort_noise(lyra_hip_ctx* c, const int32_t* ids, int B, const flo
   return 0;
 }
 
+int lyra_hip_set_encoder_sample_rate(lyra_hip_ctx* c, int sample_rate_hz) {
+  if (!c) return LYRA_HIP_EINVAL;
+  if (sample_rate_hz != 8000 && sample_rate_hz != 16000 && sample_rate_hz != 32000 && sample_rate_hz != 48000)
+    return fail(c, LYRA_HIP_EINVAL, "sample rate %d Hz is not supported by the codec (lyra_config.h:57)", sample_rate_hz);
+  c->enc_noise_rate = sample_rate_hz;
+  return 0;
+}
+
 int lyra_hip_set_cng_seed(lyra_hip_ctx* c, uint64_t seed) {
   if (!c) return LYRA_HIP_EINVAL;
   c->cng_seed = seed;
@@ -1264,7 +1276,7 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
   if ((enc || (dec && !feats)) && (rc = check_bits(c, S->num_bits))) return rc;
   if (!S->d_stream_ids || S->n_steps < 0 || S->first_step < 0) return fail(c, LYRA_HIP_EINVAL, "run_steps: bad argument");
   if (enc && (!S->d_pcm_ring || S->ring <= 0)) return fail(c, LYRA_HIP_EINVAL, "run_steps: ENCODE needs d_pcm_ring / ring");
-  if ((enc || (dec && !feats)) && (!S->d_packets[0] || !S->d_packets[1]))
+  if ((enc || (dec && !feats && !S->d_packet_ring)) && (!S->d_packets[0] || !S->d_packets[1]))
     return fail(c, LYRA_HIP_EINVAL, "run_steps: two packet buffers needed");
   if (dec && (!S->d_pcm_out[0] || !S->d_pcm_out[1])) return fail(c, LYRA_HIP_EINVAL, "run_steps: two PCM output buffers needed");
   if ((F & LYRA_HIP_STEP_DTX) && (!S->d_packet_bytes[0] || !S->d_packet_bytes[1]))
@@ -1296,8 +1308,13 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
       if (rc) return rc;
     }
     if (dec) {
-      if (feats) rc = lyra_hip_generate_dev(c, S->d_stream_ids, S->B, S->d_features, S->d_pcm_out[set]);
-      else rc = lyra_hip_decode_dev(c, S->d_stream_ids, S->B, S->d_packets[set], S->num_bits, S->d_pcm_out[set]);
+      if (feats) rc = lyra_hip_generate_dev(c, S->d_stream_ids, S->B, S->d_features + (size_t)(step % (S->n_features > 0 ? S->n_features : 1)) * B * 64, S->d_pcm_out[set]);
+      else {
+        const uint8_t* pk = S->d_packets[set];
+        if (!enc && S->d_packet_ring && S->n_packet_ring > 0)
+          pk = S->d_packet_ring + (size_t)(step % S->n_packet_ring) * B * (size_t)((S->num_bits + 7) / 8);
+        rc = lyra_hip_decode_dev(c, S->d_stream_ids, S->B, pk, S->num_bits, S->d_pcm_out[set]);
+      }
       if (rc) return rc;
       if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
         if ((rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise))) return rc;

@@ -112,8 +112,9 @@ std::optional<std::vector<uint8_t>> BatchLyraEncoder::Encode(const absl::Span<co
   const int bits = BatchBitrateToNumQuantizedBits(bitrate_);
   std::vector<uint8_t> packets(static_cast<size_t>(num_streams_) * packet_size());
   int rc;
-  if (enable_dtx_) {   // lyra_encoder.cc:131-141
-    rc = lyra_hip_encode_dtx(ctx_, ids_.data(), num_streams_, pcm, bits, packets.data(), lengths_.data());
+  if (enable_dtx_) {   // lyra_encoder.cc:131-141; the estimator's time constants follow the EXTERNAL rate (:82-85)
+    rc = lyra_hip_set_encoder_sample_rate(ctx_, sample_rate_hz_);
+    if (rc == 0) rc = lyra_hip_encode_dtx(ctx_, ids_.data(), num_streams_, pcm, bits, packets.data(), lengths_.data());
   } else {
     rc = lyra_hip_encode(ctx_, ids_.data(), num_streams_, pcm, bits, packets.data());
     std::fill(lengths_.begin(), lengths_.end(), packet_size());

@@ -18,12 +18,17 @@ class Span {
   Span(const V& v) : p_(v.data()), n_(v.size()) {}  // NOLINT
   constexpr T* data() const { return p_; }
   constexpr size_t size() const { return n_; }
+  constexpr size_t length() const { return n_; }
   constexpr bool empty() const { return n_ == 0; }
   constexpr T* begin() const { return p_; }
   constexpr T* end() const { return p_ + n_; }
   constexpr T& operator[](size_t i) const { return p_[i]; }
   constexpr T& at(size_t i) const { return p_[i]; }
   constexpr Span subspan(size_t pos, size_t len) const { return Span(p_ + pos, len); }
+  constexpr Span first(size_t len) const { return Span(p_, len); }
+  constexpr Span last(size_t len) const { return Span(p_ + n_ - len, len); }
+  constexpr T& front() const { return p_[0]; }
+  constexpr T& back() const { return p_[n_ - 1]; }
  private:
   T* p_;
   size_t n_;

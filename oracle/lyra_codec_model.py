@@ -27,8 +27,8 @@ class OracleKit:
     def Stream(self):
         return lo.Stream(self.o)
 
-    def NoiseEstimator(self, side):
-        return lo.NoiseEstimator(self.o)
+    def NoiseEstimator(self, side, sample_rate_hz=16000):
+        return lo.NoiseEstimator(self.o, sample_rate_hz=sample_rate_hz)
 
     def ComfortNoiseGenerator(self, seed):
         return lo.ComfortNoiseGenerator(self.o, seed=seed)
@@ -52,7 +52,8 @@ class RefLyraEncoder:
         self.rate, self.bits, self.dtx = sample_rate_hz, num_bits, enable_dtx
         self.resampler = self.o.Resampler(sample_rate_hz, 16000) if sample_rate_hz != 16000 else None
         self.stream = self.o.Stream()
-        self.noise = self.o.NoiseEstimator(0) if enable_dtx else None
+        # NoiseEstimator::Create(sample_rate_hz, ...): the encoder hands over its EXTERNAL rate (lyra_encoder.cc:82-85)
+        self.noise = self.o.NoiseEstimator(0, sample_rate_hz) if enable_dtx else None
 
     def Encode(self, audio):
         audio = np.asarray(audio, np.int16)

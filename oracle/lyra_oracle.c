@@ -992,6 +992,14 @@ lo_noise* lo_noise_new(int num_hops_per_update, float max_smoothing, float bound
   n->is_noise = 1;                            /* noise_estimator.cc:139 */
   return n;
 }
+/* NoiseEstimator::Create(sample_rate_hz, 320, ...) (noise_estimator.cc:96-124): the hop duration -- hence the update
+ * period and both half-lives in hops -- is derived from the sample rate THE CALLER passes.  The decoder passes 16 kHz
+ * (lyra_decoder.cc:129-131); the DTX encoder passes its EXTERNAL rate with the internal hop of 320 samples
+ * (lyra_encoder.cc:82-85), so an 8 / 32 / 48 kHz encoder updates every 25 / 100 / 150 hops, not every 50. */
+lo_noise* lo_noise_new_rate(int sample_rate_hz) {
+  const float secs_per_hop = 320.f / sample_rate_hz;
+  return lo_noise_new((int)roundf(1.f / secs_per_hop), powf(0.5f, secs_per_hop / 0.7f), powf(0.5f, secs_per_hop / 1.f));
+}
 void lo_noise_free(lo_noise* n) { free(n); }
 
 static float average160(const float* v) {     /* std::accumulate(..., 0.f) / size */

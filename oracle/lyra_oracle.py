@@ -47,6 +47,8 @@ def lib():
         L.lo_rvq_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.lo_noise_new.restype = C.c_void_p
         L.lo_noise_new.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.lo_noise_new_rate.restype = C.c_void_p
+        L.lo_noise_new_rate.argtypes = [C.c_int]
         L.lo_noise_free.argtypes = [C.c_void_p]
         L.lo_noise_compute_is_noise.argtypes = [C.c_void_p, C.c_void_p]
         L.lo_noise_update.argtypes = [C.c_void_p, C.c_void_p]
@@ -187,10 +189,15 @@ class Stream:
 class NoiseEstimator:
     """lyra/noise_estimator.{h,cc}: one instance per encoder (DTX) or decoder stream."""
 
-    def __init__(self, oracle, num_hops_per_update=0, max_smoothing=0.0, bound_decay=0.0):
+    def __init__(self, oracle, num_hops_per_update=0, max_smoothing=0.0, bound_decay=0.0, sample_rate_hz=None):
+        """sample_rate_hz: what NoiseEstimator::Create is given -- 16000 by the decoder, the EXTERNAL rate by a DTX
+        encoder (lyra_encoder.cc:82-85); the time constants follow from it."""
         self.o = oracle
         self.L = oracle.L
-        self.h = self.L.lo_noise_new(num_hops_per_update, max_smoothing, bound_decay)
+        if sample_rate_hz is not None:
+            self.h = self.L.lo_noise_new_rate(sample_rate_hz)
+        else:
+            self.h = self.L.lo_noise_new(num_hops_per_update, max_smoothing, bound_decay)
 
     def __del__(self):
         try:

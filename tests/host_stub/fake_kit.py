@@ -70,7 +70,7 @@ class FakeKit:
     def Stream(self):
         return self._Stream()
 
-    def NoiseEstimator(self, side):
+    def NoiseEstimator(self, side, sample_rate_hz=16000):
         return self._Noise(side)
 
     def ComfortNoiseGenerator(self, seed):

@@ -133,7 +133,8 @@ def test_bench_main_two_ranks_with_stub_context_gloo():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--stub-context", "--gpus", "2",
-           "--config", "5", "--steps", "6", "--warmup", "3", "--bcast-weights", "--no-kernel-table", "--no-cpu-baseline"]
+           "--config", "5", "--steps", "6", "--warmup", "3", "--bcast-weights", "--no-kernel-table", "--no-cpu-baseline",
+           "--latency-steps", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -147,6 +148,45 @@ def test_bench_main_two_ranks_with_stub_context_gloo():
     assert abs(r["value"] - 32768 * 6 / secs) < 1.0   # whole-job frames / max-over-ranks seconds
     assert r["stub"]["first_id"] == 0 and r["stub"]["calls"]["encdec"] == 3 + 6
     assert r["stub"]["weights_bytes"] == os.path.getsize(os.path.join(ROOT, "lyra_amd", "assets", "lyra_v1.lyrapack"))
+
+
+def test_bench_default_invocation_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` exactly as a driver without a launcher types it: bench.py re-executes itself under
+    torch.distributed.run, so the job is two processes with a process group (gloo here, RCCL on the GPU box), not two
+    threads of one process.  Stub shard; the latency leg and the kernel-table pass run too."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stub-context", "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--latency-steps", "10"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks"] == 2 and r["scaling"] == "weak"
+    assert "self-spawned" in r["config"]["parallelism"] and "2 rank(s)" in r["config"]["parallelism"]
+    assert r["config"]["total_streams"] == 2 * 4096
+    assert abs(r["value"] - 2 * 4096 * 5 / (5 * 1e-4 * 1.5)) < 1.0
+    # warm-up 2 + kernel-table pass 10 + 2 + timed 5 + latency 10
+    assert r["stub"]["calls"]["encdec"] == 2 + 10 + 2 + 5 + 10
+    lat = r["step_latency_us"]
+    assert lat["n"] == 10 and lat["min"] == 100.0 and lat["max"] == 200.0 and lat["p50"] == 100.0 and lat["p99"] == 200.0
+
+
+def test_bench_roofline_bookkeeping():
+    """Pure functions of bench.py: per-kernel bounds and the whole-step roofline of every leg."""
+    sys.path.insert(0, ROOT)
+    import bench
+    b, t_ns, all_t = bench.kernel_bound("rvq_encode_kernel")
+    # sub / mul / add are one flop each: priced at the non-FMA vector rate, not at the FMA peak
+    assert b == "valu" and abs(t_ns - (3 * 16 * 64 * 46 + 3 * 64 * 46) / 78.65e12 * 1e9) < 1e-6
+    assert bench.kernel_bound("enc_s0_kernel")[0] == "mfma" and bench.kernel_bound("dec_s0_kernel")[0] == "hbm"
+    base = bench.step_work("encdec", dict(rate=16000))
+    full = bench.step_work("encdec", dict(full_decoder=True, dtx=True, rate=48000))
+    assert len(full[0]) == len(base[0]) + 4 and full[3] > base[3] and full[1] == base[1]
+    r = bench.step_roofline("encdec", dict(rate=16000), 13.0e6, None)
+    assert r["bound"] == "mfma" and abs(r["frac"] - 2 * base[1] * 13.0e6 / 157.3e12) < 1e-3
+    st = bench.latency_stats([1e-4] * 99 + [5e-4])
+    assert st["p50"] == 100.0 and st["p99"] == 100.0 and st["max"] == 500.0 and st["n"] == 100
 
 
 def test_cpp_plugin_layer_host_logic_against_fake_abi(tmp_path):

@@ -109,7 +109,7 @@ def _speech_noise_silence(golden_dir, T, B):
     return np.stack([kinds[b % 4] for b in range(B)], axis=1).copy()     # [T][B][320]
 
 
-@pytest.mark.parametrize("mode", ["plain", "dtx+noise", "48k", "features"])
+@pytest.mark.parametrize("mode", ["plain", "dtx+noise", "48k", "features", "packet_ring"])
 def test_run_steps_equals_individual_calls(golden_dir, mode):
     """lyra_hip_run_steps_dev over [1, 2, 5, 12, 30] cumulative steps on context A against the individual `_dev` calls
     on context B (state is carried, so equal outputs at every checkpoint means equal at every hop that fed them)."""
@@ -140,22 +140,28 @@ def test_run_steps_equals_individual_calls(golden_dir, mode):
                     flag=torch.full((B,), -1, device=dev, dtype=torch.int32),
                     in16=torch.zeros((B, 320), device=dev, dtype=torch.int16))
     a, b = bufs(), bufs()
-    feats = None
-    if mode == "features":
-        feats = torch.from_numpy(np.random.default_rng(2).normal(0, 1.5, size=(B, 64)).astype(np.float32)).to(dev)
+    feats = pkring = None
+    if mode == "features":     # a ring of three feature frames: step t generates from frame t % 3
+        feats = torch.from_numpy(np.random.default_rng(2).normal(0, 1.5, size=(3, B, 64)).astype(np.float32)).to(dev)
+    if mode == "packet_ring":  # decode-only from a ring of four received packets per stream
+        pkring = torch.from_numpy(np.random.default_rng(3).integers(0, 256, size=(4, B, nb)).astype(np.uint8)).to(dev)
     torch.cuda.synchronize()
     try:
         done = 0
         for upto in (1, 2, 5, 12, 30):
-            A.run_steps_dev(ids, bits, upto - done, first_step=done, d_pcm_ring=None if feats is not None else ring,
-                            d_packets=a["pk"], d_pcm_out=a["out"], d_features=feats,
+            decode_only = feats is not None or pkring is not None
+            A.run_steps_dev(ids, bits, upto - done, first_step=done, d_pcm_ring=None if decode_only else ring,
+                            d_packets=a["pk"], d_pcm_out=a["out"], d_features=feats, d_packet_ring=pkring,
                             d_packet_bytes=a["nbytes"] if dtx else None, d_is_noise=a["flag"] if noise else None,
                             external_rate=ext, d_ext_out=a["ext"] if ext != 16000 else None,
-                            encode=feats is None, decode=True, dtx=dtx, decoder_noise=noise)
+                            encode=not decode_only, decode=True, dtx=dtx, decoder_noise=noise)
             for t in range(done, upto):
                 s = t & 1
                 if feats is not None:
-                    Bc.generate_dev(ids, feats, b["out"][s])
+                    Bc.generate_dev(ids, feats[t % 3], b["out"][s])
+                    continue
+                if pkring is not None:
+                    Bc.decode_dev(ids, pkring[t % 4], bits, b["out"][s])
                     continue
                 x = ring[t % T]
                 if ext != 16000:
@@ -180,7 +186,7 @@ def test_run_steps_equals_individual_calls(golden_dir, mode):
                     assert np.array_equal(la, lb), f"{mode}: packet lengths differ after {upto} steps"
                     live = la > 0
                     assert np.array_equal(a["pk"][s].cpu().numpy()[live], b["pk"][s].cpu().numpy()[live])
-                elif feats is None:
+                elif not decode_only:
                     assert torch.equal(a["pk"][s], b["pk"][s]), f"{mode}: packets differ after {upto} steps"
                 assert torch.equal(a["out"][s], b["out"][s]), f"{mode}: PCM differs after {upto} steps"
                 if ext != 16000:
