@@ -66,14 +66,14 @@ class StepsDesc(C.Structure):
 STEP_ENCODE, STEP_DECODE, STEP_DTX, STEP_DECODER_NOISE = 1, 2, 4, 8
 
 
-_lib = None
+_libs = {}
 
 
-def _load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+def _load(path=None):
+    """The C-ABI library (default: library_path()); a second path loads a build variant beside it (lyra_amd/variants/)."""
+    path = os.path.abspath(path or library_path())
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise LyraHipError(f"{path} not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "there is no CPU fallback")
@@ -134,7 +134,7 @@ def _load():
     L.lyra_hip_profile_read.argtypes = [vp, vp, vp]
     L.lyra_hip_debug_read.restype = C.c_long
     L.lyra_hip_debug_read.argtypes = [vp, ci, vp, C.c_long]
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -147,12 +147,12 @@ class LyraHip:
     """One GPU context: weights + per-stream state for `max_streams` streams."""
 
     def __init__(self, model_dir=None, device=0, max_streams=4096, requant="exact", weights_image=None,
-                 sub_batches=None):
+                 sub_batches=None, library=None):
         """sub_batches: split every `_dev` call into that many independent sub-batches on stream pairs of their own
         (the library's LYRA_HIP_SUBBATCHES switch, read when the context is created).  Pays when only ONE side is
         driven (decode-only at B = 8192: +6 %), not for interleaved encode + decode, where the two sides already
         overlap."""
-        self.L = _load()
+        self.L = _load(library)   # library: path of a build variant (experiments); default liblyra_hip.so
         h = C.c_void_p()
         mode = {"exact": 0, "gemmlowp_double": 1}[requant]
         saved = os.environ.get("LYRA_HIP_SUBBATCHES")

@@ -419,6 +419,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   float* e0 = c->d_e0 + (size_t)lo * 512;
   float* e1 = c->d_e1 + (size_t)lo * 512;
   float* codes = c->d_codes + (size_t)lo * 64;
+#ifdef LYRA_PARKED
   if (c->fused & 1) {   // the whole side in one launch (enc_side_kernel.hip)
     for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
     { ProfScope ps(c, K_ENC_SIDE, st_);
@@ -429,6 +430,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
     c->last_B_enc = B;
     return 0;
   }
+#endif
   { ProfScope ps(c, K_ENC_S0, st_);
     hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(enc_s0_threads()), enc_s0_lds_bytes(), st_,
                        M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0]); }
@@ -450,7 +452,12 @@ int launch_rvq_encode(lyra_hip_ctx* c, int k, int B, const float* d_feat, int nu
                       bool on_quantizer_stream = false) {
   hipStream_t st_ = on_quantizer_stream ? c->sq[k] : c->se[k];
   { ProfScope ps(c, K_RVQ_ENC, st_);
-    hipLaunchKernelGGL(c->rvq_wide ? rvq_encode_wide_kernel : rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(256), 0, st_, c->model.cb, d_feat, B,
+#ifdef LYRA_PARKED
+    const auto kern = c->rvq_wide ? rvq_encode_wide_kernel : rvq_encode_kernel;
+#else
+    const auto kern = rvq_encode_kernel;
+#endif
+    hipLaunchKernelGGL(kern, dim3(cdiv(B, 16)), dim3(256), 0, st_, c->model.cb, d_feat, B,
                        num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes); }
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -472,6 +479,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
   hipStream_t st_ = c->sd[k];
   float* d0 = c->d_d0 + (size_t)lo * 512;
   float* d1 = c->d_d1 + (size_t)lo * 1280;
+#ifdef LYRA_PARKED
   if (c->fused & 2) {   // the whole side in one launch (dec_side_kernel.hip)
     { ProfScope ps(c, K_DEC_SIDE, st_);
       hipLaunchKernelGGL(c->mode ? dec_side_dr_kernel : dec_side_kernel, dim3(cdiv(B, 8)), dim3(512), dec_side_lds_bytes(), st_,
@@ -481,6 +489,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
     c->last_B_dec = B;
     return 0;
   }
+#endif
   { ProfScope ps(c, K_DEC_S0, st_);
     hipLaunchKernelGGL(c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512),
                        dec_s0_lds_bytes(), st_,
@@ -654,9 +663,13 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     }
   }
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
-      set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(enc_side_kernel, enc_side_lds_bytes()) != hipSuccess ||
+      set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess ||
+#ifdef LYRA_PARKED
+      set_lds(enc_side_kernel, enc_side_lds_bytes()) != hipSuccess ||
       set_lds(enc_side_dr_kernel, enc_side_lds_bytes()) != hipSuccess || set_lds(dec_side_kernel, dec_side_lds_bytes()) != hipSuccess ||
-      set_lds(dec_side_dr_kernel, dec_side_lds_bytes()) != hipSuccess || set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
+      set_lds(dec_side_dr_kernel, dec_side_lds_bytes()) != hipSuccess ||
+#endif
+      set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, logmel_lds_bytes()) != hipSuccess)
@@ -666,8 +679,13 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_dr_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_dr_kernel");
     c->cw[K_ENC_SIDE] = code_warm_bytes("enc_side_dr_kernel"); c->cw[K_DEC_SIDE] = code_warm_bytes("dec_side_dr_kernel");
   }
+#ifdef LYRA_PARKED   // parked experiments: only in the `make EXTRA=-DLYRA_PARKED` variant
   if (const char* f = getenv("LYRA_HIP_FUSED")) c->fused = atoi(f);
   if (const char* f = getenv("LYRA_HIP_RVQ_WIDE")) c->rvq_wide = atoi(f);
+#else
+  if (getenv("LYRA_HIP_FUSED") && atoi(getenv("LYRA_HIP_FUSED")))
+    return bail(LYRA_HIP_EINVAL, "LYRA_HIP_FUSED: the one-launch-per-side kernels are not in this build (make EXTRA=-DLYRA_PARKED)");
+#endif
   for (int k = 0; k < c->nsub; ++k)
     if (enc_side_done(c, k) != 0) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
   *out = c;

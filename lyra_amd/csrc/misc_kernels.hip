@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 4) void rvq_encode_kernel(const float* __restr
                                                             int32_t* __restrict__ packet_bytes) {
   rvq_encode_body<2, false>(cb, feats, B, num_stages, indices, packets, mask_ids, packet_bytes);
 }
+#ifdef LYRA_PARKED   // the 104 KB / 244-VGPR form: measured, not shipped
 __global__ __launch_bounds__(256) void rvq_encode_wide_kernel(const float* __restrict__ cb, const float* __restrict__ feats,
                                                               int B, int num_stages, int32_t* __restrict__ indices,
                                                               uint8_t* __restrict__ packets,
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void rvq_encode_wide_kernel(const float* __res
                                                               int32_t* __restrict__ packet_bytes) {
   rvq_encode_body<8, true>(cb, feats, B, num_stages, indices, packets, mask_ids, packet_bytes);
 }
+#endif
 
 // RVQ decode: quantizer.tflite `decode` (233 ops) + the index extraction of DecodeToLossyFeatures
 // (residual_vector_quantizer.cc:140-157).  ((v0 + v1) + v2) + ... strictly left to right, masked

@@ -4,8 +4,20 @@
 //   VectorQuantizerInterface    lyra/vector_quantizer_interface.h:28-41
 //   GenerativeModelInterface + GenerativeModel FIFO base   lyra/generative_model_interface.h:32-134
 // (Interfaces are API, not implementation: they have to be spelled the same way to be a drop-in.)
+//
+// Inside a google/lyra checkout the reference's own headers are used instead (the #if below); this file is the
+// stand-alone spelling for builds without it.  The three abstract classes and the GenerativeModel FIFO base restate
+// declarations of google/lyra, Copyright 2021 Google LLC, licensed under the Apache License, Version 2.0
+// (http://www.apache.org/licenses/LICENSE-2.0); used here under that licence, "AS IS", without warranties or conditions
+// of any kind.
 #ifndef LYRA_AMD_HOST_PLUGIN_INTERFACES_H_
 #define LYRA_AMD_HOST_PLUGIN_INTERFACES_H_
+#if defined(__has_include) && __has_include("lyra/generative_model_interface.h") && \
+    __has_include("lyra/feature_extractor_interface.h") && __has_include("lyra/vector_quantizer_interface.h")
+#include "lyra/feature_extractor_interface.h"
+#include "lyra/generative_model_interface.h"
+#include "lyra/vector_quantizer_interface.h"
+#else
 #include <cstdint>
 #include <optional>
 #include <queue>
@@ -95,4 +107,5 @@ class GenerativeModel : public GenerativeModelInterface {
 
 }  // namespace codec
 }  // namespace chromemedia
+#endif  // reference headers not on the include path
 #endif

@@ -1,5 +1,6 @@
-"""GPU (-m gpu): the one-launch-per-side kernels (csrc/enc_side_kernel.hip, dec_side_kernel.hip; opt-in through
-LYRA_HIP_FUSED, bit 0 encoder side, bit 1 decoder side) against the seven-launch path: packets and PCM bit-identical
+"""GPU (-m gpu): the one-launch-per-side kernels (csrc/enc_side_kernel.hip, dec_side_kernel.hip; PARKED: only in the
+build variant lyra_amd/variants/parked.so = `make -C lyra_amd/csrc parked`, there opt-in through LYRA_HIP_FUSED, bit 0
+encoder side, bit 1 decoder side) against the seven-launch path: packets and PCM bit-identical
 over several hops (ring phases advance), ragged tile (B not a multiple of 8), scattered stream ids, both requantisation
 modes.  The seven-launch path itself is pinned to the oracle in test_gpu_parity.py, which can also be run whole with
 LYRA_HIP_FUSED=3 in the environment."""
@@ -11,12 +12,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+PARKED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lyra_amd", "variants", "parked.so")
+
+
 def _ctx(fused, requant):
     import lyra_amd
+    if not os.path.exists(PARKED):
+        pytest.skip("lyra_amd/variants/parked.so not built (make -C lyra_amd/csrc parked)")
     old = os.environ.get("LYRA_HIP_FUSED")
     os.environ["LYRA_HIP_FUSED"] = str(fused)
     try:
-        return lyra_amd.LyraHip(max_streams=4200, requant=requant)
+        return lyra_amd.LyraHip(max_streams=4200, requant=requant, library=PARKED)
     finally:
         if old is None:
             del os.environ["LYRA_HIP_FUSED"]
