@@ -256,6 +256,38 @@ typedef struct lyra_hip_steps {
 } lyra_hip_steps;
 int lyra_hip_run_steps_dev(lyra_hip_ctx* ctx, const lyra_hip_steps* steps);
 
+/* ---- Decoder twin: the device half of a batched LyraDecoder (lyra_amd/host/lyra_batch_codec.cc) ------------------------
+ * LyraDecoder::DecodeSamplesInternal (lyra_decoder.cc:228-315) keeps per stream the conditioned hop of the generative
+ * model and of the comfort-noise generator and hands out slices of them.  With these calls the two hops of every stream
+ * stay on the device (arrays indexed by stream id); the caller runs the reference's per-stream state machine on integers
+ * and describes each round of its loop.  All calls take HOST pointers, copy their arguments at call time, enqueue on
+ * the decode-side stream and do NOT synchronise -- except lyra_hip_twin_fetch, which ends the request with one
+ * device-to-host copy.  Per DecodeSamples call: packets + a few integers per stream up, the result down. */
+/* RunConditioning for streams whose next hop comes from a received packet (SetEncodedPacket's DecodeToLossyFeatures +
+ * AddFeatures happen here too, lyra_decoder.cc:198-206): packets [B][bytes of num_bits] -> generative-model hop of ids[b] */
+int lyra_hip_twin_decode(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const uint8_t* packets, int num_bits);
+/* ... from estimated features (packet loss concealment, ZeroFeatureEstimator::Estimate; lyra_decoder.cc:317-326) */
+int lyra_hip_twin_conceal(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B);
+/* comfort-noise hop of ids[b] from that stream's decoder-side noise estimate (lyra_decoder.cc:328-340) */
+int lyra_hip_twin_comfort_noise(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B);
+/* One pass of the reference's while loop for one stream: gen_n samples of the generative-model hop from gan_off and / or
+ * cng_n samples of the comfort-noise hop from cng_off (equal when both are non-zero: cross-faded with fade_progress
+ * `fade` stepping by fade_dir = +-1 per sample, MaybeOverlapAndInsert lyra_decoder.cc:342-373) to samples out_off.. of
+ * row `id` of the request's output.  noise_row >= 0: the slice completes a received hop; its 320 samples become input
+ * row noise_row of the lyra_hip_twin_noise call that follows (-1 otherwise). */
+typedef struct lyra_hip_twin_slice {
+  int32_t id, gan_off, gen_n, cng_off, cng_n, fade, fade_dir, out_off, noise_row;
+} lyra_hip_twin_slice;
+/* out_samples: internal-rate samples per stream of the whole request (the same in every call of one request) */
+int lyra_hip_twin_assemble(lyra_hip_ctx* ctx, const lyra_hip_twin_slice* slices, int B, int out_samples);
+/* NoiseEstimator::ReceiveSamples (lyra_decoder.cc:304-311) on the completed received hops marked by the preceding
+ * lyra_hip_twin_assemble; stream_ids[r] = the stream whose slice carried noise_row r */
+int lyra_hip_twin_noise(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B);
+/* Ends the request: rows 0..num_streams-1 of the output, resampled from 16 kHz to out_rate when they differ (the
+ * decoder-side resampler of streams 0..num_streams-1; any length, buffered_resampler.cc:120-128), into
+ * out [num_streams][num_internal_samples * out_rate / 16000]; synchronises.  num_internal_samples == 0 just synchronises. */
+int lyra_hip_twin_fetch(lyra_hip_ctx* ctx, int num_streams, int num_internal_samples, int out_rate, int16_t* out);
+
 /* The context's HIP streams (hipStream_t as void*), for event timing / ordering by the caller: encode side, decode
  * side, and the quantizer stream of lyra_hip_encode_dev / lyra_hip_encode_dtx_dev.  The packets of those two calls are
  * written on the QUANTIZER stream: lyra_hip_stream() does not cover them (it covers every other encode-side output).

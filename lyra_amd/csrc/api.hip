@@ -91,6 +91,19 @@ struct lyra_hip_ctx {
   int16_t* d_rs_in = nullptr;     // [cap][960] resampler staging (host-pointer entry points)
   int16_t* d_rs_out = nullptr;    // [cap][960]
   unsigned long long cng_seed = 0x4C797261ull;   // comfort-noise phase generator seed (lyra_hip_set_cng_seed)
+  // decoder twin (lyra_hip_twin_*, twin_api.inc): by-stream-id hop buffers and the staging arenas of its host arguments
+  int16_t* d_twin_gan = nullptr;   // [max_streams][320] conditioned hop of the generative model
+  int16_t* d_twin_cng = nullptr;   // [max_streams][320] conditioned hop of the comfort-noise generator
+  int16_t* d_twin_noise = nullptr; // [max_streams][320] dense: completed received hops for the noise estimator
+  int16_t* d_twin_out = nullptr;   // [max_streams][twin_out_n] the request being assembled (internal rate)
+  int16_t* d_twin_ext = nullptr;   // [max_streams][twin_ext_n] ... resampled
+  size_t twin_out_cap = 0, twin_ext_cap = 0;   // samples allocated
+  int twin_out_n = 0;              // row length of the request in flight (0: none)
+  float* d_twin_fade = nullptr;    // [TWIN_FADE_N] cross-fade weights
+  int32_t* d_twin_iota = nullptr;  // [max_streams] 0, 1, 2, ...
+  uint8_t* h_twin_args = nullptr;  // pinned
+  uint8_t* d_twin_args = nullptr;
+  size_t twin_args_cap = 0, twin_args_used = 0;
   int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
@@ -137,6 +150,7 @@ int sync_all(lyra_hip_ctx* c) {
   return 0;
 }
 
+void twin_free(lyra_hip_ctx* c);
 void free_scratch(lyra_hip_ctx* c) {
   void* ps[] = {c->d_ids, c->d_ids_dec, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_feat2, c->d_codes, c->d_idx, c->d_pkt,
                 c->d_lossy, c->d_d0, c->d_d1, c->d_pcm_out, c->d_mel, c->d_mel_enc, c->d_flag_enc, c->d_flag_dec,
@@ -699,6 +713,7 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
+  twin_free(c);
   free_scratch(c);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -931,7 +946,7 @@ static bool resample_design(int in_rate, int out_rate, ResampleP* P) {
 
 // side 0: the encoder's resampler slot (external rate -> 16 kHz, encode-side stream); 1: the decoder's (16 kHz -> external)
 int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
-                    int out_rate, int16_t* d_out, int* n_out_p) {
+                    int out_rate, int16_t* d_out, int* n_out_p, int in_stride = 0, int out_stride = 0) {
   ResampleP P;
   if (!resample_design(in_rate, out_rate, &P))
     return fail(c, LYRA_HIP_EINVAL, "unsupported resampling %d -> %d Hz (one side must be 16000; 8000/16000/32000/48000)", in_rate, out_rate);
@@ -942,7 +957,8 @@ int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, cons
   hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
   { ProfScope ps(c, K_RESAMPLE, st_);
     hipLaunchKernelGGL(resample_kernel, dim3(B), dim3(256), (size_t)(st::RS_TAPS - 1 + n_in) * 4, st_, P, d_ids, B,
-                       c->sm.base[side == 0 ? st::R_RS_E : st::R_RS_D], d_in, n_in, d_out, n_out); }
+                       c->sm.base[side == 0 ? st::R_RS_E : st::R_RS_D], d_in, n_in, in_stride > 0 ? in_stride : n_in, d_out,
+                       n_out, out_stride > 0 ? out_stride : n_out); }
   HIPCHK(c, hipGetLastError());
   if (n_out_p) *n_out_p = n_out;
   return 0;
@@ -1393,3 +1409,5 @@ long lyra_hip_debug_read(lyra_hip_ctx* c, int which, float* host_out, long capac
 }
 
 }  // extern "C"
+
+#include "twin_api.inc"

@@ -104,8 +104,18 @@ __global__ void noise_update_kernel(NoiseP P, const int32_t* ids, int B, uint8_t
                                     int32_t* is_noise_out, int32_t* masked_ids);
 // Resampler (lyra/resampler.cc): out/in = up/down, coef[phase][tap] oldest tap first (oracle lo_resampler_design)
 struct ResampleP { int up, down; float coef[3][40]; };
+// in_stride / out_stride: samples between consecutive streams' rows (>= n_in / n_out: a chunk of longer rows)
 __global__ void resample_kernel(ResampleP P, const int32_t* ids, int B, uint8_t* state, const int16_t* in, int n_in,
-                                int16_t* out, int n_out);
+                                int in_stride, int16_t* out, int n_out, int out_stride);
+// ---- device half of BatchLyraDecoder (host/lyra_batch_codec.cc): hop buffers stay on the device, the host keeps ints --
+// One slice of LyraDecoder::DecodeSamplesInternal's loop for one stream (lyra_decoder.cc:228-315): which samples of the
+// conditioned generative-model hop and of the comfort-noise hop go where, and how they are cross-faded
+// (MaybeOverlapAndInsert, :342-373).  Layout = lyra_hip_twin_slice (include/lyra_hip.h).
+struct TwinSlice { int32_t id, gan_off, gen_n, cng_off, cng_n, fade, fade_dir, out_off, noise_row; };
+constexpr int TWIN_FADE_LO = -640, TWIN_FADE_N = 1921;   // fade_progress range the weight table covers
+__global__ void twin_scatter_kernel(const int16_t* src, const int32_t* ids, int B, int16_t* dst);
+__global__ void twin_assemble_kernel(const TwinSlice* slices, int B, const int16_t* gan, const int16_t* cng,
+                                     const float* fade_w, int16_t* out, int out_stride, int16_t* noise_dense);
 __global__ void cng_kernel(const MelP* P, unsigned long long seed, const int32_t* ids, int B, uint8_t* state,
                            const uint8_t* noise_state, const float* features, int16_t* pcm);
 __global__ void noise_read_kernel(const int32_t* ids, int B, const uint8_t* state, int field_off, float* out);

@@ -490,14 +490,15 @@ __global__ __launch_bounds__(256) void noise_read_kernel(const int32_t* __restri
 // =============================================================================================
 __global__ __launch_bounds__(256) void resample_kernel(ResampleP P, const int32_t* __restrict__ ids, int B,
                                                         uint8_t* __restrict__ state, const int16_t* __restrict__ in,
-                                                        int n_in, int16_t* __restrict__ out, int n_out) {
+                                                        int n_in, int in_stride, int16_t* __restrict__ out, int n_out,
+                                                        int out_stride) {
   extern __shared__ __attribute__((aligned(16))) float rsb[];   // [RS_TAPS - 1 + n_in]
   constexpr int H = st::RS_TAPS - 1;
   const int b = blockIdx.x, tid = threadIdx.x;
   uint8_t* slot = state + (size_t)ids[b] * st::RS_BYTES;
   float* hist = reinterpret_cast<float*>(slot + st::RS_HIST);
   const int in_pos = *reinterpret_cast<const int*>(slot + st::RS_IN_POS);
-  for (int i = tid; i < H + n_in; i += 256) rsb[i] = i < H ? hist[i] : (float)in[(size_t)b * n_in + (i - H)];
+  for (int i = tid; i < H + n_in; i += 256) rsb[i] = i < H ? hist[i] : (float)in[(size_t)b * in_stride + (i - H)];
   __syncthreads();
   // first input index (0-based in this call) that yields an output when decimating
   const int first = P.down == 1 ? 0 : ((P.down - in_pos % P.down) % P.down);
@@ -509,13 +510,59 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleP P, const int32_
 #pragma unroll 5
     for (int j = 0; j < st::RS_TAPS; ++j) acc = acc + P.coef[p][j] * rsb[k + j];
     acc = acc < -32768.f ? -32768.f : (acc > 32767.f ? 32767.f : acc);   // ClipToInt16 (dsp_utils.h:56-72)
-    out[(size_t)b * n_out + o] = (int16_t)acc;
+    out[(size_t)b * out_stride + o] = (int16_t)acc;
   }
   __syncthreads();
   for (int i = tid; i < H; i += 256) hist[i] = rsb[n_in + i];
   // only the decimation phase is ever used: kept modulo 6 = lcm of the possible `down` factors (1, 2, 3), so the
   // counter never wraps out of phase however long the stream runs (the oracle keeps an unbounded counter)
   if (tid == 0) *reinterpret_cast<int*>(slot + st::RS_IN_POS) = (in_pos + n_in) % 6;
+}
+
+// =============================================================================================
+// Device half of the batched LyraDecoder twin (host/lyra_batch_codec.cc).  The host runs the reference's per-stream
+// state machine on integers only; the conditioned hops of the generative model and of the comfort-noise generator live
+// in two [max_streams][320] arrays indexed by stream id, and each round's slices are assembled here.
+// =============================================================================================
+// dst[ids[b]][0..320) = src[b][0..320): a dense batch result into the by-id hop buffer (8 bytes per thread)
+__global__ __launch_bounds__(128) void twin_scatter_kernel(const int16_t* __restrict__ src, const int32_t* __restrict__ ids,
+                                                            int B, int16_t* __restrict__ dst) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < 80) reinterpret_cast<uint2*>(dst + (size_t)ids[b] * 320)[t] = reinterpret_cast<const uint2*>(src + (size_t)b * 320)[t];
+}
+// One workgroup per slice.  RunModel slices + MaybeOverlapAndInsert (lyra_decoder.cc:342-373): where both hops
+// contribute, sample i is (int16)(gan * w + cng * (1.f - w)) with w = fade_w[fade + i * fade_dir] -- the table holds
+// (1.f + std::cos(fade * M_PI / 640)) / 2.f evaluated on the host in double exactly as the reference writes it, so the
+// mix is bit-identical to the reference's on that host; float products and sum are separate roundings
+// (-ffp-contract=off), the conversion truncates as the implicit float -> int16_t of push_back does.
+// noise_row >= 0: this slice completes a RECEIVED hop -- its 320 samples are what noise_estimator_->ReceiveSamples has
+// accumulated (:304-311); they are copied to row noise_row of the dense buffer the estimator kernel then reads.
+__global__ __launch_bounds__(256) void twin_assemble_kernel(const TwinSlice* __restrict__ slices, int B,
+                                                             const int16_t* __restrict__ gan,
+                                                             const int16_t* __restrict__ cng,
+                                                             const float* __restrict__ fade_w, int16_t* __restrict__ out,
+                                                             int out_stride, int16_t* __restrict__ noise_dense) {
+  const TwinSlice s = slices[blockIdx.x];
+  const int n = s.gen_n > s.cng_n ? s.gen_n : s.cng_n;
+  const int16_t* g = gan + (size_t)s.id * 320 + s.gan_off;
+  const int16_t* c = cng + (size_t)s.id * 320 + s.cng_off;
+  int16_t* o = out + (size_t)s.id * out_stride + s.out_off;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int16_t v;
+    if (s.cng_n == 0) v = g[i];
+    else if (s.gen_n == 0) v = c[i];
+    else {
+      const float w = fade_w[s.fade + i * s.fade_dir - TWIN_FADE_LO];
+      const float a = (float)g[i] * w;
+      const float b = (float)c[i] * (1.f - w);
+      v = (int16_t)(int)(a + b);
+    }
+    o[i] = v;
+  }
+  if (s.noise_row >= 0)
+    for (int i = threadIdx.x; i < 80; i += 256)
+      reinterpret_cast<uint2*>(noise_dense + (size_t)s.noise_row * 320)[i] =
+          reinterpret_cast<const uint2*>(gan + (size_t)s.id * 320)[i];
 }
 
 // =============================================================================================

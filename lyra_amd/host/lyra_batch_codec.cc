@@ -214,69 +214,83 @@ std::optional<std::vector<int16_t>> BatchLyraDecoder::DecodeSamples(int num_samp
     LOG(ERROR) << "Number of samples has to be non-negative.";
     return std::nullopt;
   }
-  if (sample_rate_hz_ == kBatchInternalSampleRateHz) return DecodeInternal(num_samples);
-  // BufferedResampler::FilterAndBuffer (buffered_resampler.cc:63-147); all streams are asked for the same number of
-  // samples every time, so their leftover buffers have the same length.
-  const int leftover = static_cast<int>(leftover_[0].size());
-  const int used = std::min(leftover, num_samples);
-  int internal = 0;
-  if (num_samples > leftover) {
-    const float ratio = static_cast<float>(sample_rate_hz_) / static_cast<float>(kBatchInternalSampleRateHz);
-    internal = static_cast<int>(std::ceil(static_cast<float>(num_samples - leftover) / ratio));
-  }
   std::vector<int16_t> out(static_cast<size_t>(num_streams_) * num_samples);
-  for (int s = 0; s < num_streams_; ++s) {
-    std::copy(leftover_[s].begin(), leftover_[s].begin() + used, out.begin() + static_cast<size_t>(s) * num_samples);
-    leftover_[s].erase(leftover_[s].begin(), leftover_[s].begin() + used);
-  }
-  auto internal_samples = DecodeInternal(internal);
-  if (!internal_samples.has_value()) return std::nullopt;
-  if (internal == 0) return out;
-  // the device resampler takes whole multiples of the decimation factor (16 kHz -> 8 kHz: pairs of samples)
-  const int down = sample_rate_hz_ < kBatchInternalSampleRateHz ? kBatchInternalSampleRateHz / sample_rate_hz_ : 1;
-  if (internal % down != 0 || internal > 960) {
-    LOG(ERROR) << "Could not decode samples: " << internal << " internal samples in one request are not supported.";
-    return std::nullopt;
-  }
-  const int produced = internal * sample_rate_hz_ / kBatchInternalSampleRateHz;
-  std::vector<int16_t> external(static_cast<size_t>(num_streams_) * produced);
-  const std::vector<int32_t> ids = Iota(num_streams_);
-  if (lyra_hip_resample(ctx_, LYRA_HIP_SIDE_DECODER, ids.data(), num_streams_, internal_samples->data(), internal,
-                        kBatchInternalSampleRateHz, sample_rate_hz_, external.data()) != 0) {
-    LOG(ERROR) << "Could not decode samples: " << lyra_hip_last_error(ctx_);
-    return std::nullopt;
-  }
-  const int to_copy = num_samples - used;
-  for (int s = 0; s < num_streams_; ++s) {
-    const int16_t* e = &external[static_cast<size_t>(s) * produced];
-    std::copy(e, e + to_copy, out.begin() + static_cast<size_t>(s) * num_samples + used);
-    leftover_[s].insert(leftover_[s].end(), e + to_copy, e + produced);
-  }
+  if (!DecodeSamples(num_samples, absl::Span<int16_t>(out.data(), out.size()))) return std::nullopt;
   return out;
 }
 
+bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
+  if (num_samples < 0) {
+    LOG(ERROR) << "Number of samples has to be non-negative.";
+    return false;
+  }
+  if (out.size() != static_cast<size_t>(num_streams_) * num_samples) {
+    LOG(ERROR) << "Output span has " << out.size() << " samples, expected " << static_cast<size_t>(num_streams_) * num_samples;
+    return false;
+  }
+  // BufferedResampler::FilterAndBuffer (buffered_resampler.cc:63-147); all streams are asked for the same number of
+  // samples every time, so their leftover buffers have the same length.  At 16 kHz there is no resampler and no buffer.
+  const bool resampling = sample_rate_hz_ != kBatchInternalSampleRateHz;
+  const int leftover = resampling ? static_cast<int>(leftover_[0].size()) : 0;
+  const int used = std::min(leftover, num_samples);
+  int internal = num_samples;
+  if (resampling) {
+    internal = 0;
+    if (num_samples > leftover) {
+      const float ratio = static_cast<float>(sample_rate_hz_) / static_cast<float>(kBatchInternalSampleRateHz);
+      internal = static_cast<int>(std::ceil(static_cast<float>(num_samples - leftover) / ratio));
+    }
+  }
+  if (!EnqueueInternal(internal)) return false;
+  const int produced = resampling ? static_cast<int>(static_cast<long>(internal) * sample_rate_hz_ / kBatchInternalSampleRateHz)
+                                  : internal;
+  // nothing to splice: the device result IS the answer
+  const bool direct = used == 0 && produced == num_samples;
+  int16_t* dst = out.data();
+  if (!direct) {
+    external_.resize(static_cast<size_t>(num_streams_) * produced);
+    dst = external_.data();
+  }
+  if (lyra_hip_twin_fetch(ctx_, num_streams_, internal, sample_rate_hz_, dst) != 0) {
+    LOG(ERROR) << "Could not decode samples: " << lyra_hip_last_error(ctx_);
+    return false;
+  }
+  if (direct) return true;
+  const int to_copy = num_samples - used;
+  for (int s = 0; s < num_streams_; ++s) {
+    int16_t* o = out.data() + static_cast<size_t>(s) * num_samples;
+    std::copy(leftover_[s].begin(), leftover_[s].begin() + used, o);
+    leftover_[s].erase(leftover_[s].begin(), leftover_[s].begin() + used);
+    if (produced > 0) {
+      const int16_t* e = &external_[static_cast<size_t>(s) * produced];
+      std::copy(e, e + to_copy, o + used);
+      leftover_[s].insert(leftover_[s].end(), e + to_copy, e + produced);
+    }
+  }
+  return true;
+}
+
 // LyraDecoder::DecodeSamplesInternal (lyra_decoder.cc:228-315) for all streams.  One pass of the reference's while loop
-// per stream and round; model runs are gathered per round.
-std::optional<std::vector<int16_t>> BatchLyraDecoder::DecodeInternal(int n) {
-  for (Stream& st : streams_) { st.out.clear(); st.out.reserve(n); }
+// per stream and round; the host decides (integers), the device computes: per round one conditioning call per group of
+// streams that start a hop, one call that cuts / cross-fades every stream's slice into the request's output, one
+// noise-estimator call for the received hops that completed.  Nothing synchronises here.
+bool BatchLyraDecoder::EnqueueInternal(int n) {
+  for (Stream& st : streams_) st.done = 0;
   std::vector<int32_t> active, need_packet[3], need_estimated, need_cng, need_noise;
   static const int kBits[3] = {64, 120, 184};
   std::vector<uint8_t> packets;
-  std::vector<int16_t> pcm;
-  std::vector<float> zeros;
-  std::vector<int32_t> flags;
+  std::vector<lyra_hip_twin_slice> slices;
   while (true) {
     active.clear();
     for (int s = 0; s < num_streams_; ++s)
-      if (static_cast<int>(streams_[s].out.size()) < n) active.push_back(s);
+      if (streams_[s].done < n) active.push_back(s);
     if (active.empty()) break;
     for (auto& v : need_packet) v.clear();
-    need_estimated.clear(); need_cng.clear(); need_noise.clear();
+    need_estimated.clear(); need_cng.clear(); need_noise.clear(); slices.clear();
     // ---- host: the state machine up to the two model calls --------------------------------------------------------
     for (int32_t s : active) {
       Stream& st = streams_[s];
-      st.n_gen = GetNumSamplesToGenerate(n, static_cast<int>(st.out.size()), st.concealment_progress, gan_available(st),
-                                         cng_available(st));
+      st.n_gen = GetNumSamplesToGenerate(n, st.done, st.concealment_progress, gan_available(st), cng_available(st));
       st.packet_received = gan_available(st) > 0 && st.concealment_progress == 0;
       if (st.packet_received) st.fade_direction = kFadeFromCNG;
       else if (st.concealment_progress == kConcealmentDurationSamples) st.fade_direction = kFadeToCNG;
@@ -294,7 +308,7 @@ std::optional<std::vector<int16_t>> BatchLyraDecoder::DecodeInternal(int n) {
         if (gan_available(st) == 0) st.queue.push_back(Entry{true, 0, {}});   // feature_estimator_->Estimate(): zeros
         if (st.gen_n > kBatchHopSamples - st.next_in_hop) {
           LOG(ERROR) << "Model could not be run on features.";
-          return std::nullopt;
+          return false;
         }
         if (st.next_in_hop == 0) {
           const Entry& e = st.queue.front();
@@ -302,7 +316,25 @@ std::optional<std::vector<int16_t>> BatchLyraDecoder::DecodeInternal(int n) {
           else need_packet[e.bits == 64 ? 0 : (e.bits == 120 ? 1 : 2)].push_back(s);
         }
       }
-      if (st.cng_n > 0 && cng_available(st) == 0) need_cng.push_back(s);   // RunComfortNoiseGenerator (:328-340)
+      if (st.cng_n > 0 && cng_available(st) == 0) {   // RunComfortNoiseGenerator (:328-340)
+        need_cng.push_back(s);
+        st.cng_has_hop = true;
+        st.cng_next = 0;
+      }
+      // RunModel slices + MaybeOverlapAndInsert (:342-373), and the noise estimator's share (:304-311): a received hop
+      // is handed over when its last sample has been generated
+      lyra_hip_twin_slice sl;
+      sl.id = s;
+      sl.gan_off = st.next_in_hop; sl.gen_n = st.gen_n;
+      sl.cng_off = st.cng_next; sl.cng_n = st.cng_n;
+      sl.fade = st.fade_progress; sl.fade_dir = st.fade_direction;
+      sl.out_off = st.done;
+      sl.noise_row = -1;
+      if (st.packet_received && st.next_in_hop + st.gen_n == kBatchHopSamples) {
+        sl.noise_row = static_cast<int32_t>(need_noise.size());
+        need_noise.push_back(s);
+      }
+      slices.push_back(sl);
     }
     // ---- device: RunConditioning of every stream that starts a hop ----------------------------------------------------
     for (int k = 0; k < 3; ++k) {
@@ -313,56 +345,33 @@ std::optional<std::vector<int16_t>> BatchLyraDecoder::DecodeInternal(int n) {
       for (size_t i = 0; i < ids.size(); ++i)
         std::copy(streams_[ids[i]].queue.front().packet.begin(), streams_[ids[i]].queue.front().packet.end(),
                   packets.begin() + i * nb);
-      pcm.resize(ids.size() * kBatchHopSamples);
-      if (lyra_hip_decode(ctx_, ids.data(), static_cast<int>(ids.size()), packets.data(), kBits[k], pcm.data()) != 0) {
+      if (lyra_hip_twin_decode(ctx_, ids.data(), static_cast<int>(ids.size()), packets.data(), kBits[k]) != 0) {
         LOG(ERROR) << "Model could not be run on features: " << lyra_hip_last_error(ctx_);
-        return std::nullopt;
-      }
-      for (size_t i = 0; i < ids.size(); ++i)
-        streams_[ids[i]].hop.assign(pcm.begin() + i * kBatchHopSamples, pcm.begin() + (i + 1) * kBatchHopSamples);
-    }
-    if (!need_estimated.empty()) {
-      zeros.assign(need_estimated.size() * LYRA_HIP_NUM_FEATURES, 0.f);
-      pcm.resize(need_estimated.size() * kBatchHopSamples);
-      if (lyra_hip_generate(ctx_, need_estimated.data(), static_cast<int>(need_estimated.size()), zeros.data(), pcm.data()) != 0) {
-        LOG(ERROR) << "Could not add estimated features to generative model: " << lyra_hip_last_error(ctx_);
-        return std::nullopt;
-      }
-      for (size_t i = 0; i < need_estimated.size(); ++i)
-        streams_[need_estimated[i]].hop.assign(pcm.begin() + i * kBatchHopSamples, pcm.begin() + (i + 1) * kBatchHopSamples);
-    }
-    if (!need_cng.empty()) {
-      pcm.resize(need_cng.size() * kBatchHopSamples);
-      // AddFeatures(noise_estimator_->noise_estimate()) + conditioning: the device reads the estimate in place
-      if (lyra_hip_comfort_noise(ctx_, need_cng.data(), static_cast<int>(need_cng.size()), nullptr, pcm.data()) != 0) {
-        LOG(ERROR) << "Could not generate comfort noise: " << lyra_hip_last_error(ctx_);
-        return std::nullopt;
-      }
-      for (size_t i = 0; i < need_cng.size(); ++i) {
-        Stream& st = streams_[need_cng[i]];
-        st.cng_hop.assign(pcm.begin() + i * kBatchHopSamples, pcm.begin() + (i + 1) * kBatchHopSamples);
-        st.cng_has_hop = true;
-        st.cng_next = 0;
+        return false;
       }
     }
-    // ---- host: RunModel slices, MaybeOverlapAndInsert (:342-373), bookkeeping --------------------------------------------
+    if (!need_estimated.empty() &&
+        lyra_hip_twin_conceal(ctx_, need_estimated.data(), static_cast<int>(need_estimated.size())) != 0) {
+      LOG(ERROR) << "Could not add estimated features to generative model: " << lyra_hip_last_error(ctx_);
+      return false;
+    }
+    // AddFeatures(noise_estimator_->noise_estimate()) + conditioning: the device reads the estimate in place, BEFORE
+    // this round's noise-estimator update, as the reference's statement order has it
+    if (!need_cng.empty() && lyra_hip_twin_comfort_noise(ctx_, need_cng.data(), static_cast<int>(need_cng.size())) != 0) {
+      LOG(ERROR) << "Could not generate comfort noise: " << lyra_hip_last_error(ctx_);
+      return false;
+    }
+    if (lyra_hip_twin_assemble(ctx_, slices.data(), static_cast<int>(slices.size()), n) != 0) {
+      LOG(ERROR) << "Could not overlap comfort noise: " << lyra_hip_last_error(ctx_);
+      return false;
+    }
+    if (!need_noise.empty() && lyra_hip_twin_noise(ctx_, need_noise.data(), static_cast<int>(need_noise.size())) != 0) {
+      LOG(ERROR) << "Could not update noise estimator on decoder output: " << lyra_hip_last_error(ctx_);
+      return false;
+    }
+    // ---- host: bookkeeping of GenerativeModel::GenerateSamples (generative_model_interface.h:88-101) -------------------
     for (int32_t s : active) {
       Stream& st = streams_[s];
-      const int16_t* audio = st.gen_n > 0 ? &st.hop[st.next_in_hop] : nullptr;
-      const int16_t* noise = st.cng_n > 0 ? &st.cng_hop[st.cng_next] : nullptr;
-      if (noise == nullptr) {
-        st.out.insert(st.out.end(), audio, audio + st.gen_n);
-      } else if (audio == nullptr) {
-        st.out.insert(st.out.end(), noise, noise + st.cng_n);
-      } else {
-        int fade = st.fade_progress;
-        for (int i = 0; i < st.gen_n; ++i) {
-          const float w = (1.f + std::cos(fade * M_PI / kFadeDurationSamples)) / 2.f;
-          st.out.push_back(static_cast<int16_t>(audio[i] * w + noise[i] * (1.f - w)));
-          fade += st.fade_direction;
-        }
-      }
-      if (st.packet_received) st.noise_in.insert(st.noise_in.end(), audio, audio + st.gen_n);
       if (st.gen_n > 0) {
         st.next_in_hop += st.gen_n;
         if (st.next_in_hop == kBatchHopSamples) { st.next_in_hop = 0; st.queue.pop_front(); }
@@ -372,27 +381,10 @@ std::optional<std::vector<int16_t>> BatchLyraDecoder::DecodeInternal(int n) {
         if (st.cng_next == kBatchHopSamples) { st.cng_next = 0; st.cng_has_hop = false; }
       }
       st.fade_progress = st.next_fade;
-      if (static_cast<int>(st.noise_in.size()) == kBatchHopSamples) need_noise.push_back(s);
-    }
-    // ---- device: noise_estimator_->ReceiveSamples for every stream whose received hop is complete (:304-311) ---------
-    if (!need_noise.empty()) {
-      pcm.resize(need_noise.size() * kBatchHopSamples);
-      for (size_t i = 0; i < need_noise.size(); ++i) {
-        Stream& st = streams_[need_noise[i]];
-        std::copy(st.noise_in.begin(), st.noise_in.end(), pcm.begin() + i * kBatchHopSamples);
-        st.noise_in.clear();
-      }
-      flags.resize(need_noise.size());
-      if (lyra_hip_noise_receive(ctx_, LYRA_HIP_SIDE_DECODER, need_noise.data(), static_cast<int>(need_noise.size()),
-                                 pcm.data(), flags.data()) != 0) {
-        LOG(ERROR) << "Could not update noise estimator on decoder output: " << lyra_hip_last_error(ctx_);
-        return std::nullopt;
-      }
+      st.done += st.n_gen;
     }
   }
-  std::vector<int16_t> result(static_cast<size_t>(num_streams_) * n);
-  for (int s = 0; s < num_streams_; ++s) std::copy(streams_[s].out.begin(), streams_[s].out.end(), result.begin() + static_cast<size_t>(s) * n);
-  return result;
+  return true;
 }
 
 }  // namespace codec

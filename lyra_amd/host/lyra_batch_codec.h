@@ -11,9 +11,12 @@
 //  * decoder: per-stream packet FIFO, DecodeSamples(n) for any n (requests may straddle hops), packet-loss
 //    concealment with estimated (zero) features, comfort noise from the decoder-side noise estimate, cosine
 //    cross-fades, noise-estimator updates on received hops only (lyra_decoder.cc:172-373).
-// The control flow is the reference's, statement for statement, run for every stream; in each round of the decode
-// loop the streams that need a new hop from the generative model / the comfort-noise generator / a noise-estimator
-// update are collected and served by ONE device call each.
+// The control flow is the reference's, statement for statement, run for every stream ON INTEGERS ONLY: the conditioned
+// hops of the generative model and of the comfort-noise generator stay on the device (include/lyra_hip.h "Decoder
+// twin").  In each round of the decode loop the streams that need a new hop from the generative model / the
+// comfort-noise generator / a noise-estimator update are collected and served by ONE device call each, the round's
+// slices and cross-fades by one more; nothing synchronises until the request's single device-to-host copy.  Per
+// DecodeSamples call: the queued packets and a few integers per stream go up, the result comes down.
 #ifndef LYRA_AMD_HOST_LYRA_BATCH_CODEC_H_
 #define LYRA_AMD_HOST_LYRA_BATCH_CODEC_H_
 #include <cstdint>
@@ -88,6 +91,9 @@ class BatchLyraDecoder {
   // LyraDecoder::DecodeSamples (lyra_decoder.cc:211-315) for every stream: any num_samples >= 0 at sample_rate_hz();
   // streams without a packet conceal, then fade to comfort noise.  Returns num_streams * num_samples samples.
   std::optional<std::vector<int16_t>> DecodeSamples(int num_samples);
+  // The same into caller memory (num_streams * num_samples samples; pinned memory avoids a staging copy): no allocation
+  // on the steady-state path.  false + LOG(ERROR) where the other form returns nullopt.
+  bool DecodeSamples(int num_samples, absl::Span<int16_t> out);
   int sample_rate_hz() const { return sample_rate_hz_; }
   int num_channels() const { return 1; }
   int frame_rate() const { return kBatchFrameRate; }
@@ -101,21 +107,18 @@ class BatchLyraDecoder {
   struct Entry { bool estimated; int bits; std::vector<uint8_t> packet; };
   struct Stream {
     std::deque<Entry> queue;              // generative model: queued conditioning inputs
-    int next_in_hop = 0;                  // generative model: next_sample_in_hop_
-    std::vector<int16_t> hop;             // generative model: the conditioned hop
+    int next_in_hop = 0;                  // generative model: next_sample_in_hop_ (the hop itself lives on the device)
     bool cng_has_hop = false;             // comfort noise generator: one hop at most is ever queued
     int cng_next = 0;
-    std::vector<int16_t> cng_hop;
     int concealment_progress = 0;
     int fade_progress = 0;
     int fade_direction = -1;              // kFadeFromCNG (lyra_decoder.h FadeDirection)
-    std::vector<int16_t> noise_in;        // decoded samples waiting for the noise estimator (ReceiveSamples buffer)
-    std::vector<int16_t> out;             // this call's internal-rate result
+    int done = 0;                         // internal-rate samples of the current request produced so far
     // scratch of the current round
     int n_gen = 0, gen_n = 0, cng_n = 0, next_fade = 0;
     bool packet_received = false;
   };
-  std::optional<std::vector<int16_t>> DecodeInternal(int num_internal_samples);   // DecodeSamplesInternal, all streams
+  bool EnqueueInternal(int num_internal_samples);   // DecodeSamplesInternal for all streams, enqueued on the device
   int gan_available(const Stream& s) const { return (int)s.queue.size() * kBatchHopSamples - s.next_in_hop; }
   int cng_available(const Stream& s) const { return s.cng_has_hop ? kBatchHopSamples - s.cng_next : 0; }
 
@@ -124,6 +127,7 @@ class BatchLyraDecoder {
   int num_streams_;
   std::vector<Stream> streams_;
   std::vector<std::vector<int16_t>> leftover_;   // BufferedResampler::leftover_samples_ per stream (same length for all)
+  std::vector<int16_t> external_;                // a request's resampled samples when leftovers have to be spliced in
 };
 
 }  // namespace codec

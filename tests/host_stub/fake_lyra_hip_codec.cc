@@ -4,6 +4,7 @@
 // updates -- runs in the CPU test suite against oracle/lyra_codec_model.py driven by the SAME fake arithmetic
 // (tests/host_stub/fake_kit.py).  The fakes are integer formulas with small per-stream counters, so that a call made
 // for the wrong stream, at the wrong time or a wrong number of times changes the output.  Never linked into the product.
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -12,8 +13,17 @@
 
 #include "../../include/lyra_hip.h"
 
-struct PerStream { long enc_hops = 0, dec_hops = 0, cng_hops = 0, noise_calls[2] = {0, 0}; };
-struct lyra_hip_ctx { int max_streams; std::map<int32_t, PerStream> st; };
+struct PerStream {
+  long enc_hops = 0, dec_hops = 0, cng_hops = 0, noise_calls[2] = {0, 0};
+  int16_t gan[320] = {}, cng[320] = {};   // "Decoder twin": the conditioned hops that the real library keeps on the device
+};
+struct lyra_hip_ctx {
+  int max_streams;
+  std::map<int32_t, PerStream> st;
+  int out_n = 0;                          // the request being assembled
+  std::vector<int16_t> out;               // [max_streams][out_n]
+  std::vector<std::vector<int16_t>> noise_rows;
+};
 
 namespace {
 bool is_noise_hop(const int16_t* pcm) {
@@ -29,7 +39,8 @@ void fake_packet(PerStream& s, const int16_t* pcm, int nbytes, uint8_t* pk) {
 
 extern "C" {
 int lyra_hip_create(const char*, int, int max_streams, int, lyra_hip_ctx** out) {
-  *out = new lyra_hip_ctx{max_streams, {}};
+  *out = new lyra_hip_ctx{};
+  (*out)->max_streams = max_streams;
   return 0;
 }
 void lyra_hip_destroy(lyra_hip_ctx* c) { delete c; }
@@ -96,6 +107,78 @@ int lyra_hip_comfort_noise(lyra_hip_ctx* c, const int32_t* ids, int B, const flo
       pcm[b * 320 + i] = (int16_t)(2000 + (i & 31) + 3 * (int)s.noise_calls[LYRA_HIP_SIDE_DECODER] + 11 * (int)s.cng_hops);
     s.cng_hops++;
   }
+  return 0;
+}
+
+// ---- "Decoder twin" (include/lyra_hip.h): same formulas as lyra_hip_decode / _generate / _comfort_noise above, the hops
+// kept per stream, slices cut and cross-faded as MaybeOverlapAndInsert writes it (lyra_decoder.cc:342-373) ------------------
+int lyra_hip_twin_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* packets, int num_bits) {
+  const int nbytes = (num_bits + 7) / 8;
+  for (int b = 0; b < B; ++b) {
+    PerStream& s = c->st[ids[b]];
+    for (int i = 0; i < 320; ++i) s.gan[i] = (int16_t)((int)packets[b * nbytes + i % nbytes] * 64 + i + 7 * (int)s.dec_hops);
+    s.dec_hops++;
+  }
+  return 0;
+}
+int lyra_hip_twin_conceal(lyra_hip_ctx* c, const int32_t* ids, int B) {
+  for (int b = 0; b < B; ++b) {
+    PerStream& s = c->st[ids[b]];
+    for (int i = 0; i < 320; ++i) s.gan[i] = (int16_t)(-500 + i + 7 * (int)s.dec_hops);
+    s.dec_hops++;
+  }
+  return 0;
+}
+int lyra_hip_twin_comfort_noise(lyra_hip_ctx* c, const int32_t* ids, int B) {
+  for (int b = 0; b < B; ++b) {
+    PerStream& s = c->st[ids[b]];
+    for (int i = 0; i < 320; ++i)
+      s.cng[i] = (int16_t)(2000 + (i & 31) + 3 * (int)s.noise_calls[LYRA_HIP_SIDE_DECODER] + 11 * (int)s.cng_hops);
+    s.cng_hops++;
+  }
+  return 0;
+}
+int lyra_hip_twin_assemble(lyra_hip_ctx* c, const lyra_hip_twin_slice* sl, int B, int out_samples) {
+  if (c->out_n == 0) {
+    c->out_n = out_samples;
+    c->out.assign((size_t)c->max_streams * out_samples, 0);
+  } else if (c->out_n != out_samples) {
+    return LYRA_HIP_EINVAL;
+  }
+  c->noise_rows.clear();
+  for (int b = 0; b < B; ++b) {
+    const lyra_hip_twin_slice& x = sl[b];
+    PerStream& s = c->st[x.id];
+    int16_t* o = &c->out[(size_t)x.id * out_samples + x.out_off];
+    const int n = x.gen_n > x.cng_n ? x.gen_n : x.cng_n;
+    int fade = x.fade;
+    for (int i = 0; i < n; ++i) {
+      if (x.cng_n == 0) o[i] = s.gan[x.gan_off + i];
+      else if (x.gen_n == 0) o[i] = s.cng[x.cng_off + i];
+      else {
+        const float w = (1.f + std::cos(fade * M_PI / 640)) / 2.f;
+        o[i] = static_cast<int16_t>(s.gan[x.gan_off + i] * w + s.cng[x.cng_off + i] * (1.f - w));
+        fade += x.fade_dir;
+      }
+    }
+    if (x.noise_row >= 0) {
+      if ((size_t)x.noise_row >= c->noise_rows.size()) c->noise_rows.resize(x.noise_row + 1);
+      c->noise_rows[x.noise_row].assign(s.gan, s.gan + 320);
+    }
+  }
+  return 0;
+}
+int lyra_hip_twin_noise(lyra_hip_ctx* c, const int32_t* ids, int B) {
+  if ((size_t)B != c->noise_rows.size()) return LYRA_HIP_EINVAL;
+  for (int b = 0; b < B; ++b) c->st[ids[b]].noise_calls[LYRA_HIP_SIDE_DECODER]++;
+  return 0;
+}
+int lyra_hip_twin_fetch(lyra_hip_ctx* c, int num_streams, int n, int out_rate, int16_t* out) {
+  if (n > 0 && c->out_n != n) return LYRA_HIP_EINVAL;
+  const int n_out = (int)((long)n * out_rate / 16000);
+  for (int s = 0; s < num_streams && n > 0; ++s)
+    for (int j = 0; j < n_out; ++j) out[(size_t)s * n_out + j] = c->out[(size_t)s * n + (int)((long)j * 16000 / out_rate)];
+  c->out_n = 0;
   return 0;
 }
 }
