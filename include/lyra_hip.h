@@ -319,6 +319,9 @@ int lyra_hip_profile_sample(lyra_hip_ctx* ctx, int every);
 int lyra_hip_profile_kernel_count(void);
 const char* lyra_hip_profile_kernel_name(int i);
 int lyra_hip_profile_read(lyra_hip_ctx* ctx, double* total_ms, long* launches);
+/* start / end (ms, relative to the first recorded span's start) of every span recorded since the last read; call
+ * BEFORE lyra_hip_profile_read.  Returns the number of spans written (<= cap) or a negative error. */
+int lyra_hip_profile_timeline(lyra_hip_ctx* ctx, int cap, int* kernel_ids, float* start_ms, float* end_ms);
 
 /* Test hook: copies stage-boundary activations of the LAST extract/generate call (device scratch) to host.
  * which: 0 enc stage0 out [B][4][128], 1 enc stage1 out [B][2][256], 2 enc int8 codes [B][64] (as f32),

@@ -649,7 +649,12 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   // quantizer runs beside decoder stage 0, both VALU-bound); with this it stays in the fast one.
   int prio_lo = 0, prio_hi = 0;
   if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
-  const int prio[3] = {prio_lo, getenv("LYRA_HIP_FLAT_PRIO") ? prio_lo : prio_hi, prio_lo};
+  int prio[3] = {prio_lo, getenv("LYRA_HIP_FLAT_PRIO") ? prio_lo : prio_hi, prio_lo};
+  if (const char* p = getenv("LYRA_HIP_PRIO")) {   // experiment hook: "e,d,q" each 0 = lowest .. 2 = highest
+    int v[3] = {0, 2, 0};
+    sscanf(p, "%d,%d,%d", &v[0], &v[1], &v[2]);
+    for (int i = 0; i < 3; ++i) prio[i] = v[i] >= 2 ? prio_hi : (v[i] == 1 ? (prio_lo + prio_hi) / 2 : prio_lo);
+  }
   const unsigned evflags = hipEventDisableTiming | (getenv("LYRA_HIP_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
   for (int k = 0; k < c->nsub; ++k)
     if (hipStreamCreateWithPriority(&c->se[k], hipStreamNonBlocking, prio[0]) != hipSuccess ||
@@ -1387,6 +1392,22 @@ int lyra_hip_profile_read(lyra_hip_ctx* c, double* total_ms, long* launches) {
   }
   c->spans.clear();
   return 0;
+}
+
+// Start / end of every recorded span in ms relative to the FIRST span's start (HIP events compare across streams of one
+// device); call before lyra_hip_profile_read, which recycles the events.  -> spans written (at most cap).
+int lyra_hip_profile_timeline(lyra_hip_ctx* c, int cap, int* kernel_ids, float* start_ms, float* end_ms) {
+  if (!c || !kernel_ids || !start_ms || !end_ms) return LYRA_HIP_EINVAL;
+  int rc = sync_all(c);
+  if (rc) return rc;
+  int n = 0;
+  for (auto& sp : c->spans) {
+    if (n >= cap) break;
+    HIPCHK(c, hipEventElapsedTime(&start_ms[n], c->spans.front().a, sp.a));
+    HIPCHK(c, hipEventElapsedTime(&end_ms[n], c->spans.front().a, sp.b));
+    kernel_ids[n++] = sp.kid;
+  }
+  return n;
 }
 
 long lyra_hip_debug_read(lyra_hip_ctx* c, int which, float* host_out, long capacity) {

@@ -24,7 +24,7 @@ def main():
     for p in which:
         out = f"/tmp/pmc_{p}"
         cmd = ["rocprofv3", "--pmc"] + PASSES[p].split() + ["--kernel-trace", "-d", out, "-o", "x", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-kernel-table", "--steps", "4", "--warmup", "2"]
+               os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-kernel-table", "--steps", "4", "--warmup", "2", "--latency-steps", "0"]
         subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
         db = os.path.join(out, "x_results.db")
         if not os.path.exists(db):
