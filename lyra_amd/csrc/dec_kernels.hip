@@ -31,7 +31,14 @@ __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_kernel(const DecS0
                                                        uint8_t* __restrict__ state, float* __restrict__ out0,
                                                        const uint8_t* __restrict__ packets, int num_stages,
                                                        const float* __restrict__ cb, int code_bytes) {
+#ifdef LYRA_TLOOP   // experiment: T hops per launch (timing only: same inputs every trip)
+  for (int t_ = 0; t_ < LYRA_TLOOP; ++t_) {
+    dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
+    __syncthreads();
+  }
+#else
   dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
+#endif
 }
 __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_dr_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                           const int32_t* __restrict__ ids, int B,
@@ -49,7 +56,14 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
                                                                           const int32_t* __restrict__ ids, int B,
                                                                           uint8_t* __restrict__ state, float* __restrict__ out1,
                                                                           int code_bytes) {
+#ifdef LYRA_TLOOP   // experiment: T hops per launch (timing only: same inputs every trip)
+  for (int t_ = 0; t_ < LYRA_TLOOP; ++t_) {
+    dec_s1_body(*Pp, in0, ids, B, state, out1, code_bytes);
+    __syncthreads();
+  }
+#else
   dec_s1_body(*Pp, in0, ids, B, state, out1, code_bytes);
+#endif
 }
 
 #ifdef LYRA_WAVE_PRIVATE
