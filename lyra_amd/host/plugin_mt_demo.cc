@@ -4,6 +4,7 @@
 // pcm_in is [frames][streams][320] int16; thread s owns the extractor / quantizer / generative model of stream s and
 // runs all frames of it.  Writes one '0'/'1' line per (frame, stream) and the decoded PCM in the input's layout; prints
 // how many plugin calls became how many device calls.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
   std::vector<int16_t> out(pcm.size());
   std::vector<int> rc(n, 0);
   std::vector<std::thread> th;
+  const auto t0 = std::chrono::steady_clock::now();
   for (int s = 0; s < n; ++s)
     th.emplace_back([&, s] {
       for (int f = 0; f < frames && rc[s] == 0; ++f) {
@@ -58,6 +60,7 @@ int main(int argc, char** argv) {
       }
     });
   for (auto& t : th) t.join();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (int s = 0; s < n; ++s)
     if (rc[s]) { std::fprintf(stderr, "stream %d failed (%d)\n", s, rc[s]); return rc[s]; }
   std::ofstream bits_out(argv[5]);
@@ -66,5 +69,9 @@ int main(int argc, char** argv) {
   pcm_out.write(reinterpret_cast<const char*>(out.data()), out.size() * 2);
   const HipCallStats st = GetHipCallStats();
   std::printf("plugin_calls %ld device_calls %ld largest_batch %ld\n", st.calls, st.device_calls, st.largest_batch);
+  // one hop per plugin call and stream, every call a blocking host call (the reference's plugin contract): what the
+  // call-combining layer makes of `n` threads driving `n` codecs
+  std::printf("threads %d frames_per_stream %d seconds %.4f frames_per_s %.1f (extract + quantize + dequantize + generate per frame)\n",
+              n, frames, secs, (double)n * frames / secs);
   return 0;
 }
