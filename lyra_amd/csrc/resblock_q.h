@@ -92,7 +92,6 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
   const int m = lane & 15, q = lane >> 4;
   const int w4 = tid & 63, s = tid >> 6;
   const int R2 = 2 * d;
-  (void)tb;
   LYRA_TSTAMP(tb + 0);
   {  // a = LeakyReLU(X); depthwise over [a(t-2d), a(t-d), a(t)]; the ring row t-2d is replaced by a(t)
     const int base = (cx.sphase[s] * 2) % R2;
@@ -120,14 +119,22 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
     i32x4 acc[1][2];
     auto aoff = [&](int i, int c) { return m * QS + c * 64 + q * 16; };
     gemm_i8<1, 2, 4>(QD, aoff, pw.w + (wave * 2) * 4 * 64, acc);
+#ifdef LYRA_TIMING
+    if (tb == 94) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][3])); LYRA_TSTAMP(122); }   // GEMM done (results awaited)
+#endif
+    // all eight table reads before the first store: an int8 store between two LDS reads of unknown aliasing makes the
+    // compiler drain the LDS queue each time (eight serial round trips instead of one pipelined batch)
+    int8_t r8[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        r8[j][e] = (int8_t)lut8(lm, clamp8(requant(acc[0][j][e] + pre.pb[j], pre.pM[j], pre.psh[j], mode) + pw.zout));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int c8 = clamp8(requant(acc[0][j][e] + pre.pb[j], pre.pM[j], pre.psh[j], mode) + pw.zout);
-        QP[(q * 4 + e) * QS + n] = (int8_t)lut8(lm, c8);
-      }
+      for (int e = 0; e < 4; ++e) QP[(q * 4 + e) * QS + n] = r8[j][e];
     }
   }
   __syncthreads();
@@ -137,15 +144,31 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
     const int g = wave >> 1;
     auto aoff = [&](int i, int c) { return m * QS + g * 64 + q * 16; };
     gemm_i8<1, 2, 1>(QP, aoff, cv.w + (wave * 2) * 64, acc);
+#ifdef LYRA_TIMING
+    if (tb == 94) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][3])); LYRA_TSTAMP(123); }
+#endif
+    // reads batched ahead of the stores for the same reason: residual bytes, then both ADD operand tables, then stores
+    int xo[2][4], ta[2][4], tb2[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
 #pragma unroll
+      for (int e = 0; e < 4; ++e) xo[j][e] = (int)QX[(q * 4 + e) * QS + n];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int row = q * 4 + e;
         int c8 = clamp8(requant(acc[0][j][e] + pre.cb[j], pre.cM[j], pre.csh[j], mode) + cv.zout);
-        QX[row * QS + n] = (int8_t)add_q_lut(addlut, c8, (int)QX[row * QS + n], add);
+        ta[j][e] = addlut[c8 + 128];
+        tb2[j][e] = addlut[256 + xo[j][e] + 128];
       }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int n = (wave * 2 + j) * 16 + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        QX[(q * 4 + e) * QS + n] = (int8_t)clamp8(mbqm_double(ta[j][e] + tb2[j][e], add.mo, add.so) + add.zo);
     }
   }
   __syncthreads();

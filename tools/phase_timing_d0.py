@@ -18,6 +18,7 @@ for i in range(81, 89):
     print(f"  {names[i-80]:22s} {t[i] - t[i-1]:7d}")
 for base in (90, 94):
     print("  resblock@", base, " lrelu+dw+state", t[base+1]-t[base], " pw gemm+epi", t[base+2]-t[base+1], " cv gemm+add", t[base+3]-t[base+2])
+print("  resblock@94 split: pw phase = gemm (LDS A + L2 weight fragments + 8 MFMA)", t[122]-t[95], "+ epilogue", t[96]-t[122], "; cv phase = gemm", t[123]-t[96], "+ epilogue (requant + ADD tables)", t[97]-t[123])
 wall = (t[121] - t[120]) / 100.0
 print(f"  WG0 wall {wall:.1f} us  -> shader clock {(t[88]-t[80])/wall/1e3:.2f} GHz")
 idx = [i for i in range(128) if t[i] != 0 and i < 100]
