@@ -670,12 +670,22 @@ static void push_state_q(float* state, int S, const int8_t* a, int T, int C, flo
   for (int i = 0; i < S * C; ++i) state[i] = dequantize_f(buf8[(size_t)T * C + i], s, z);
 }
 
+/* Int16ToUnitScalar (dsp_utils.h:106-108) and UnitToInt16Scalar + ClipToInt16Scalar (dsp_utils.h:54-88): scale, clip,
+ * the implicit float -> int16_t conversion (truncation) */
+static inline float int16_to_unit(int16_t x) { return -(float)x / -32768.f; }
+static inline int16_t unit_to_int16(float u) {
+  float v = u * 32768.f;
+  v = v < -32768.f ? -32768.f : v;
+  v = v > 32767.f ? 32767.f : v;
+  return (int16_t)v;
+}
+
 void lo_encode_frame(const lo_model* m, lo_stream* s, const int16_t* pcm, float* feat) {
   const enc_model* E = &m->enc;
   float x[20 * 64], s0[38 * 64], s1[38 * 64], s2[20 * 64];
   float in[368];
   memcpy(in, s->e_first, sizeof(float) * 48);
-  for (int i = 0; i < HOP; ++i) in[48 + i] = -(float)pcm[i] / -32768.f; /* dsp_utils.h:106-108 */
+  for (int i = 0; i < HOP; ++i) in[48 + i] = int16_to_unit(pcm[i]);
   memcpy(s->e_first, in + 320, sizeof(float) * 48);
   conv_f_run(&E->first, in, 368, x);                      /* [20][64] */
   tap(s, x, 20 * 64);
@@ -866,13 +876,12 @@ void lo_decode_frame(const lo_model* m, lo_stream* s, const float* feat, int16_t
   overlap_state(out, 368, 1, s->d_up3, 48, D->sub3);
   for (int i = 0; i < HOP; ++i) {
     if (pcm_f) pcm_f[i] = out[i];
-    /* dsp_utils.h:54-88: scale, clip, C truncation */
-    float v = out[i] * 32768.f;
-    v = v < -32768.f ? -32768.f : v;
-    v = v > 32767.f ? 32767.f : v;
-    pcm[i] = (int16_t)v;
+    pcm[i] = unit_to_int16(out[i]);
   }
 }
+/* the two conversions on their own, for the check against the reference's dsp_utils.h compiled in oracle/_ref */
+void lo_unit_to_int16(const float* in, long n, int16_t* out) { for (long i = 0; i < n; ++i) out[i] = unit_to_int16(in[i]); }
+void lo_int16_to_unit(const int16_t* in, long n, float* out) { for (long i = 0; i < n; ++i) out[i] = int16_to_unit(in[i]); }
 
 /* ------------------------------------------------------------------------ */
 /* log-mel (log_mel_spectrogram_extractor_impl.cc:96-126)     */

@@ -47,6 +47,8 @@ def lib():
         L.lo_rvq_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.lo_noise_new.restype = C.c_void_p
         L.lo_noise_new.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.lo_unit_to_int16.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        L.lo_int16_to_unit.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         L.lo_noise_new_rate.restype = C.c_void_p
         L.lo_noise_new_rate.argtypes = [C.c_int]
         L.lo_noise_free.argtypes = [C.c_void_p]

@@ -49,6 +49,10 @@ def load(oracle):
         L.ref_packet_pack.argtypes = [C.c_char_p, vp, C.c_int]
         L.ref_packet_unpack.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         L.ref_version.restype = C.c_char_p
+        L.ref_unit_to_int16.argtypes = [vp, C.c_long, vp]
+        L.ref_int16_to_unit.argtypes = [vp, C.c_long, vp]
+        L.ref_log_spectral_distance.restype = C.c_float
+        L.ref_log_spectral_distance.argtypes = [vp, vp, C.c_int]
         _lib = L
     _lib.ref_set_model(oracle.h)
     return _lib
@@ -164,3 +168,28 @@ def unpack(oracle, packet):
     buf = C.create_string_buffer(256)
     n = L.ref_packet_unpack(_p(packet), packet.size, buf, 256)
     return None if n < 0 else buf.value.decode()
+
+
+def unit_to_int16(oracle, x):
+    """UnitToInt16Scalar over an array (dsp_utils.h:76-88)."""
+    L = load(oracle)
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.int16)
+    L.ref_unit_to_int16(_p(x), x.size, _p(out))
+    return out
+
+
+def int16_to_unit(oracle, x):
+    """Int16ToUnitScalar<float> over an array (dsp_utils.h:104-108)."""
+    L = load(oracle)
+    x = np.ascontiguousarray(x, np.int16)
+    out = np.empty(x.shape, np.float32)
+    L.ref_int16_to_unit(_p(x), x.size, _p(out))
+    return out
+
+
+def log_spectral_distance(oracle, a, b):
+    """LogSpectralDistance (dsp_utils.cc:27-41)."""
+    L = load(oracle)
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return float(L.ref_log_spectral_distance(_p(a), _p(b), a.size))

@@ -6,6 +6,7 @@
 //   NoiseEstimator (lyra/noise_estimator.cc:144-245) with its log-mel front end injected (ref_shims/ shadow)
 //   BufferedResampler (lyra/buffered_resampler.cc)   leftover bookkeeping of the decoder's output resampler
 //   Packet<> (lyra/packet.h:91-146), GenerativeModel FIFO (generative_model_interface.h:45-134), ZeroFeatureEstimator
+//   Int16ToUnit / UnitToInt16 / ClipToInt16 / LogSpectralDistance (lyra/dsp_utils.h:41-108, dsp_utils.cc:27-41)
 //
 // What cannot be compiled here -- TFLite + XNNPACK behind the three model wrappers, audio_dsp behind the resampler, the
 // log-mel extractor and the comfort-noise generator -- is injected as components computed by the CPU oracle
@@ -22,6 +23,7 @@
 
 #include "absl/types/span.h"
 #include "lyra/buffered_resampler.h"
+#include "lyra/dsp_utils.h"
 #include "lyra/comfort_noise_generator.h"
 #include "lyra/feature_extractor_interface.h"
 #include "lyra/generative_model_interface.h"
@@ -246,5 +248,14 @@ int ref_packet_unpack(const uint8_t* bytes, int n, char* bits_out, int cap) {
 int ref_packet_size_to_bits(int packet_size) { return PacketSizeToNumQuantizedBits(packet_size); }
 int ref_bitrate_to_bits(int bitrate) { return BitrateToNumQuantizedBits(bitrate); }
 const char* ref_version(void) { return GetVersionString().c_str(); }
+
+// dsp_utils.h:54-108 and dsp_utils.cc:27-41, as the model wrappers and the integration test use them
+void ref_unit_to_int16(const float* in, long n, int16_t* out) { for (long i = 0; i < n; ++i) out[i] = UnitToInt16Scalar(in[i]); }
+void ref_int16_to_unit(const int16_t* in, long n, float* out) { for (long i = 0; i < n; ++i) out[i] = Int16ToUnitScalar<float>(in[i]); }
+float ref_log_spectral_distance(const float* a, const float* b, int n) {
+  const auto d = LogSpectralDistance(absl::MakeConstSpan(a, (size_t)n), absl::MakeConstSpan(b, (size_t)n));
+  return d.has_value() ? *d : -1.f;
+}
+int ref_convert_num_samples(int n, int from_hz, int to_hz) { return ConvertNumSamplesBetweenSampleRate(n, from_hz, to_hz); }
 
 }  // extern "C"

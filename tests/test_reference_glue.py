@@ -55,6 +55,30 @@ def test_packet_layout_is_the_references(ref, oracle_exact):
     assert ref.unpack(oracle_exact, np.zeros(9, np.uint8)) is None       # not a packet size the codec knows
 
 
+def test_sample_conversions_are_the_references(ref, oracle_exact):
+    """Row a7: the oracle's int16 <-> unit-float conversions (fused into enc_s0's prologue and dec_s2's epilogue on the
+    GPU, where PCM equality with the oracle covers them) against dsp_utils.h compiled from the reference: every int16
+    value; 2^22 floats across (-1.5, 1.5) incl. every clipping edge, +-inf and values far out of range; the
+    log-spectral distance the integration test thresholds (dsp_utils.cc:27-41)."""
+    import ctypes as C
+    L = oracle_exact.L
+    allv = np.arange(-32768, 32768, dtype=np.int32).astype(np.int16)
+    mine = np.empty(allv.size, np.float32)
+    L.lo_int16_to_unit(allv.ctypes.data_as(C.c_void_p), allv.size, mine.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(mine, ref.int16_to_unit(oracle_exact, allv))
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-1.5, 1.5, 1 << 22).astype(np.float32),
+                        (np.arange(-40000, 40000, dtype=np.float32) + np.float32(0.5)) / np.float32(32768.0),
+                        np.arange(-40000, 40000, dtype=np.float32) / np.float32(32768.0),
+                        np.array([np.inf, -np.inf, 1e30, -1e30, 0.0, -0.0, 32767.0 / 32768.0, 0.99999994, -1.0, 1.0], np.float32)])
+    got = np.empty(x.size, np.int16)
+    L.lo_unit_to_int16(x.ctypes.data_as(C.c_void_p), x.size, got.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(got, ref.unit_to_int16(oracle_exact, x))
+    a, b = rng.normal(0, 1, 160).astype(np.float32), rng.normal(0, 1, 160).astype(np.float32)
+    want = np.float32(10) * np.sqrt(np.float32(((a - b) ** 2).astype(np.float32).sum(dtype=np.float32)) / np.float32(160))
+    assert abs(ref.log_spectral_distance(oracle_exact, a, b) - float(want)) < 1e-4
+
+
 def test_noise_estimator_restatement_vs_reference_class(ref, oracle_exact, golden_dir):
     """oracle NoiseEstimator (lyra_oracle.c, what noise_update_kernel is checked against) vs
     chromemedia::codec::NoiseEstimator compiled from noise_estimator.cc: is_noise identical at every hop.  Estimate and
