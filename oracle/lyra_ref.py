@@ -49,6 +49,9 @@ def load(oracle):
         L.ref_packet_pack.argtypes = [C.c_char_p, vp, C.c_int]
         L.ref_packet_unpack.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         L.ref_version.restype = C.c_char_p
+        L.ref_encode_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+        L.ref_decode_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int,
+                                      C.c_char_p]
         L.ref_unit_to_int16.argtypes = [vp, C.c_long, vp]
         L.ref_int16_to_unit.argtypes = [vp, C.c_long, vp]
         L.ref_log_spectral_distance.restype = C.c_float
@@ -193,3 +196,34 @@ def log_spectral_distance(oracle, a, b):
     L = load(oracle)
     a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
     return float(L.ref_log_spectral_distance(_p(a), _p(b), a.size))
+
+
+def make_model_dir(path):
+    """A directory LyraEncoder::Create / LyraDecoder::Create accept as model_path: AreParamsSupported
+    (lyra_config.h:117-168) probes for the three asset names and reads lyra_config.binarypb (identifier = 3); the
+    factories of oracle/ref_glue.cc never open the assets."""
+    os.makedirs(path, exist_ok=True)
+    for name in ("quantizer.tflite", "lyragan.tflite", "soundstream_encoder.tflite"):
+        open(os.path.join(path, name), "wb").close()
+    with open(os.path.join(path, "lyra_config.binarypb"), "wb") as f:
+        f.write(bytes([0x08, 0x03]))
+    return str(path)
+
+
+def encode_file(oracle, wav_path, out_path, bitrate, model_dir, enable_dtx=False):
+    """chromemedia::codec::EncodeFile (cli_example/encoder_main_lib.cc:99-140)."""
+    L = load(oracle)
+    return bool(L.ref_encode_file(str(wav_path).encode(), str(out_path).encode(), bitrate, 0, int(enable_dtx),
+                                  str(model_dir).encode()))
+
+
+def decode_file(oracle, encoded_path, out_path, sample_rate_hz, bitrate, model_dir, cng_seed=0, randomize_requests=False,
+                loss_starts=(), loss_durations=()):
+    """chromemedia::codec::DecodeFile (cli_example/decoder_main_lib.cc:142-222); loss pattern in seconds
+    (FixedPacketLossModel) or none."""
+    L = load(oracle)
+    L.ref_set_cng_seed(cng_seed)
+    a = np.ascontiguousarray(loss_starts, np.float32)
+    b = np.ascontiguousarray(loss_durations, np.float32)
+    return bool(L.ref_decode_file(str(encoded_path).encode(), str(out_path).encode(), sample_rate_hz, bitrate,
+                                  int(randomize_requests), 0.0, 1.0, _p(a), _p(b), a.size, str(model_dir).encode()))

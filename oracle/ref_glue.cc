@@ -6,6 +6,7 @@
 //   NoiseEstimator (lyra/noise_estimator.cc:144-245) with its log-mel front end injected (ref_shims/ shadow)
 //   BufferedResampler (lyra/buffered_resampler.cc)   leftover bookkeeping of the decoder's output resampler
 //   Packet<> (lyra/packet.h:91-146), GenerativeModel FIFO (generative_model_interface.h:45-134), ZeroFeatureEstimator
+//   EncodeFile / DecodeFile (cli_example/encoder_main_lib.cc, decoder_main_lib.cc) + the two packet-loss models
 //   Int16ToUnit / UnitToInt16 / ClipToInt16 / LogSpectralDistance (lyra/dsp_utils.h:41-108, dsp_utils.cc:27-41)
 //
 // What cannot be compiled here -- TFLite + XNNPACK behind the three model wrappers, audio_dsp behind the resampler, the
@@ -23,6 +24,8 @@
 
 #include "absl/types/span.h"
 #include "lyra/buffered_resampler.h"
+#include "lyra/cli_example/decoder_main_lib.h"
+#include "lyra/cli_example/encoder_main_lib.h"
 #include "lyra/dsp_utils.h"
 #include "lyra/comfort_noise_generator.h"
 #include "lyra/feature_extractor_interface.h"
@@ -255,6 +258,21 @@ void ref_int16_to_unit(const int16_t* in, long n, float* out) { for (long i = 0;
 float ref_log_spectral_distance(const float* a, const float* b, int n) {
   const auto d = LogSpectralDistance(absl::MakeConstSpan(a, (size_t)n), absl::MakeConstSpan(b, (size_t)n));
   return d.has_value() ? *d : -1.f;
+}
+// cli_example/encoder_main_lib.cc:99-140 / decoder_main_lib.cc:142-222: whole files through LyraEncoder::Create /
+// LyraDecoder::Create.  model_path has to hold files named like the reference's assets (lyra_config.h:117-168 probes
+// for them and reads lyra_config.binarypb); their content is never read -- the factories above build the components.
+int ref_encode_file(const char* wav_path, const char* out_path, int bitrate, int enable_preprocessing, int enable_dtx,
+                    const char* model_path) {
+  return EncodeFile(wav_path, out_path, bitrate, enable_preprocessing != 0, enable_dtx != 0, model_path) ? 1 : 0;
+}
+int ref_decode_file(const char* encoded_path, const char* out_path, int sample_rate_hz, int bitrate, int randomize_requests,
+                    float packet_loss_rate, float average_burst_length, const float* loss_starts,
+                    const float* loss_durations, int n_loss, const char* model_path) {
+  const PacketLossPattern pattern(std::vector<float>(loss_starts, loss_starts + n_loss),
+                                  std::vector<float>(loss_durations, loss_durations + n_loss));
+  return DecodeFile(encoded_path, out_path, sample_rate_hz, bitrate, randomize_requests != 0, packet_loss_rate,
+                    average_burst_length, pattern, model_path) ? 1 : 0;
 }
 int ref_convert_num_samples(int n, int from_hz, int to_hz) { return ConvertNumSamplesBetweenSampleRate(n, from_hz, to_hz); }
 

@@ -177,6 +177,66 @@ def test_reference_decoder_accepts_any_request_size(ref, oracle_exact):
     assert not d.SetEncodedPacket(np.zeros(9, np.uint8))  # unsupported packet size
 
 
+def _write_wav(path, pcm, rate=16000):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(np.asarray(pcm, np.int16).tobytes())
+
+
+def _read_wav(path):
+    import wave
+    with wave.open(str(path), "rb") as w:
+        return np.frombuffer(w.readframes(w.getnframes()), np.int16), w.getframerate()
+
+
+def test_reference_file_codec_vs_model(ref, oracle_exact, golden_dir, tmp_path):
+    """The reference's EncodeFile / DecodeFile (cli_example/*_main_lib.cc, compiled from the reference tree; LyraEncoder /
+    LyraDecoder created through their public Create) against the per-stream model: .lyra bytes, decoded samples, the
+    trailing partial hop dropped, a fixed packet-loss pattern (FixedPacketLossModel), random request sizes."""
+    from oracle import lyra_codec_model as M
+    model_dir = ref.make_model_dir(tmp_path / "model")
+    speech = np.load(os.path.join(golden_dir, "sample_wavs.npz"))["sample1_16kHz"]
+    pcm = speech[:320 * 60 + 123]
+    _write_wav(tmp_path / "in.wav", pcm)
+    assert ref.encode_file(oracle_exact, tmp_path / "in.wav", tmp_path / "a.lyra", 6000, model_dir)
+    got = np.fromfile(tmp_path / "a.lyra", np.uint8)
+    enc = M.RefLyraEncoder(oracle_exact, 16000, 120, False)
+    want = np.concatenate([enc.Encode(pcm[h * 320:(h + 1) * 320]) for h in range(60)])
+    assert np.array_equal(got, want)
+    # no loss, whole hops
+    assert ref.decode_file(oracle_exact, tmp_path / "a.lyra", tmp_path / "a.wav", 16000, 6000, model_dir, cng_seed=5)
+    out, rate = _read_wav(tmp_path / "a.wav")
+    dec = M.RefLyraDecoder(oracle_exact, 16000, cng_seed=5)
+    ref_out = []
+    for h in range(60):
+        dec.SetEncodedPacket(want[h * 15:(h + 1) * 15])
+        ref_out.append(dec.DecodeSamples(320))
+    assert rate == 16000 and np.array_equal(out, np.concatenate(ref_out))
+    # packets lost from 0.25 s for 0.25 s = hops [13, 25) (fixed_packet_loss_model.cc:33-40 rounds both ends up):
+    # concealment, fade, comfort noise, fade back; 48 kHz output
+    assert ref.decode_file(oracle_exact, tmp_path / "a.lyra", tmp_path / "b.wav", 48000, 6000, model_dir, cng_seed=5,
+                           loss_starts=[0.25], loss_durations=[0.25])
+    out, rate = _read_wav(tmp_path / "b.wav")
+    dec = M.RefLyraDecoder(oracle_exact, 48000, cng_seed=5)
+    ref_out, lost = [], 0
+    for h in range(60):
+        if 13 <= h < 25:
+            lost += 1
+        else:
+            dec.SetEncodedPacket(want[h * 15:(h + 1) * 15])
+        ref_out.append(dec.DecodeSamples(960))
+    ref_out = np.concatenate(ref_out)
+    assert rate == 48000 and out.size == ref_out.size and lost == 12
+    d = np.abs(out.astype(int) - ref_out.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3      # 1 LSB where comfort noise is mixed in (expf, see above)
+    # a file without a single full hop: nothing to encode, and DecodeFile refuses an empty stream (decoder_main_lib.cc:186)
+    _write_wav(tmp_path / "tiny.wav", pcm[:100])
+    assert ref.encode_file(oracle_exact, tmp_path / "tiny.wav", tmp_path / "tiny.lyra", 6000, model_dir)
+    assert os.path.getsize(tmp_path / "tiny.lyra") == 0
+    assert not ref.decode_file(oracle_exact, tmp_path / "tiny.lyra", tmp_path / "tiny_out.wav", 16000, 6000, model_dir)
+
+
 # ---- GPU: the product vs the reference's classes -------------------------------------------------------------------
 @pytest.mark.gpu
 def test_gpu_packets_vs_reference_encoder(ref, oracle_exact, golden_dir):
@@ -260,3 +320,34 @@ def test_gpu_batch_twins_vs_reference_classes(ref, oracle_exact, golden_dir, tmp
                 n_exact += int((d == 0).sum()); n_total += k
                 saw_cng = saw_cng or decs[s].is_comfort_noise()
     assert pos == out.size and worst <= 2 and n_exact / n_total > 0.97 and saw_cng
+
+
+@pytest.mark.gpu
+def test_gpu_file_transcode_vs_reference_file_codec(ref, oracle_exact, golden_dir, tmp_path):
+    """EncodeFiles / DecodeFiles (lyra_amd/host/lyra_file_codec.cc: several WAV files of different lengths transcoded
+    together on the device) against the reference's EncodeFile / DecodeFile run file by file: identical .lyra bytes,
+    identical decoded samples."""
+    import lyra_amd
+    demo = os.path.join(ROOT, "lyra_amd", "file_demo")
+    assert os.path.exists(demo), "lyra_amd/file_demo not built (__graft_entry__.build())"
+    model_dir = ref.make_model_dir(tmp_path / "model")
+    speech = np.load(os.path.join(golden_dir, "sample_wavs.npz"))
+    a, b = speech["sample1_16kHz"], speech["sample2_16kHz"]
+    files = {"one": a[:320 * 40 + 17], "two": b[4000:4000 + 320 * 23], "three": a[20000:20000 + 320 * 31 + 300]}
+    wavs = []
+    for name, pcm in files.items():
+        _write_wav(tmp_path / f"{name}.wav", pcm)
+        wavs.append(str(tmp_path / f"{name}.wav"))
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    r = subprocess.run([demo, lyra_amd.default_model_dir(), "9200", str(out_dir)] + wavs, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    for name in files:
+        assert ref.encode_file(oracle_exact, tmp_path / f"{name}.wav", tmp_path / f"{name}.ref.lyra", 9200, model_dir)
+        assert np.array_equal(np.fromfile(out_dir / f"{name}.lyra", np.uint8),
+                              np.fromfile(tmp_path / f"{name}.ref.lyra", np.uint8)), name
+        assert ref.decode_file(oracle_exact, out_dir / f"{name}.lyra", tmp_path / f"{name}.ref.wav", 16000, 9200, model_dir)
+        got, _ = _read_wav(out_dir / f"{name}_decoded.wav")
+        want, _ = _read_wav(tmp_path / f"{name}.ref.wav")
+        assert np.array_equal(got, want), name
