@@ -181,6 +181,14 @@ __device__ __forceinline__ void wg_schedule_hint() {
 // the compiler emits counted s_waitcnt (the prefetches stay in flight across the MFMA block).
 //   KS   = K-chunk stride between a tile's fragments in memory (> KC when only part of the packed K range is run)
 //   ZERO = start the chains from 0; otherwise acc carries values in (a chain continued from an earlier GEMM)
+// LYRA_WEIGHT_ALIAS (timing experiment only, results are wrong): every K chunk of a tile re-reads the tile's first
+// weight fragment -- the GEMM's L2 -> CU weight traffic collapses to one 1 KB fragment per wave and N tile while the
+// instruction stream stays the same.  What that buys is what weight bandwidth costs.
+#ifdef LYRA_WEIGHT_ALIAS
+#define LYRA_WCHUNK(c) 0
+#else
+#define LYRA_WCHUNK(c) (c)
+#endif
 template <int MTW, int NTW, int KC, int KS = KC, bool ZERO = true,
           int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
 __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* bfrag_generic,
@@ -198,7 +206,7 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
   for (int p = 0; p < PF; ++p)
     if (p < KC) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[p][j] = bfrag[(j * KS + p) * 64];
+      for (int j = 0; j < NTW; ++j) bq[p][j] = bfrag[(j * KS + LYRA_WCHUNK(p)) * 64];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[p][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, p));
     }
@@ -207,7 +215,7 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
     if (c + PF < KC) {
       const int sl = (c + PF) % (PF + 1);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[sl][j] = bfrag[(j * KS + c + PF) * 64];
+      for (int j = 0; j < NTW; ++j) bq[sl][j] = bfrag[(j * KS + LYRA_WCHUNK(c + PF)) * 64];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[sl][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c + PF));
     }
