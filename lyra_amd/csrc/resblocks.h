@@ -18,7 +18,12 @@ struct TileCtx {
   int stride;          // bytes per stream in this region
   // A stream id of -1 masks a slot (DTX: the hop is noise, the encoder must not run for that stream,
   // lyra_encoder.cc:131-141): it reads stream 0's state like a tail slot reads the last stream's, and writes nothing.
+#ifdef LYRA_STATE_ALIAS   // timing experiment only (results are wrong): every stream uses one of 64 state slots -- the
+                          // per-stream state never leaves L2, so what the HBM state traffic costs shows as the difference
+  __device__ __forceinline__ uint8_t* sbase(int s) const { return state + (size_t)(max(sids[s], 0) & 63) * stride; }
+#else
   __device__ __forceinline__ uint8_t* sbase(int s) const { return state + (size_t)max(sids[s], 0) * stride; }
+#endif
   __device__ __forceinline__ bool valid(int s) const { return s < nvalid && sids[s] >= 0; }
 };
 
