@@ -241,7 +241,10 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
       internal = static_cast<int>(std::ceil(static_cast<float>(num_samples - leftover) / ratio));
     }
   }
-  if (!EnqueueInternal(internal)) return false;
+  if (!EnqueueInternal(internal)) {
+    (void)lyra_hip_twin_fetch(ctx_, num_streams_, 0, sample_rate_hz_, nullptr);   // abandon the half-assembled request
+    return false;
+  }
   const int produced = resampling ? static_cast<int>(static_cast<long>(internal) * sample_rate_hz_ / kBatchInternalSampleRateHz)
                                   : internal;
   // nothing to splice: the device result IS the answer
