@@ -230,17 +230,18 @@ int check_ids_host(lyra_hip_ctx* c, const int32_t* ids, int B) {
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // machine-code size of each kernel (generated at build time by code_sizes.sh from the kernel objects)
-struct CodeSize { const char* name; int bytes; };
+struct CodeSize { const char* name; int bytes; int getpc; };   // getpc: offset of the kernel's s_getpc_b64 (= bytes: none found)
 const CodeSize kCodeSizes[] = {
 #include "code_sizes.inc"
-    {"", 0}};
-// what a kernel is told to warm: its size minus a margin (s_getpc at the first statement is not byte 0 of the function,
-// and the range must not run past the end of the code object); disabled with LYRA_HIP_NO_CODE_WARM=1
+    {"", 0, 0}};
+// What a kernel is told to warm: from the 128-byte line of its s_getpc to the end of the function.  The offset of that
+// instruction is read back from the kernel object at build time (code_sizes.sh), so the range ends inside the function
+// wherever the compiler scheduled the s_getpc; disabled with LYRA_HIP_NO_CODE_WARM=1
 int code_warm_bytes(const char* kernel) {
   static const bool off = getenv("LYRA_HIP_NO_CODE_WARM") != nullptr;
   if (off) return 0;
   for (const CodeSize& c : kCodeSizes)
-    if (strcmp(c.name, kernel) == 0) return c.bytes > 2048 ? c.bytes - 1024 : 0;
+    if (strcmp(c.name, kernel) == 0) return c.bytes > 2048 && c.bytes > c.getpc ? c.bytes - c.getpc : 0;
   return 0;
 }
 

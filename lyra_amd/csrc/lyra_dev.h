@@ -337,7 +337,8 @@ __device__ __forceinline__ WarmTok<MAXIT> l2_warm(const WarmRange& w) {
 // chain.  Measured (tools/pipeline_probe.py): inside the sustained encode+decode pipeline the two largest kernels
 // (enc_s2 29 KB, dec_s0 42 KB of code) ran 64 / 82 us instead of 40 / 45 us on most boxes of the pool; pulling
 // the code into L2 with data loads at kernel start brings them back to 51 / 61 us.
-// `code_bytes` comes from the host (symbol size of this kernel, minus a margin: s_getpc is not byte 0 of the function).
+// `code_bytes` comes from the host: the symbol size of this kernel minus the offset of this very s_getpc_b64 inside it,
+// both read back from the kernel object at build time (code_sizes.sh) -- the range cannot run past the function.
 template <int NT>
 __device__ __forceinline__ WarmTok<1> code_warm(int code_bytes) {
   const uint64_t pc = __builtin_amdgcn_s_getpc();
