@@ -351,3 +351,38 @@ def test_gpu_file_transcode_vs_reference_file_codec(ref, oracle_exact, golden_di
         got, _ = _read_wav(out_dir / f"{name}_decoded.wav")
         want, _ = _read_wav(tmp_path / f"{name}.ref.wav")
         assert np.array_equal(got, want), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate", [48000, 8000, 16000])
+def test_gpu_batch_decoder_large_requests_vs_reference_class(ref, oracle_exact, golden_dir, tmp_path, rate):
+    """DecodeSamples with requests far beyond one hop (the reference's BufferedResampler / LyraDecoder accept any
+    num_samples): several hops per request -- so most of what is played is concealment and comfort noise -- including
+    requests of more than 960 internal samples, which the device resampler serves in chunks (lyra_hip_twin_fetch)."""
+    from test_batch_codec_semantics import _run_session
+    bitrate, bits = 6000, 120
+    pcm, _ = _session(golden_dir, rate, bitrate, T=14)
+    n, hop = pcm.shape[1], rate // 50
+    big = [3 * hop + 20, 5 * hop + 8, 1, 2 * hop, 7, 6 * hop + 2]        # at 48 kHz: up to 5,762 samples = 1,921 internal
+    if rate == 8000:
+        big = [2 * k for k in big]                                          # keep the 16 -> 8 kHz decimation whole
+    script = [("1111", [big[t % len(big)]]) for t in range(pcm.shape[0])]
+    packets, lengths, out = _run_session(tmp_path, oracle_exact, rate, bitrate, False, pcm, script)
+    encs = [ref.LyraEncoder(oracle_exact, rate, bits, False) for _ in range(n)]
+    decs = [ref.LyraDecoder(oracle_exact, rate, 0x4C797261 ^ s) for s in range(n)]
+    pos = worst = n_diff = n_total = 0
+    for t, (mask, sizes) in enumerate(script):
+        for s in range(n):
+            p = encs[s].Encode(pcm[t, s])
+            assert np.array_equal(packets[t, s], p), (t, s)
+            decs[s].SetEncodedPacket(p)
+        for k in sizes:
+            got = out[pos:pos + n * k].reshape(n, k)
+            pos += n * k
+            for s in range(n):
+                want = decs[s].DecodeSamples(k)
+                assert want is not None and want.size == k
+                d = np.abs(got[s].astype(int) - want.astype(int))
+                worst = max(worst, int(d.max()))
+                n_diff += int((d > 0).sum()); n_total += k
+    assert pos == out.size and worst <= 2 and n_diff / n_total < 0.03, (worst, n_diff, n_total)
