@@ -66,14 +66,12 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) {
 // ---------------------------------------------------------------------------------------------
 // SaturatingRoundingDoublingHighMul: gemmlowp nudges by +2^30 (ab >= 0) or 1-2^30 (ab < 0) and divides by 2^31
 // truncating toward zero -- which is exactly floor((ab + 2^30) / 2^31), i.e. round-half-up, for either sign.
-// Done on the 32-bit halves of the product (v_mul_lo / v_mul_hi_i32 + carry) instead of 64-bit VALU sequences.
+// One v_mad_i64_i32 for the nudged product and one v_alignbit_b32 for bits [62:31] (round 2 did this on the 32-bit
+// halves with a carry: eight instructions).  `b` is a quantized multiplier in [2^30, 2^31) wherever this is called
+// (model.hip builds them with QuantizeMultiplier), so gemmlowp's one saturating case, a == b == INT32_MIN, cannot occur.
 __device__ __forceinline__ int32_t srdhm(int32_t a, int32_t b) {
-  const uint32_t lo = (uint32_t)a * (uint32_t)b;
-  int32_t hi = __mulhi(a, b);
-  const uint32_t lo2 = lo + 0x40000000u;
-  hi += (lo2 < lo) ? 1 : 0;
-  const int32_t r = (int32_t)(((uint32_t)hi << 1) | (lo2 >> 31));
-  return (a == INT32_MIN && b == INT32_MIN) ? INT32_MAX : r;
+  const int64_t p = (int64_t)a * (int64_t)b + (1ll << 30);
+  return (int32_t)(p >> 31);
 }
 __device__ __forceinline__ int32_t rdivpot(int32_t x, int e) {
   const int32_t mask = (int32_t)((1u << e) - 1u);
