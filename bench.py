@@ -141,6 +141,10 @@ def parse(argv=None):
     ap.add_argument("--per-call", action="store_true",
                     help="drive the individual `_dev` entry points from Python instead of lyra_hip_run_steps_dev")
     ap.add_argument("--latency-steps", type=int, default=200, help="isolated steps for the latency distribution (0: skip)")
+    ap.add_argument("--ramp-steps", type=int, default=64,
+                    help="extra UNTIMED steps enqueued right before the timed region so that it starts on a chip at its "
+                         "loaded clocks: after >= 20 ms of idling a 20-step region runs 14 %% slower "
+                         "(profiles/r03_idle_gap_probe.txt); 0: none")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N in ONE process: a host thread and a context per GPU, no process group")
     ap.add_argument("--bcast-weights", action="store_true",
@@ -559,6 +563,9 @@ def run_shard(sh, args, wl, barrier):
         cursor += 2
         sh.sync()
     dom = max(table, key=lambda k: table[k]["avg_us"]) if table else None
+    if args.ramp_steps > 0:     # untimed; timed() synchronises behind them and starts the clock at once
+        sh.steps(kind, cursor, args.ramp_steps)
+        cursor += args.ramp_steps
     secs, prof = sh.timed(kind, cursor, K, barrier, only=dom)
     cursor += K
     res = {"seconds": secs, "table": table, "dom": dom, "dom_prof": prof.get(dom) if dom else None,
@@ -575,6 +582,9 @@ def run_shard(sh, args, wl, barrier):
             table2 = sh.kernel_table("decode", cursor, 8)
             cursor += 10
             sh.sync()
+        if args.ramp_steps > 0:
+            sh.steps("decode", cursor, args.ramp_steps)
+            cursor += args.ramp_steps
         secs2, _ = sh.timed("decode", cursor, K, barrier)
         res["secondary_seconds"] = secs2
         res["secondary_table"] = table2
@@ -595,7 +605,8 @@ def result_line(args, wl, world, secs, frames, res, launcher):
     out = {
         "metric": "20ms 16kHz frames/sec encode+decode (whole node) at batch 4096; xRT/stream",
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(secs / K * 1e3, 4), "higher_is_better": True, "scaling": wl["scaling"],
+        "ms_per_step": round(secs / K * 1e3, 4), "untimed_ramp_steps": args.ramp_steps, "higher_is_better": True,
+        "scaling": wl["scaling"],
         "vs_baseline": None, "dtype": "f32+i8 (fp32 and int8 layers exactly as the reference graphs)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE config #{wl['config']}: batch={B} streams/GPU x 1 frame(20 ms, 320 samples)"

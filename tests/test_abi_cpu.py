@@ -134,7 +134,7 @@ def test_bench_main_two_ranks_with_stub_context_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--stub-context", "--gpus", "2",
            "--config", "5", "--steps", "6", "--warmup", "3", "--bcast-weights", "--no-kernel-table", "--no-cpu-baseline",
-           "--latency-steps", "0"]
+           "--latency-steps", "0", "--ramp-steps", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -166,8 +166,8 @@ def test_bench_default_invocation_spawns_one_rank_per_gpu():
     assert "self-spawned" in r["config"]["parallelism"] and "2 rank(s)" in r["config"]["parallelism"]
     assert r["config"]["total_streams"] == 2 * 4096
     assert abs(r["value"] - 2 * 4096 * 5 / (5 * 1e-4 * 1.5)) < 1.0
-    # warm-up 2 + kernel-table pass 10 + 2 + timed 5 + latency 10
-    assert r["stub"]["calls"]["encdec"] == 2 + 10 + 2 + 5 + 10
+    # warm-up 2 + kernel-table pass 10 + 2 + untimed ramp 64 + timed 5 + latency 10
+    assert r["stub"]["calls"]["encdec"] == 2 + 10 + 2 + 64 + 5 + 10 and r["untimed_ramp_steps"] == 64
     lat = r["step_latency_us"]
     assert lat["n"] == 10 and lat["min"] == 100.0 and lat["max"] == 200.0 and lat["p50"] == 100.0 and lat["p99"] == 200.0
 
