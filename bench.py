@@ -46,7 +46,7 @@ One JSON line on rank 0:
     (lyra_hip_set_serial: the library streams strictly in call order, so no cross-stream contention), each with
     its own binding bound computed from the bytes it actually moves (lyra_amd/csrc/state_layout.h);
   * `dominant_kernel` = the kernel with the largest serialised duration, bracketed by HIP events inside the timed
-    region (i.e. under the two-stream overlap the step really runs with);
+    region (i.e. under the overlap of the library streams the step really runs with);
   * `step_latency_us` = distribution of ONE isolated step (enqueue -> all outputs complete, nothing else in flight):
     min / mean / p50 / p99 / max / stddev over --latency-steps steps (lyra_benchmark_lib.cc:164-182 prints the same
     statistics per stage; a 20 ms-deadline codec cares about the tail, not the mean);

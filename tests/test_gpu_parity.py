@@ -270,7 +270,7 @@ def test_full_size_properties(ctx, oracle_exact, B, bits):
 
 # ------------------------------------------------------------------------------------------------
 # the device-pointer pipeline exactly as bench.py drives it (two alternating buffers, no caller sync between
-# encode and decode, encode of step i+1 overlapping decode of step i on the library's two streams)
+# encode and decode, encode of step i+1 overlapping decode of step i on the library's streams)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,bits", [(37, 184), (1000, 64), (4096, 184)])
 def test_device_pipeline_as_benchmarked(ctx, oracle_exact, B, bits):
