@@ -73,7 +73,9 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   wg_schedule_hint();
   LYRA_TSTAMP(80);
   LYRA_WSTAMP(120);
+#if !defined(LYRA_WGTRACE_D1) && !defined(LYRA_WGTRACE_D2)
   LYRA_WG_BEGIN();
+#endif
   if (tid < SD0) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
@@ -344,7 +346,9 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   }
   LYRA_TSTAMP(88);
   LYRA_WSTAMP(121);
+#if !defined(LYRA_WGTRACE_D1) && !defined(LYRA_WGTRACE_D2)
   LYRA_WG_END();
+#endif
   if (tid < SD0 && cx.valid(tid)) {   // this region's ring phase
     int ph = sphase[tid] + 1;
     *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
@@ -445,6 +449,9 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   const int tid = threadIdx.x, wave = tid >> 6;
   const int b0 = blockIdx.x * SD1;
   LYRA_TSTAMP(50);
+#ifdef LYRA_WGTRACE_D1   // per-workgroup trace of THIS kernel instead of dec_s0 (tools/wg_trace_full.py)
+  LYRA_WG_BEGIN();
+#endif
   if (tid < SD1) {
     int id = ids[min(b0 + tid, B - 1)];
     sids[tid] = id;
@@ -484,6 +491,10 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   if (NTD1 == 256) dec_s1_tconv<5>(XB, SB, P, cx, b0, out1, wave * 5);
   else if (wave < 4) dec_s1_tconv<3>(XB, SB, P, cx, b0, out1, wave * 3);
   else dec_s1_tconv<2>(XB, SB, P, cx, b0, out1, 12 + (wave - 4) * 2);
+#ifdef LYRA_WGTRACE_D1
+  __syncthreads();
+  LYRA_WG_END();
+#endif
   if (tid < SD1 && cx.valid(tid)) {   // this region's ring phase
     int ph = sphase[tid] + 1;
     *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
@@ -514,6 +525,9 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   wg_schedule_hint();
   const int b0 = blockIdx.x * SD2;
   LYRA_TSTAMP(60);
+#ifdef LYRA_WGTRACE_D2
+  LYRA_WG_BEGIN();
+#endif
   if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NTD2, 1>(P.warm);
   const auto warm_code = code_warm<NTD2>(code_bytes);
@@ -580,6 +594,10 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
         }
       }
   }
+#ifdef LYRA_WGTRACE_D2
+  __syncthreads();
+  LYRA_WG_END();
+#endif
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);
 }

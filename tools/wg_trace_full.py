@@ -7,7 +7,7 @@ from collections import Counter
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-os.environ["LYRA_HIP_LIB"] = os.path.join(ROOT, "lyra_amd", "variants", "timing.so")
+os.environ["LYRA_HIP_LIB"] = os.path.join(ROOT, "lyra_amd", "variants", os.environ.get("VARIANT", "timing") + ".so")
 import torch
 import lyra_amd
 B = int(os.environ.get("B", 4096))
