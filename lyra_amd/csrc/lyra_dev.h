@@ -158,7 +158,7 @@ __device__ __forceinline__ const T LYRA_GLOBAL* as_global(const T* p) {
 #define LYRA_MFMA_END() do { } while (0)
 #endif
 __device__ __forceinline__ void wg_schedule_hint() {
-#if defined(LYRA_PRIO_SLOT) || defined(LYRA_STAGGER)
+#if defined(LYRA_PRIO_SLOT) || defined(LYRA_STAGGER) || defined(LYRA_STAGGER2)
   const unsigned slot = __builtin_amdgcn_s_getreg(63492) & 15u;   // HW_ID.wave_id: the wave's slot on its SIMD
 #endif
 #ifdef LYRA_PRIO_SLOT
@@ -171,6 +171,9 @@ __device__ __forceinline__ void wg_schedule_hint() {
 #endif
 #ifdef LYRA_STAGGER
   for (unsigned i = 0; i < (slot & 3u) * LYRA_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+#endif
+#ifdef LYRA_STAGGER2   // half of a CU's co-resident tiles (wave slots 2, 3 of each SIMD) start LYRA_STAGGER2 * 64 cycles late
+  if (slot & 2u) __builtin_amdgcn_s_sleep(LYRA_STAGGER2);
 #endif
 }
 
