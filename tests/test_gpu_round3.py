@@ -297,3 +297,56 @@ def test_resampler_48k_past_the_old_counter_wrap():
             assert np.array_equal(back, wantb), f"16->48 differs at hop {t}"
     finally:
         ctx.close()
+
+
+def test_run_steps_full_pipeline_at_benchmark_scale(golden_dir):
+    """The complete step -- 48 kHz in, encoder resampler, DTX encoder, decoder, decoder-side noise estimator on its own
+    stream, output resampler -- at B = 4096, where every kernel is long enough to overlap its neighbours on the four
+    library streams: 40 steps from ONE asynchronous lyra_hip_run_steps_dev call against the same calls issued one by one
+    with a full synchronise after each, on a second context.  Packets of live hops, packet lengths, PCM at both rates and
+    the is_noise flags of the last steps must be identical: any missing ordering edge shows as a difference here."""
+    import torch
+    import lyra_amd
+    B, T, bits, ext = 4096, 40, 120, 48000
+    base = _speech_noise_silence(golden_dir, T, 64)
+    pcm48 = np.repeat(base[:, np.arange(B) % 64], 3, axis=2).copy()
+    dev = torch.device("cuda", 0)
+    ids = torch.from_numpy(np.random.default_rng(1).permutation(B).astype(np.int32)).to(dev)
+    ring = torch.from_numpy(pcm48).to(dev)
+    nb = lyra_amd.packet_size(bits)
+    A, Bc = lyra_amd.LyraHip(max_streams=B), lyra_amd.LyraHip(max_streams=B)
+    A.torch_order = Bc.torch_order = False
+    A.set_encoder_sample_rate(ext); Bc.set_encoder_sample_rate(ext)
+
+    def bufs():
+        return dict(pk=[torch.zeros((B, nb), device=dev, dtype=torch.uint8) for _ in range(2)],
+                    nbytes=[torch.full((B,), -1, device=dev, dtype=torch.int32) for _ in range(2)],
+                    out=[torch.zeros((B, 320), device=dev, dtype=torch.int16) for _ in range(2)],
+                    ext=[torch.zeros((B, 960), device=dev, dtype=torch.int16) for _ in range(2)],
+                    flag=torch.full((B,), -1, device=dev, dtype=torch.int32),
+                    in16=torch.zeros((B, 320), device=dev, dtype=torch.int16))
+    a, b = bufs(), bufs()
+    torch.cuda.synchronize()
+    try:
+        A.run_steps_dev(ids, bits, T, first_step=0, d_pcm_ring=ring, d_packets=a["pk"], d_pcm_out=a["out"],
+                        d_packet_bytes=a["nbytes"], d_is_noise=a["flag"], external_rate=ext, d_ext_out=a["ext"],
+                        encode=True, decode=True, dtx=True, decoder_noise=True)
+        for t in range(T):
+            s = t & 1
+            Bc.resample_dev(ids, ring[t], ext, 16000, b["in16"], side="encoder"); Bc.synchronize()
+            Bc.encode_dtx_dev(ids, b["in16"], bits, b["pk"][s], b["nbytes"][s]); Bc.synchronize()
+            Bc.decode_dev(ids, b["pk"][s], bits, b["out"][s]); Bc.synchronize()
+            Bc.noise_receive_dev(ids, b["out"][s], b["flag"], side="decoder"); Bc.synchronize()
+            Bc.resample_dev(ids, b["out"][s], 16000, ext, b["ext"][s], side="decoder"); Bc.synchronize()
+        A.synchronize()
+        for s in range(2):
+            la, lb = a["nbytes"][s].cpu().numpy(), b["nbytes"][s].cpu().numpy()
+            assert np.array_equal(la, lb)
+            live = la > 0
+            assert np.array_equal(a["pk"][s].cpu().numpy()[live], b["pk"][s].cpu().numpy()[live])
+            assert torch.equal(a["out"][s], b["out"][s]) and torch.equal(a["ext"][s], b["ext"][s])
+        assert torch.equal(a["flag"], b["flag"])
+        assert int((a["nbytes"][1] == 0).sum()) > 100 and int((a["nbytes"][1] > 0).sum()) > 100
+    finally:
+        A.close()
+        Bc.close()
