@@ -386,3 +386,52 @@ def test_gpu_batch_decoder_large_requests_vs_reference_class(ref, oracle_exact, 
                 worst = max(worst, int(d.max()))
                 n_diff += int((d > 0).sum()); n_total += k
     assert pos == out.size and worst <= 2 and n_diff / n_total < 0.03, (worst, n_diff, n_total)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_twins_many_streams_random_loss_vs_reference_classes(ref, oracle_exact, golden_dir, tmp_path):
+    """192 streams, 24 ticks, every stream losing its packets independently (18 %, in bursts), odd request sizes: the
+    rounds of BatchLyraDecoder's loop now hold large mixed groups (received / concealing / comfort noise / fading, hops
+    starting and ending in different rounds) -- against 192 pairs of the reference's LyraEncoder / LyraDecoder."""
+    from test_batch_codec_semantics import _run_session
+    rate, bitrate, bits = 16000, 9200, 184
+    n, T, hop = 192, 24, 320
+    speech = np.load(os.path.join(golden_dir, "sample_wavs.npz"))["sample1_16kHz"]
+    rng = np.random.default_rng(42)
+    pcm = np.stack([speech[o:o + T * hop].reshape(T, hop) for o in rng.integers(0, speech.size - T * hop, n)], axis=1)
+    pcm = (pcm.astype(np.int32) * rng.choice([1, 1, 1, 0], size=(1, n, 1))).astype(np.int16)   # a quarter of the streams silent
+    lost = np.zeros((T, n), bool)
+    for s in range(n):
+        t = 0
+        while t < T:
+            if rng.random() < 0.08:
+                L = int(rng.integers(1, 9))
+                lost[t:t + L, s] = True
+                t += L
+            t += 1
+    script = []
+    for t in range(T):
+        mask = "".join("0" if lost[t, s] else "1" for s in range(n))
+        sizes = [hop] if t % 3 == 0 else ([97, hop - 97] if t % 3 == 1 else [1, 160, 159])
+        script.append((mask, sizes))
+    packets, lengths, out = _run_session(tmp_path, oracle_exact, rate, bitrate, False, pcm, script)
+    encs = [ref.LyraEncoder(oracle_exact, rate, bits, False) for _ in range(n)]
+    decs = [ref.LyraDecoder(oracle_exact, rate, 0x4C797261 ^ s) for s in range(n)]
+    pos = worst = n_diff = n_total = 0
+    saw_cng = 0
+    for t, (mask, sizes) in enumerate(script):
+        for s in range(n):
+            p = encs[s].Encode(pcm[t, s])
+            assert np.array_equal(packets[t, s], p), (t, s)
+            if mask[s] == "1":
+                decs[s].SetEncodedPacket(p)
+        for k in sizes:
+            got = out[pos:pos + n * k].reshape(n, k)
+            pos += n * k
+            for s in range(n):
+                want = decs[s].DecodeSamples(k)
+                d = np.abs(got[s].astype(int) - want.astype(int))
+                worst = max(worst, int(d.max()))
+                n_diff += int((d > 0).sum()); n_total += k
+                saw_cng += int(decs[s].is_comfort_noise())
+    assert pos == out.size and worst <= 2 and n_diff / n_total < 0.02 and saw_cng > 50, (worst, n_diff, n_total, saw_cng)
