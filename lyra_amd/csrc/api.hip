@@ -104,6 +104,7 @@ struct lyra_hip_ctx {
   uint8_t* h_twin_args = nullptr;  // pinned
   uint8_t* d_twin_args = nullptr;
   size_t twin_args_cap = 0, twin_args_used = 0;
+  size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
   int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
@@ -228,6 +229,15 @@ int check_ids_host(lyra_hip_ctx* c, const int32_t* ids, int B) {
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// EXPERIMENT hook (occupancy): LYRA_HIP_LDS_PAD_<kernel>=bytes asks for that much extra dynamic LDS per workgroup of a
+// stage kernel, i.e. fewer of its workgroups per CU and more room for the kernel running beside it.
+inline size_t lds_pad(const char* kernel) {
+  char name[64];
+  snprintf(name, sizeof name, "LYRA_HIP_LDS_PAD_%s", kernel);
+  const char* v = getenv(name);
+  return v ? (size_t)atol(v) : 0;
+}
 
 // machine-code size of each kernel (generated at build time by code_sizes.sh from the kernel objects)
 struct CodeSize { const char* name; int bytes; int getpc; };   // getpc: offset of the kernel's s_getpc_b64 (= bytes: none found)
@@ -447,15 +457,15 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   }
 #endif
   { ProfScope ps(c, K_ENC_S0, st_);
-    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(enc_s0_threads()), enc_s0_lds_bytes(), st_,
+    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(enc_s0_threads()), enc_s0_lds_bytes() + c->lds_pad[0], st_,
                        M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0]); }
   { ProfScope ps(c, K_ENC_S1, st_);
-    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes(), st_,
+    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes() + c->lds_pad[1], st_,
                        M.d_enc1, e0, d_ids, B, c->sm.base[st::R_E1], e1, c->cw[K_ENC_S1]); }
   for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
   { ProfScope ps(c, K_ENC_S2, st_);
     hipLaunchKernelGGL(c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512),
-                       enc_s2_lds_bytes(), st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
+                       enc_s2_lds_bytes() + c->lds_pad[2], st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
                        c->cw[K_ENC_S2]); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
@@ -507,14 +517,14 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
 #endif
   { ProfScope ps(c, K_DEC_S0, st_);
     hipLaunchKernelGGL(c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512),
-                       dec_s0_lds_bytes(), st_,
+                       dec_s0_lds_bytes() + c->lds_pad[3], st_,
                        M.d_dec0, d_feat, d_ids, B, c->sm.base[st::R_D0], d0, d_pkt, num_stages, M.cb,
                        c->cw[K_DEC_S0]); }
   { ProfScope ps(c, K_DEC_S1, st_);
-    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(dec_s1_threads()), dec_s1_lds_bytes(), st_,
+    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(dec_s1_threads()), dec_s1_lds_bytes() + c->lds_pad[4], st_,
                        M.d_dec1, d0, d_ids, B, c->sm.base[st::R_D1], d1, c->cw[K_DEC_S1]); }
   { ProfScope ps(c, K_DEC_S2, st_);
-    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(dec_s2_threads()), dec_s2_lds_bytes(), st_,
+    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(dec_s2_threads()), dec_s2_lds_bytes() + c->lds_pad[5], st_,
                        M.d_dec2, d1, d_ids, B, c->sm.base[st::R_D2], d_pcm, c->cw[K_DEC_S2]); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
@@ -682,16 +692,20 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       off += (size_t)max_streams * st::REGION_BYTES[r];
     }
   }
-  if (set_lds(enc_s0_kernel, enc_s0_lds_bytes()) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes()) != hipSuccess ||
-      set_lds(enc_s2_kernel, enc_s2_lds_bytes()) != hipSuccess ||
+  {
+    const char* names[6] = {"ENC_S0", "ENC_S1", "ENC_S2", "DEC_S0", "DEC_S1", "DEC_S2"};
+    for (int i = 0; i < 6; ++i) c->lds_pad[i] = lds_pad(names[i]);
+  }
+  if (set_lds(enc_s0_kernel, enc_s0_lds_bytes() + c->lds_pad[0]) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes() + c->lds_pad[1]) != hipSuccess ||
+      set_lds(enc_s2_kernel, enc_s2_lds_bytes() + c->lds_pad[2]) != hipSuccess ||
 #ifdef LYRA_PARKED
       set_lds(enc_side_kernel, enc_side_lds_bytes()) != hipSuccess ||
       set_lds(enc_side_dr_kernel, enc_side_lds_bytes()) != hipSuccess || set_lds(dec_side_kernel, dec_side_lds_bytes()) != hipSuccess ||
       set_lds(dec_side_dr_kernel, dec_side_lds_bytes()) != hipSuccess ||
 #endif
-      set_lds(dec_s0_kernel, dec_s0_lds_bytes()) != hipSuccess ||
+      set_lds(dec_s0_kernel, dec_s0_lds_bytes() + c->lds_pad[3]) != hipSuccess ||
       set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||
-      set_lds(dec_s1_kernel, dec_s1_lds_bytes()) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes()) != hipSuccess ||
+      set_lds(dec_s1_kernel, dec_s1_lds_bytes() + c->lds_pad[4]) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes() + c->lds_pad[5]) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, logmel_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
   for (int i = 0; i < K_COUNT; ++i) c->cw[i] = code_warm_bytes(kKernelNames[i]);
