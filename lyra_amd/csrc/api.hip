@@ -105,6 +105,7 @@ struct lyra_hip_ctx {
   uint8_t* d_twin_args = nullptr;
   size_t twin_args_cap = 0, twin_args_used = 0;
   size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
+  int tile_div[6] = {1, 1, 1, 1, 1, 1};   // tiles per workgroup of each stage kernel (LYRA_TILE_LOOP), see tile_div()
   int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
@@ -237,6 +238,17 @@ inline size_t lds_pad(const char* kernel) {
   snprintf(name, sizeof name, "LYRA_HIP_LDS_PAD_%s", kernel);
   const char* v = getenv(name);
   return v ? (size_t)atol(v) : 0;
+}
+
+// LYRA_HIP_TILE_DIV_<kernel>=k launches a stage kernel as k back-to-back slices of 1/k of its tiles each (tile0 = first
+// tile of the slice): at any time the kernel holds at most 1/k of the CUs' LDS and wave slots, the rest stays free for
+// the other chain's kernel.
+inline int tile_div(const char* kernel) {
+  char name[64];
+  snprintf(name, sizeof name, "LYRA_HIP_TILE_DIV_%s", kernel);
+  const char* v = getenv(name);
+  const int k = v ? atoi(v) : 1;
+  return k < 1 ? 1 : k;
 }
 
 // machine-code size of each kernel (generated at build time by code_sizes.sh from the kernel objects)
@@ -457,16 +469,19 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   }
 #endif
   { ProfScope ps(c, K_ENC_S0, st_);
-    hipLaunchKernelGGL(enc_s0_kernel, dim3(cdiv(B, enc_s0_streams_per_wg())), dim3(enc_s0_threads()), enc_s0_lds_bytes() + c->lds_pad[0], st_,
-                       M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0]); }
+    for (int nt = cdiv(B, enc_s0_streams_per_wg()), g = cdiv(nt, c->tile_div[0]), t0 = 0; t0 < nt; t0 += g)
+      hipLaunchKernelGGL(enc_s0_kernel, dim3(std::min(g, nt - t0)), dim3(enc_s0_threads()), enc_s0_lds_bytes() + c->lds_pad[0], st_,
+                         M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0], t0); }
   { ProfScope ps(c, K_ENC_S1, st_);
-    hipLaunchKernelGGL(enc_s1_kernel, dim3(cdiv(B, enc_s1_streams_per_wg())), dim3(enc_s1_threads()), enc_s1_lds_bytes() + c->lds_pad[1], st_,
-                       M.d_enc1, e0, d_ids, B, c->sm.base[st::R_E1], e1, c->cw[K_ENC_S1]); }
+    for (int nt = cdiv(B, enc_s1_streams_per_wg()), g = cdiv(nt, c->tile_div[1]), t0 = 0; t0 < nt; t0 += g)
+      hipLaunchKernelGGL(enc_s1_kernel, dim3(std::min(g, nt - t0)), dim3(enc_s1_threads()), enc_s1_lds_bytes() + c->lds_pad[1], st_,
+                         M.d_enc1, e0, d_ids, B, c->sm.base[st::R_E1], e1, c->cw[K_ENC_S1], t0); }
   for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
   { ProfScope ps(c, K_ENC_S2, st_);
-    hipLaunchKernelGGL(c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(cdiv(B, enc_s2_streams_per_wg())), dim3(512),
-                       enc_s2_lds_bytes() + c->lds_pad[2], st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
-                       c->cw[K_ENC_S2]); }
+    for (int nt = cdiv(B, enc_s2_streams_per_wg()), g = cdiv(nt, c->tile_div[2]), t0 = 0; t0 < nt; t0 += g)
+      hipLaunchKernelGGL(c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(std::min(g, nt - t0)), dim3(512),
+                         enc_s2_lds_bytes() + c->lds_pad[2], st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
+                         c->cw[K_ENC_S2], t0); }
   HIPCHK(c, hipGetLastError());
   c->last_B_enc = B;
   return 0;
@@ -516,16 +531,19 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
   }
 #endif
   { ProfScope ps(c, K_DEC_S0, st_);
-    hipLaunchKernelGGL(c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(cdiv(B, dec_s0_streams_per_wg())), dim3(512),
-                       dec_s0_lds_bytes() + c->lds_pad[3], st_,
-                       M.d_dec0, d_feat, d_ids, B, c->sm.base[st::R_D0], d0, d_pkt, num_stages, M.cb,
-                       c->cw[K_DEC_S0]); }
+    for (int nt = cdiv(B, dec_s0_streams_per_wg()), g = cdiv(nt, c->tile_div[3]), t0 = 0; t0 < nt; t0 += g)
+      hipLaunchKernelGGL(c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(std::min(g, nt - t0)), dim3(512),
+                         dec_s0_lds_bytes() + c->lds_pad[3], st_,
+                         M.d_dec0, d_feat, d_ids, B, c->sm.base[st::R_D0], d0, d_pkt, num_stages, M.cb,
+                         c->cw[K_DEC_S0], t0); }
   { ProfScope ps(c, K_DEC_S1, st_);
-    hipLaunchKernelGGL(dec_s1_kernel, dim3(cdiv(B, dec_s1_streams_per_wg())), dim3(dec_s1_threads()), dec_s1_lds_bytes() + c->lds_pad[4], st_,
-                       M.d_dec1, d0, d_ids, B, c->sm.base[st::R_D1], d1, c->cw[K_DEC_S1]); }
+    for (int nt = cdiv(B, dec_s1_streams_per_wg()), g = cdiv(nt, c->tile_div[4]), t0 = 0; t0 < nt; t0 += g)
+      hipLaunchKernelGGL(dec_s1_kernel, dim3(std::min(g, nt - t0)), dim3(dec_s1_threads()), dec_s1_lds_bytes() + c->lds_pad[4], st_,
+                         M.d_dec1, d0, d_ids, B, c->sm.base[st::R_D1], d1, c->cw[K_DEC_S1], t0); }
   { ProfScope ps(c, K_DEC_S2, st_);
-    hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(dec_s2_threads()), dec_s2_lds_bytes() + c->lds_pad[5], st_,
-                       M.d_dec2, d1, d_ids, B, c->sm.base[st::R_D2], d_pcm, c->cw[K_DEC_S2]); }
+    for (int nt = cdiv(B, dec_s2_streams_per_wg()), g = cdiv(nt, c->tile_div[5]), t0 = 0; t0 < nt; t0 += g)
+      hipLaunchKernelGGL(dec_s2_kernel, dim3(std::min(g, nt - t0)), dim3(dec_s2_threads()), dec_s2_lds_bytes() + c->lds_pad[5], st_,
+                         M.d_dec2, d1, d_ids, B, c->sm.base[st::R_D2], d_pcm, c->cw[K_DEC_S2], t0); }
   HIPCHK(c, hipGetLastError());
   c->last_B_dec = B;
   return 0;
@@ -695,6 +713,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   {
     const char* names[6] = {"ENC_S0", "ENC_S1", "ENC_S2", "DEC_S0", "DEC_S1", "DEC_S2"};
     for (int i = 0; i < 6; ++i) c->lds_pad[i] = lds_pad(names[i]);
+    for (int i = 0; i < 6; ++i) c->tile_div[i] = tile_div(names[i]);
   }
   if (set_lds(enc_s0_kernel, enc_s0_lds_bytes() + c->lds_pad[0]) != hipSuccess || set_lds(enc_s1_kernel, enc_s1_lds_bytes() + c->lds_pad[1]) != hipSuccess ||
       set_lds(enc_s2_kernel, enc_s2_lds_bytes() + c->lds_pad[2]) != hipSuccess ||

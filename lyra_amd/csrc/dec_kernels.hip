@@ -30,22 +30,17 @@ __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_kernel(const DecS0
                                                        const int32_t* __restrict__ ids, int B,
                                                        uint8_t* __restrict__ state, float* __restrict__ out0,
                                                        const uint8_t* __restrict__ packets, int num_stages,
-                                                       const float* __restrict__ cb, int code_bytes) {
-#ifdef LYRA_TLOOP   // experiment: T hops per launch (timing only: same inputs every trip)
-  for (int t_ = 0; t_ < LYRA_TLOOP; ++t_) {
-    dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
-    __syncthreads();
-  }
-#else
-  dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
-#endif
+                                                       const float* __restrict__ cb, int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * SD0 >= B) return;
+  dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
 __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_dr_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                           const int32_t* __restrict__ ids, int B,
                                                           uint8_t* __restrict__ state, float* __restrict__ out0,
                                                           const uint8_t* __restrict__ packets, int num_stages,
-                                                          const float* __restrict__ cb, int code_bytes) {
-  dec_s0_body<1>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes);
+                                                          const float* __restrict__ cb, int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * SD0 >= B) return;
+  dec_s0_body<1>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
 
 size_t dec_s1_lds_bytes() { return dec_s1_lds(); }
@@ -55,15 +50,9 @@ int dec_s1_threads() { return NTD1; }
 __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const DecS1P* __restrict__ Pp, const float* __restrict__ in0,
                                                                           const int32_t* __restrict__ ids, int B,
                                                                           uint8_t* __restrict__ state, float* __restrict__ out1,
-                                                                          int code_bytes) {
-#ifdef LYRA_TLOOP   // experiment: T hops per launch (timing only: same inputs every trip)
-  for (int t_ = 0; t_ < LYRA_TLOOP; ++t_) {
-    dec_s1_body(*Pp, in0, ids, B, state, out1, code_bytes);
-    __syncthreads();
-  }
-#else
-  dec_s1_body(*Pp, in0, ids, B, state, out1, code_bytes);
-#endif
+                                                                          int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * SD1 >= B) return;
+  dec_s1_body(*Pp, in0, ids, B, state, out1, code_bytes, (int)blockIdx.x + tile0);
 }
 
 #ifdef LYRA_WAVE_PRIVATE
@@ -87,7 +76,7 @@ int dec_s2_threads() { return NTD2; }
 __global__ __launch_bounds__(NTD2, 3) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                           const int32_t* __restrict__ ids, int B,
                                                           uint8_t* __restrict__ state, int16_t* __restrict__ pcm,
-                                                          int code_bytes) {
+                                                          int code_bytes, int tile0) {
   const DecS2P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [27][S][72]: rows 0-2 zeros, rows 3-22 activations, rows 23-26 zeros
@@ -95,7 +84,7 @@ __global__ __launch_bounds__(NTD2, 3) void dec_s2_kernel(const DecS2P* __restric
   int* sids = reinterpret_cast<int*>(SB + SD2 * 48);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * SD2;
+  const int b0 = ((int)blockIdx.x + tile0) * SD2;
   if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NTD2, 1>(P.warm);
   const auto warm_code = code_warm<NTD2>(code_bytes);
@@ -180,8 +169,9 @@ int dec_s2_threads() { return 64 * SD2; }
 __global__ __launch_bounds__(64 * SD2, LYRA_C64_WAVES) void dec_s2_kernel(const DecS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                             const int32_t* __restrict__ ids, int B,
                                                             uint8_t* __restrict__ state, int16_t* __restrict__ pcm,
-                                                            int code_bytes) {
-  dec_s2_body<SD2>(*Pp, in1, ids, B, state, pcm, code_bytes);
+                                                            int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * SD2 >= B) return;
+  dec_s2_body<SD2>(*Pp, in1, ids, B, state, pcm, code_bytes, (int)blockIdx.x + tile0);
 }
 #endif  // LYRA_WAVE_PRIVATE
 

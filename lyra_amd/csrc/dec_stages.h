@@ -52,7 +52,7 @@ template <int MODE>
 __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                             const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
                                             float* __restrict__ out0, const uint8_t* __restrict__ packets, int num_stages,
-                                            const float* __restrict__ cb, int code_bytes) {
+                                            const float* __restrict__ cb, int code_bytes, int tile = (int)blockIdx.x) {
   const DecS0P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* FB = smem;                                   // [3][16][72]: two history rows + new features (rows s < S used)
@@ -68,7 +68,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   int8_t* LQ = reinterpret_cast<int8_t*>(LA + NADD * 512);   // [NLR][256] LeakyReLU tables
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * SD0;
+  const int b0 = tile * SD0;
   constexpr int mode = MODE;
   wg_schedule_hint();
   LYRA_TSTAMP(80);
@@ -437,7 +437,7 @@ __host__ __device__ constexpr size_t dec_s1_lds() { return (size_t)(4 * SD1 * CS
 
 __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __restrict__ in0,
                                             const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
-                                            float* __restrict__ out1, int code_bytes) {
+                                            float* __restrict__ out1, int code_bytes, int tile = (int)blockIdx.x) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [4][S][136]: X[t]
   float* DB = XB + 4 * SD1 * CS1;       // [4][S][136]
@@ -447,7 +447,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   int* sphase = sids + SD1;
   wg_schedule_hint();
   const int tid = threadIdx.x, wave = tid >> 6;
-  const int b0 = blockIdx.x * SD1;
+  const int b0 = tile * SD1;
   LYRA_TSTAMP(50);
 #ifdef LYRA_WGTRACE_D1   // per-workgroup trace of THIS kernel instead of dec_s0 (tools/wg_trace_full.py)
   LYRA_WG_BEGIN();
@@ -514,7 +514,7 @@ __host__ __device__ constexpr size_t dec_s2_lds(int sd2) { return (size_t)(27 * 
 template <int SD2>
 __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __restrict__ in1,
                                             const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
-                                            int16_t* __restrict__ pcm, int code_bytes) {
+                                            int16_t* __restrict__ pcm, int code_bytes, int tile = (int)blockIdx.x) {
   constexpr int NTD2 = 64 * SD2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [27][S][72]: rows 0-2 zeros, rows 3-22 activations, rows 23-26 zeros
@@ -523,7 +523,7 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   wg_schedule_hint();
-  const int b0 = blockIdx.x * SD2;
+  const int b0 = tile * SD2;
   LYRA_TSTAMP(60);
 #ifdef LYRA_WGTRACE_D2
   LYRA_WG_BEGIN();

@@ -36,29 +36,17 @@ int enc_s1_threads() { return NT1; }
 __global__ __launch_bounds__(64 * S0, LYRA_C64_WAVES) void enc_s0_kernel(const EncS0P* __restrict__ Pp, const int16_t* __restrict__ pcm,
                                                            const int32_t* __restrict__ ids, int B,
                                                            uint8_t* __restrict__ state, float* __restrict__ out0,
-                                                           int code_bytes) {
-#ifdef LYRA_TLOOP   // experiment: T hops per launch (timing only: same inputs every trip)
-  for (int t_ = 0; t_ < LYRA_TLOOP; ++t_) {
-    enc_s0_body<S0>(*Pp, pcm, ids, B, state, out0, code_bytes);
-    __syncthreads();
-  }
-#else
-  enc_s0_body<S0>(*Pp, pcm, ids, B, state, out0, code_bytes);
-#endif
+                                                           int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * S0 >= B) return;
+  enc_s0_body<S0>(*Pp, pcm, ids, B, state, out0, code_bytes, (int)blockIdx.x + tile0);
 }
 
 __global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const EncS1P* __restrict__ Pp, const float* __restrict__ in0,
                                                                         const int32_t* __restrict__ ids, int B,
                                                                         uint8_t* __restrict__ state, float* __restrict__ out1,
-                                                                        int code_bytes) {
-#ifdef LYRA_TLOOP   // experiment: T hops per launch (timing only: same inputs every trip)
-  for (int t_ = 0; t_ < LYRA_TLOOP; ++t_) {
-    enc_s1_body(*Pp, in0, ids, B, state, out1, code_bytes);
-    __syncthreads();
-  }
-#else
-  enc_s1_body(*Pp, in0, ids, B, state, out1, code_bytes);
-#endif
+                                                                        int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * S1 >= B) return;
+  enc_s1_body(*Pp, in0, ids, B, state, out1, code_bytes, (int)blockIdx.x + tile0);
 }
 
 }  // namespace lyra

@@ -25,21 +25,16 @@ int enc_s2_streams_per_wg() { return S2; }
 __global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, float* __restrict__ feats,
-                                                      float* __restrict__ codes_dbg, int code_bytes) {
-#ifdef LYRA_TLOOP   // experiment: T hops per launch (timing only: same inputs every trip)
-  for (int t_ = 0; t_ < LYRA_TLOOP; ++t_) {
-    enc_s2_body<0>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes);
-    __syncthreads();
-  }
-#else
-  enc_s2_body<0>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes);
-#endif
+                                                      float* __restrict__ codes_dbg, int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * S2 >= B) return;
+  enc_s2_body<0>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
 __global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_dr_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ feats,
-                                                         float* __restrict__ codes_dbg, int code_bytes) {
-  enc_s2_body<1>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes);
+                                                         float* __restrict__ codes_dbg, int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * S2 >= B) return;
+  enc_s2_body<1>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
 
 }  // namespace lyra

@@ -36,7 +36,7 @@ __host__ __device__ constexpr size_t enc_s2_lds() { return (size_t)2 * XF_BYTES 
 template <int MODE>
 __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                             const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
-                                            float* __restrict__ feats, float* __restrict__ codes_dbg, int code_bytes) {
+                                            float* __restrict__ feats, float* __restrict__ codes_dbg, int code_bytes, int tile = (int)blockIdx.x) {
   const EncS2P& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* DF = smem;                                  // [2][S][CS2] depthwise out; later int8 staging QB4
@@ -52,7 +52,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   int8_t* QC = reinterpret_cast<int8_t*>(XF);        // [3][S][QS5]  (aliases XF and, past it, QX.. once dead)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * S2;
+  const int b0 = tile * S2;
   constexpr int mode = MODE;
   wg_schedule_hint();
   LYRA_TSTAMP(0);

@@ -37,7 +37,7 @@ __host__ __device__ constexpr size_t enc_s1_lds() { return (size_t)(6 * S1 * CS1
 template <int S0>
 __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __restrict__ pcm,
                                             const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
-                                            float* __restrict__ out0, int code_bytes) {
+                                            float* __restrict__ out0, int code_bytes, int tile = (int)blockIdx.x) {
   constexpr int NT0 = 64 * S0, NW0 = NT0 / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                     // [25][S0][CS0]: rows 0-4 strided-conv history, rows 5-24 the one
@@ -46,7 +46,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   static_assert(S0 * PBS <= 25 * S0 * CS0, "PCM staging fits");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * S0;
+  const int b0 = tile * S0;
   LYRA_WG_BEGIN();
   LYRA_TSTAMP(0);
   LYRA_WSTAMP(100);
@@ -181,7 +181,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
 // =============================================================================================
 __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __restrict__ in0,
                                             const int32_t* __restrict__ ids, int B, uint8_t* __restrict__ state,
-                                            float* __restrict__ out1, int code_bytes) {
+                                            float* __restrict__ out1, int code_bytes, int tile = (int)blockIdx.x) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* XB = smem;                    // [6][S1][CS1]: rows 0-1 strided-conv history, rows 2-5 X[t]
   float* DB = XB + 6 * S1 * CS1;       // [4][S1][CS1]
@@ -190,7 +190,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   int* sphase = sids + S1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * S1;
+  const int b0 = tile * S1;
   wg_schedule_hint();
   LYRA_TSTAMP(70);
   LYRA_WSTAMP(102);

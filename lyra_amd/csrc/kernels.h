@@ -22,14 +22,15 @@ struct EncS2P {
 };
 
 // code_bytes: size of the kernel's own machine code to pull into L2 at start (lyra_dev.h code_warm; 0 = skip)
+// tile0: first tile of this launch (workgroup i works on tile tile0 + i; api.hip tile_div)
 __global__ void enc_s0_kernel(const EncS0P* P, const int16_t* pcm, const int32_t* ids, int B, uint8_t* state, float* out0,
-                              int code_bytes);
+                              int code_bytes, int tile0);
 __global__ void enc_s1_kernel(const EncS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1,
-                              int code_bytes);
+                              int code_bytes, int tile0);
 __global__ void enc_s2_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, float* feats,
-                              float* codes_dbg, int code_bytes);
+                              float* codes_dbg, int code_bytes, int tile0);
 __global__ void enc_s2_dr_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state,
-                                 float* feats, float* codes_dbg, int code_bytes);   // gemmlowp double rounding
+                                 float* feats, float* codes_dbg, int code_bytes, int tile0);   // gemmlowp double rounding
 __global__ void enc_side_kernel(const EncS0P* P0, const EncS1P* P1, const EncS2P* P2, const int16_t* pcm, const int32_t* ids,
                                 int B, uint8_t* st0, uint8_t* st1, uint8_t* st2, float* e0, float* e1, float* feats,
                                 float* codes_dbg, int code_bytes);
@@ -63,13 +64,13 @@ struct DecS1P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; const float* up_s
 struct DecS2P { DwF dw[3]; ConvF pw[3]; ConvF cv[3]; ConvF up; float up_sub; WarmRange warm; };
 
 __global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state, float* out0,
-                              const uint8_t* packets, int num_stages, const float* cb, int code_bytes);
+                              const uint8_t* packets, int num_stages, const float* cb, int code_bytes, int tile0);
 __global__ void dec_s0_dr_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state,
-                                 float* out0, const uint8_t* packets, int num_stages, const float* cb, int code_bytes);
+                                 float* out0, const uint8_t* packets, int num_stages, const float* cb, int code_bytes, int tile0);
 __global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1,
-                              int code_bytes);
+                              int code_bytes, int tile0);
 __global__ void dec_s2_kernel(const DecS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state, int16_t* pcm,
-                              int code_bytes);
+                              int code_bytes, int tile0);
 __global__ void dec_side_kernel(const DecS0P* P0, const DecS1P* P1, const DecS2P* P2, const float* feats, const int32_t* ids,
                                 int B, uint8_t* st0, uint8_t* st1, uint8_t* st2, float* d0, float* d1, int16_t* pcm,
                                 const uint8_t* packets, int num_stages, const float* cb, int code_bytes);
