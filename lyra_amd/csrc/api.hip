@@ -725,7 +725,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       set_lds(dec_s0_kernel, dec_s0_lds_bytes() + c->lds_pad[3]) != hipSuccess ||
       set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes() + c->lds_pad[4]) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes() + c->lds_pad[5]) != hipSuccess ||
-      set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, logmel_lds_bytes()) != hipSuccess)
+      set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, cng_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
   for (int i = 0; i < K_COUNT; ++i) c->cw[i] = code_warm_bytes(kKernelNames[i]);
   if (c->mode) {
@@ -1010,7 +1010,7 @@ int launch_cng(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_feat
     if (c->nsub == 1) c->noise_done_dec = c->n_noise_calls;
   }
   { ProfScope ps(c, K_CNG, c->sd[0]);
-    hipLaunchKernelGGL(cng_kernel, dim3(B), dim3(256), logmel_lds_bytes(), c->sd[0], c->model.d_mel, c->cng_seed, d_ids, B,
+    hipLaunchKernelGGL(cng_kernel, dim3(B), dim3(256), cng_lds_bytes(), c->sd[0], c->model.d_mel, c->cng_seed, d_ids, B,
                        c->sm.base[st::R_CNG], (const uint8_t*)c->sm.base[st::R_NOISE_D], d_features, d_pcm); }
   HIPCHK(c, hipGetLastError());
   return 0;

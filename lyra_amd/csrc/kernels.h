@@ -121,6 +121,7 @@ __global__ void cng_kernel(const MelP* P, unsigned long long seed, const int32_t
                            const uint8_t* noise_state, const float* features, int16_t* pcm);
 __global__ void noise_read_kernel(const int32_t* ids, int B, const uint8_t* state, int field_off, float* out);
 size_t logmel_lds_bytes();
+size_t cng_lds_bytes();
 struct ResetP { int8_t e_r2_1, e_r2_2, e_d2, e_bott, d_r0_0, d_r0_1, d_r0_2; };
 // region base pointers and per-stream slot sizes (state_layout.h), filled on the host, passed by value
 struct StateMap { uint8_t* base[st::R_COUNT]; int bytes[st::R_COUNT]; };

@@ -30,6 +30,7 @@ static __device__ int g_lyra_exit_at = -1;
 #define LYRA_TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lyra_tdbg[i] = clock64(); \
     if (g_lyra_exit_at == (i)) return; } while (0)
 #define LYRA_WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lyra_tdbg[i] = wall_clock64(); } while (0)
+#define LYRA_TSTAMP2(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lyra_tdbg[i] = clock64(); } while (0)   // no early exit
 // per-workgroup trace: [wg][0] start (100 MHz wall clock), [1] end, [2] HW_ID, [3] XCC_ID
 static __device__ long long g_lyra_wgtrace[2048 * 4];
 #define LYRA_WG_BEGIN() do { if (threadIdx.x == 0 && blockIdx.x < 2048) { \
@@ -42,6 +43,7 @@ static __device__ long long g_lyra_wgtrace[2048 * 4];
 #define LYRA_WG_END() do { } while (0)
 #define LYRA_WSTAMP(i) do { } while (0)
 #define LYRA_TSTAMP(i) do { } while (0)
+#define LYRA_TSTAMP2(i) do { } while (0)
 #endif
 
 namespace lyra {

@@ -1,6 +1,12 @@
 // misc_kernels.hip -- residual vector quantizer, packet (un)packing, log-mel front end, state reset.
 #include "kernels.h"
 
+#ifdef LYRA_TIMING
+extern "C" int lyra_hip_debug_timing_misc(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lyra_tdbg), sizeof(long long) * 128);
+}
+#endif
+
 namespace lyra {
 
 // The 64-term distance chain of one codeword, dims in ascending order: df = r - c, sq = df * df, sum = sum + sq, three
@@ -220,11 +226,17 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const float* __restrict
 // region (R_MEL) or the slot of one of the two NoiseEstimators (R_NOISE_E / R_NOISE_D own their extractor).
 // =============================================================================================
 // NoiseEstimator::ReceiveSamples' decision + recurrence for one stream per wavefront (defined below, next to its notes)
+// Everything noise_update_wave reads from a stream's slot, requested in ONE batch (noise_prefetch) ahead of the work
+// whose result it is compared with: lane l of the stream's wavefront owns bins l, l + 64, l + 128.
+struct NoisePre { float est[3], bound[3], sm[3], sq[3], tm[3]; int initialised, hops; };
+__device__ __forceinline__ NoisePre noise_prefetch(int id, const uint8_t* state, bool mine);
 template <int NW>
 __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool on, int id, int out_index, uint8_t* state,
-                                                  const float* mel, int32_t* is_noise_out, int32_t* masked_ids);
+                                                  const float* mel, const NoisePre& pre, float* sh, float* avg,
+                                                  int32_t* is_noise_out, int32_t* masked_ids);
 
-size_t logmel_lds_bytes() { return (size_t)(1024 * 2 + 160) * 8; }   // (+160: the comfort-noise kernel's mel vector)
+size_t logmel_lds_bytes() { return (size_t)1024 * 2 * 8; }             // the FFT buffer; everything later aliases dead parts of it
+size_t cng_lds_bytes() { return (size_t)(1024 * 2 + 160) * 8; }      // (+160: the comfort-noise kernel's mel vector)
 
 __device__ __forceinline__ int digit_reverse4_1024(int n) {   // reverse the five base-4 digits of n
   unsigned r = __brev((unsigned)n) >> 22;
@@ -240,53 +252,75 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
                                                       float* __restrict__ mel, int noise_tail, NoiseP NP,
                                                       int32_t* __restrict__ is_noise_out,
                                                       int32_t* __restrict__ masked_ids) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
   const MelP& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  double* re = dsm;
-  double* im = dsm + 1024;
-  double* mag0 = re;                  // |X_A[k]|, k = 0..512, written in place over Z (see below)
-  double* mag1 = im;                  // |X_B[k]|
-  float* mel_lds = reinterpret_cast<float*>(dsm + 2048);   // [2][160] floats in the 160 spare doubles (noise tail)
+  f64x2* z = reinterpret_cast<f64x2*>(dsm);   // Z[1024], (re, im) = (frame A, frame B) interleaved; later (|X_A[k]|, |X_B[k]|)
+  // LDS reuse once the two spectra are separated (z[k], k > 512, is then dead): the mel weights of bins 0..512, the hop's
+  // mel vectors [2][160] floats and noise_update_wave's [2][2][160] + [2][2] floats -- 16 KB per workgroup in all
+  double* wl = dsm + 1026;
+  float* mel_lds = reinterpret_cast<float*>(dsm + 1540);
+  float* tail_sh = reinterpret_cast<float*>(dsm + 1540 + 160);
+  float* tail_avg = reinterpret_cast<float*>(dsm + 1540 + 160 + 320);
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * 2, b1 = b0 + 1;
   const bool two = b1 < B;
+  LYRA_TSTAMP(110);
   int16_t* prev0 = reinterpret_cast<int16_t*>(state + (size_t)ids[b0] * stride + prev_off);
   int16_t* prev1 = reinterpret_cast<int16_t*>(state + (size_t)ids[two ? b1 : b0] * stride + prev_off);
-  // window = [previous hop | this hop] x periodic Hann, zero-padded to 1024, in digit-reversed order.  Items of eight
-  // samples (one 16-byte load each): 80 per frame; the previous hop is replaced in the same pass (each item rewrites
-  // exactly the eight history samples it has just read, or none).
-  for (int i = 640 + tid; i < 1024; i += 256) { const int r = digit_reverse4_1024(i); re[r] = 0.0; im[r] = 0.0; }
-  if (tid < 160) {
-    const int f = tid >= 80, c = tid - 80 * f;            // frame, chunk of 8 samples within the 640-sample window
-    if (!f || two) {
-      int16_t* prev = f ? prev1 : prev0;
-      const int16_t* cur = pcm + (size_t)(f ? b1 : b0) * 320;
-      const i32x4 raw = c < 40 ? *reinterpret_cast<const i32x4*>(prev + c * 8)
-                               : *reinterpret_cast<const i32x4*>(cur + (c - 40) * 8);
-      if (c < 40) *reinterpret_cast<i32x4*>(prev + c * 8) = *reinterpret_cast<const i32x4*>(cur + c * 8);
-      double* dst = f ? im : re;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int i = c * 8 + e;
-        const int16_t x = (int16_t)((raw[e >> 1] >> ((e & 1) * 16)) & 0xffff);
-        dst[digit_reverse4_1024(i)] = (double)x * P.hann[i];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) im[digit_reverse4_1024(c * 8 + e)] = 0.0;
-    }
+  const int16_t* cur0 = pcm + (size_t)b0 * 320;
+  const int16_t* cur1 = pcm + (size_t)(two ? b1 : b0) * 320;
+  // window = [previous hop | this hop] x periodic Hann, zero-padded to 1024.  The first radix-4 pass of a decimation-in-
+  // time transform combines x[n], x[n+256], x[n+512], x[n+768]: thread n reads its own three window samples of both
+  // frames (x[n+768] = 0; x[n+512] = 0 for n >= 128) straight from memory, does that butterfly in registers and writes
+  // the four results where the second pass expects them (4 * digit-reverse(n) + q) -- no staging pass, no scatter of
+  // single samples.  The samples of this hop it holds are exactly the stream's next history: thread n >= 64 holds
+  // sample n-64 of the hop, thread n < 128 sample n+192.
+  const int n = tid;
+  const bool has1 = n >= 64, has2 = n < 128;
+  const int16_t a0 = prev0[n], a1 = prev1[n];
+  const int16_t b0s = has1 ? cur0[n - 64] : prev0[n + 256], b1s = has1 ? cur1[n - 64] : prev1[n + 256];
+  const int16_t c0s = has2 ? cur0[n + 192] : (int16_t)0, c1s = has2 ? cur1[n + 192] : (int16_t)0;
+  const double h0 = P.hann[n], h1 = P.hann[n + 256], h2 = has2 ? P.hann[n + 512] : 0.0;
+  // twiddles of the second pass (L = 4), requested before the first butterfly; mel weights and band edges for the epilogue
+  double w1r, w1i, w2r, w2i, w3r, w3i;
+  {
+    const int t1 = (tid & 3) * 64;
+    w1r = P.tw4_re[t1]; w1i = P.tw4_im[t1]; w2r = P.tw4_re[2 * t1]; w2i = P.tw4_im[2 * t1];
+    w3r = P.tw4_re[3 * t1]; w3i = P.tw4_im[3 * t1];
+  }
+  const double wsel0 = P.w[tid], wsel1 = P.w[tid + 256], wsel2 = tid == 0 ? P.w[512] : 0.0;
+  // band sums: 320 (frame, band) items on 256 threads -- thread t < 160 takes (frame 0, band t), thread t >= 160 takes
+  // (frame 1, band t - 96) i.e. the 96 widest bands, and threads t < 64 then also take (frame 1, band t), the narrow ones:
+  // the longest chain is ONE wide band (<= 18 bins)
+  const int my_band = tid < 160 ? tid : tid - 96;
+  const int be0 = P.band[my_band], be1 = P.band[my_band + 1], be2 = P.band[my_band + 2];
+  {
+    const double ar = (double)a0 * h0, ai = two ? (double)a1 * h0 : 0.0;
+    const double br = (double)b0s * h1, bi = two ? (double)b1s * h1 : 0.0;
+    const double cr = (double)c0s * h2, ci = two ? (double)c1s * h2 : 0.0;
+    const double s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;   // d = 0: b + d = b - d = b
+    unsigned r = __brev((unsigned)n) >> 24;                                     // reverse the four base-4 digits of n
+    r = ((r & 0xAAu) >> 1) | ((r & 0x55u) << 1);
+    f64x2* o = z + 4 * r;
+    o[0] = (f64x2){s0r + br, s0i + bi};
+    o[1] = (f64x2){s1r + bi, s1i - br};     // (a - c) - i b
+    o[2] = (f64x2){s0r - br, s0i - bi};
+    o[3] = (f64x2){s1r - bi, s1i + br};     // (a - c) + i b
   }
   __syncthreads();
-  // five radix-4 decimation-in-time passes; pass s combines four L-point transforms (L = 4^s) into one 4L-point one:
+  // every read of the old history is done: the hop becomes the history
+  if (has1) { prev0[n - 64] = b0s; if (two) prev1[n - 64] = b1s; }
+  if (has2) { prev0[n + 192] = c0s; if (two) prev1[n + 192] = c1s; }
+  LYRA_TSTAMP(111);
+  // four more radix-4 passes; pass s combines four L-point transforms (L = 4^s) into one 4L-point one:
   //   y_q = sum_r (-i)^(r q) W_4L^(r k) F_r[k].  The twiddles of pass s+1 (L2-resident table) are requested before
   // the butterflies of pass s, so their latency hides behind the LDS round trip and the barrier.
-  double w1r = 1.0, w1i = 0.0, w2r = 1.0, w2i = 0.0, w3r = 1.0, w3i = 0.0;   // pass 0: L = 1, k = 0
-  const double wsel0 = P.w[tid + 1], wsel1 = tid < 254 ? P.w[tid + 257] : 0.0;   // mel weights, parked for the epilogue
-#pragma unroll 1
-  for (int s = 0; s < 5; ++s) {
+#pragma unroll
+  for (int s = 1; s < 5; ++s) {
     const int L = 1 << (2 * s);
     const int k = tid & (L - 1), g = tid >> (2 * s);
-    const int i0 = g * 4 * L + k, i1 = i0 + L, i2 = i1 + L, i3 = i2 + L;
+    f64x2* p = z + g * 4 * L + k;
     double n1r = 1.0, n1i = 0.0, n2r = 1.0, n2i = 0.0, n3r = 1.0, n3i = 0.0;
     if (s < 4) {
       const int Ln = 4 * L, kn = tid & (Ln - 1);
@@ -294,62 +328,76 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
       n1r = P.tw4_re[t1]; n1i = P.tw4_im[t1]; n2r = P.tw4_re[2 * t1]; n2i = P.tw4_im[2 * t1];
       n3r = P.tw4_re[3 * t1]; n3i = P.tw4_im[3 * t1];
     }
-    const double ar = re[i0], ai = im[i0];
-    const double xr1 = re[i1], xi1 = im[i1], xr2 = re[i2], xi2 = im[i2], xr3 = re[i3], xi3 = im[i3];
-    const double br = xr1 * w1r - xi1 * w1i, bi = xr1 * w1i + xi1 * w1r;
-    const double cr = xr2 * w2r - xi2 * w2i, ci = xr2 * w2i + xi2 * w2r;
-    const double dr = xr3 * w3r - xi3 * w3i, di = xr3 * w3i + xi3 * w3r;
-    const double s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
+    const f64x2 xa = p[0], x1 = p[L], x2 = p[2 * L], x3 = p[3 * L];
+    const double br = __builtin_fma(x1.x, w1r, -(x1.y * w1i)), bi = __builtin_fma(x1.x, w1i, x1.y * w1r);
+    const double cr = __builtin_fma(x2.x, w2r, -(x2.y * w2i)), ci = __builtin_fma(x2.x, w2i, x2.y * w2r);
+    const double dr = __builtin_fma(x3.x, w3r, -(x3.y * w3i)), di = __builtin_fma(x3.x, w3i, x3.y * w3r);
+    const double s0r = xa.x + cr, s0i = xa.y + ci, s1r = xa.x - cr, s1i = xa.y - ci;
     const double s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
-    re[i0] = s0r + s2r; im[i0] = s0i + s2i;
-    re[i1] = s1r + s3i; im[i1] = s1i - s3r;     // (a - c) - i (b - d)
-    re[i2] = s0r - s2r; im[i2] = s0i - s2i;
-    re[i3] = s1r - s3i; im[i3] = s1i + s3r;     // (a - c) + i (b - d)
+    p[0] = (f64x2){s0r + s2r, s0i + s2i};
+    p[L] = (f64x2){s1r + s3i, s1i - s3r};         // (a - c) - i (b - d)
+    p[2 * L] = (f64x2){s0r - s2r, s0i - s2i};
+    p[3 * L] = (f64x2){s1r - s3i, s1i + s3r};     // (a - c) + i (b - d)
     w1r = n1r; w1i = n1i; w2r = n2r; w2i = n2i; w3r = n3r; w3i = n3i;
     __syncthreads();
   }
+  LYRA_TSTAMP(112);
   // Z = FFT(a + i b):  A[k] = (Z[k] + conj(Z[N-k])) / 2,  B[k] = (Z[k] - conj(Z[N-k])) / (2 i).  In place: the item
   // for bin k <= 512 reads Z[k] and Z[N - k] and writes index k only; index k < 512 is read by no other item and
   // indices > 512 are never written, so no staging buffer (and no barrier before the writes) is needed.
   for (int k = tid; k <= 512; k += 256) {
-    const int n = (1024 - k) & 1023;
-    const double zr = re[k], zi = im[k], yr = re[n], yi = im[n];
-    const double Ar = 0.5 * (zr + yr), Ai = 0.5 * (zi - yi);
-    const double Br = 0.5 * (zi + yi), Bi = 0.5 * (yr - zr);
-    mag0[k] = __builtin_sqrt(Ar * Ar + Ai * Ai);
-    mag1[k] = __builtin_sqrt(Br * Br + Bi * Bi);
+    const int nk = (1024 - k) & 1023;
+    const f64x2 zz = z[k], yy = z[nk];
+    const double Ar = 0.5 * (zz.x + yy.x), Ai = 0.5 * (zz.y - yy.y);
+    const double Br = 0.5 * (zz.y + yy.y), Bi = 0.5 * (yy.x - zz.x);
+    z[k] = (f64x2){__builtin_sqrt(Ar * Ar + Ai * Ai), __builtin_sqrt(Br * Br + Bi * Bi)};
   }
   __syncthreads();
-  // the mel weights of bins 1..510 go to the now unused upper half of `re` (index 513 + bin): the band loops below
-  // would otherwise wait for one L2 round trip per bin
-  double* wl = re + 513;
-  wl[tid + 1] = wsel0;
-  if (tid < 254) wl[tid + 257] = wsel1;
+  LYRA_TSTAMP(113);
+  // the mel weights go to the now dead upper half of the buffer: the band loops below would otherwise wait for one L2
+  // round trip per bin
+  wl[tid] = wsel0;
+  wl[tid + 256] = wsel1;
+  if (tid == 0) wl[512] = wsel2;
   __syncthreads();
-  if (tid < 160) {
-    const int e0 = P.band[tid], e1 = P.band[tid + 1], e2 = P.band[tid + 2];
-#pragma unroll 1
-    for (int f = 0; f < (two ? 2 : 1); ++f) {
-      const double* mag = f ? mag1 : mag0;
-      // bins whose lower band is tid-1 contribute (v - v*w); bins whose lower band is tid contribute v*w
-      double acc = 0.0;
-      for (int i = e0; i < e1; ++i) { double v = mag[i]; double w = v * wl[i]; acc += v - w; }
-      for (int i = e1; i < e2; ++i) { double v = mag[i]; acc += v * wl[i]; }
-      float v = (float)acc;
-      v = v > 500.f ? v : 500.f;
-      // log evaluated in double and rounded once: identical on host and device (oracle/lyra_oracle.c log_f)
-      const float lm = (float)log((double)v) / 10.f;
-      if (mel) mel[(size_t)(b0 + f) * 160 + tid] = lm;
-      if (noise_tail) mel_lds[f * 160 + tid] = lm;
+  LYRA_TSTAMP(114);
+  // the noise tail's view of the stream's slot is requested here, one batch, and arrives under the band sums
+  const int tw = tid >> 6;
+  const int tail_id = ids[(tw == 1 && two) ? b1 : b0];
+  NoisePre npre = {};
+  if (noise_tail) npre = noise_prefetch(tail_id, state, tw < 2);
+  // bins whose lower band is b-1 contribute (v - v*w) to band b, bins whose lower band is b contribute v*w; ascending
+  // bin order (== the reference's scatter loop order per band); the next bin's operands are read one trip ahead
+  auto band_item = [&](int f, int band) {
+    const double* mag = dsm + f;          // |X_f[i]| = mag[2 * i]
+    double acc = 0.0;
+    double v = mag[2 * be0], wv = wl[be0];
+    for (int i = be0; i < be2; ++i) {
+      const double vn = mag[2 * i + 2], wn = wl[i + 1];
+      const double w = v * wv;
+      acc += i < be1 ? v - w : w;
+      v = vn; wv = wn;
     }
-  }
+    float x = (float)acc;
+    x = x > 500.f ? x : 500.f;
+    // log evaluated in double and rounded once: identical on host and device (oracle/lyra_oracle.c log_f)
+    const float lm = (float)log((double)x) / 10.f;
+    if (mel) mel[(size_t)(b0 + f) * 160 + band] = lm;
+    if (noise_tail) mel_lds[f * 160 + band] = lm;
+  };
+  if (tid < 160) band_item(0, tid);
+  else if (two) band_item(1, tid - 96);
+  if (tid < 64 && two) band_item(1, tid);
+  LYRA_TSTAMP(115);
   if (noise_tail) {   // (uniform)
     __syncthreads();
-    const int w = tid >> 6;
+    LYRA_TSTAMP2(120);
+    const int w = tw;
     const bool on = w == 0 || (w == 1 && two);
-    noise_update_wave<2>(NP, w, on, ids[(w == 1 && two) ? b1 : b0], b0 + (w & 1), state, mel_lds + (w & 1) * 160,
+    noise_update_wave<2>(NP, w, on, tail_id, b0 + (w & 1), state, mel_lds + (w & 1) * 160, npre, tail_sh, tail_avg,
                          is_noise_out, masked_ids);
   }
+  LYRA_TSTAMP(119);
 }
 
 // =============================================================================================
@@ -365,11 +413,31 @@ __device__ __forceinline__ float expf_via_double(float x) { return (float)exp((d
 
 // One wavefront = one stream (slot w of the workgroup, NW slots); every thread of the workgroup calls this (two
 // workgroup barriers inside).  `mel`: the hop's 160 log-mel bins (LDS or global); `on`: the slot holds a real stream.
+__device__ __forceinline__ NoisePre noise_prefetch(int id, const uint8_t* state, bool mine) {
+  const int lane = threadIdx.x & 63;
+  const uint8_t* base = state + (size_t)id * st::NOISE_BYTES;
+  const int* hdr = reinterpret_cast<const int*>(base);
+  NoisePre p;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int bin = lane + 64 * i;
+    const bool ld = mine && bin < 160;
+    p.est[i] = ld ? reinterpret_cast<const float*>(base + st::N_EST)[bin] : 0.f;
+    p.bound[i] = ld ? reinterpret_cast<const float*>(base + st::N_BOUND)[bin] : 0.f;
+    p.sm[i] = ld ? reinterpret_cast<const float*>(base + st::N_SMOOTH)[bin] : 0.f;
+    p.sq[i] = ld ? reinterpret_cast<const float*>(base + st::N_SQ)[bin] : 0.f;
+    p.tm[i] = ld ? reinterpret_cast<const float*>(base + st::N_TMPMIN)[bin] : 0.f;
+  }
+  p.initialised = hdr[st::N_INIT / 4];
+  p.hops = hdr[st::N_HOPS / 4];
+  return p;
+}
+
 template <int NW>
 __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool on, int id, int out_index, uint8_t* state,
-                                                  const float* mel, int32_t* is_noise_out, int32_t* masked_ids) {
-  __shared__ float sh[NW][2][160];
-  __shared__ float avg[NW][2];
+                                                  const float* mel, const NoisePre& pre, float* sh, float* avg,
+                                                  int32_t* is_noise_out, int32_t* masked_ids) {
+  // sh: [NW][2][160] floats, avg: [NW][2] floats of LDS scratch owned by the caller
   const int lane = threadIdx.x & 63;
   const bool mine = w < NW;          // waves beyond the NW slots only take part in the barriers
   const int ws = mine ? w : 0;
@@ -388,14 +456,14 @@ __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool o
     cur[i] = est[i] = bound[i] = 0.f;
     if (bin < 160 && mine) {
       cur[i] = mel[bin];
-      est[i] = f_est[bin];
-      bound[i] = f_bound[bin];
+      est[i] = pre.est[i];
+      bound[i] = pre.bound[i];
       differs = differs || (__builtin_fabsf(cur[i] - est[i]) > bound[i]);
     }
   }
   const bool is_noise = __builtin_amdgcn_ballot_w64(differs) == 0ull;   // ComputeIsNoise (wave-uniform)
-  const int initialised = hdr[st::N_INIT / 4];
-  const int hops = hdr[st::N_HOPS / 4];
+  const int initialised = pre.initialised;
+  const int hops = pre.hops;
   float sm[3], sq[3], tm[3];
   if (!is_noise && mine) {
 #pragma unroll
@@ -403,20 +471,22 @@ __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool o
       const int bin = lane + 64 * i;
       sm[i] = sq[i] = tm[i] = 0.f;
       if (bin < 160) {
-        if (initialised) { sm[i] = f_smooth[bin]; sq[i] = f_sq[bin]; tm[i] = f_tmp[bin]; }
+        if (initialised) { sm[i] = pre.sm[i]; sq[i] = pre.sq[i]; tm[i] = pre.tm[i]; }
         else { sm[i] = cur[i]; sq[i] = cur[i] * cur[i]; tm[i] = cur[i]; }   // first update (noise_estimator.cc:180-186)
-        sh[ws][0][bin] = sm[i];
-        sh[ws][1][bin] = cur[i];
+        sh[(ws * 2 + 0) * 160 + bin] = sm[i];
+        sh[(ws * 2 + 1) * 160 + bin] = cur[i];
       }
     }
   }
+  if (NW == 2) LYRA_TSTAMP2(116);
   __syncthreads();
   if (!is_noise && mine && lane < 2) {   // Average(): sequential float sum from 0.f, then / 160
     float a = 0.f;
-    for (int i = 0; i < 160; ++i) a = a + sh[ws][lane][i];
-    avg[ws][lane] = a / 160.f;
+    for (int i = 0; i < 160; ++i) a = a + sh[(ws * 2 + lane) * 160 + i];
+    avg[ws * 2 + lane] = a / 160.f;
   }
   __syncthreads();
+  if (NW == 2) LYRA_TSTAMP2(117);
   if (!on || !mine) return;
   if (is_noise) {
 #pragma unroll
@@ -426,7 +496,7 @@ __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool o
     }
   } else {
     const float kPowDiff = 0.3f;
-    const float dd = (avg[ws][0] - avg[ws][1]) / kPowDiff;
+    const float dd = (avg[ws * 2 + 0] - avg[ws * 2 + 1]) / kPowDiff;
     const float correction = expf_via_double(-(dd * dd));
     const double logn = 5.075173815233827;   // std::log(160) in double (noise_bound_.size())
 #pragma unroll
@@ -448,6 +518,7 @@ __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool o
       }
     }
   }
+  if (NW == 2) LYRA_TSTAMP2(118);
   if (lane == 0) {
     if (!is_noise) {
       hdr[st::N_INIT / 4] = 1;
@@ -468,7 +539,11 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32
   const int b = blockIdx.x * 4 + w;
   const bool on = b < B;
   const int bb = on ? b : B - 1;
-  noise_update_wave<4>(P, w, on, ids[bb], b, state, mel + (size_t)bb * 160, is_noise_out, masked_ids);
+  const int id = ids[bb];
+  __shared__ float sh[4 * 2 * 160];
+  __shared__ float avg[4 * 2];
+  const NoisePre pre = noise_prefetch(id, state, true);
+  noise_update_wave<4>(P, w, on, id, b, state, mel + (size_t)bb * 160, pre, sh, avg, is_noise_out, masked_ids);
 }
 
 // noise_estimate() / noise_bound() of B streams -> dense [B][160] (NoiseEstimator::noise_estimate, :229-231)
