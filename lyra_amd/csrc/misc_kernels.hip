@@ -480,10 +480,24 @@ __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool o
   }
   if (NW == 2) LYRA_TSTAMP2(116);
   __syncthreads();
-  if (!is_noise && mine && lane < 2) {   // Average(): sequential float sum from 0.f, then / 160
+  // Average(): sequential float sum from 0.f, then / 160 -- one lane per sum.  In a workgroup with a wavefront to spare
+  // (256 threads, NW < 4) that wavefront does all 2 * NW sums at once (of rows a noise hop left unwritten too: unused),
+  // off the path of the wavefronts that carry the streams.
+  constexpr bool kSpare = NW < 4;
+  // the per-bin factor of SmoothingFactor() does not need the averages: evaluated here, beside the summing lanes
+  float ebin[3] = {0.f, 0.f, 0.f};
+  if (!is_noise && mine) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float de = (sm[i] - est[i]) / 0.3f;
+      ebin[i] = expf_via_double(-(de * de));
+    }
+  }
+  if (kSpare ? (w == NW && lane < 2 * NW) : (!is_noise && mine && lane < 2)) {
+    const int row = kSpare ? lane : ws * 2 + lane;
     float a = 0.f;
-    for (int i = 0; i < 160; ++i) a = a + sh[(ws * 2 + lane) * 160 + i];
-    avg[ws * 2 + lane] = a / 160.f;
+    for (int i = 0; i < 160; ++i) a = a + sh[row * 160 + i];
+    avg[row] = a / 160.f;
   }
   __syncthreads();
   if (NW == 2) LYRA_TSTAMP2(117);
@@ -503,8 +517,7 @@ __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool o
     for (int i = 0; i < 3; ++i) {
       const int bin = lane + 64 * i;
       if (bin < 160) {
-        const float de = (sm[i] - est[i]) / kPowDiff;
-        const float sf = P.max_smoothing * correction * expf_via_double(-(de * de));
+        const float sf = P.max_smoothing * correction * ebin[i];
         const float c2 = cur[i] * cur[i];
         const float nsm = sf * sm[i] + (1.f - sf) * cur[i];   // (-ffp-contract=off: every product rounded)
         const float nsq = sf * sq[i] + (1.f - sf) * c2;

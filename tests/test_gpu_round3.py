@@ -350,3 +350,23 @@ def test_run_steps_full_pipeline_at_benchmark_scale(golden_dir):
     finally:
         A.close()
         Bc.close()
+
+
+def test_sliced_stage_launches_are_invisible(monkeypatch):
+    """LYRA_HIP_TILE_DIV_<KERNEL>=k (api.hip tile_div) launches a stage kernel as k slices with a first-tile offset
+    (kernel parameter tile0).  Uneven slice counts on a ragged batch (B = 1003: last tile partial, last slice short) must
+    give the same packets and PCM as the plain launch, hop after hop."""
+    import lyra_amd
+    B, T, bits = 1003, 6, 184
+    pcm = synth(B, T, seed=424242)
+    plain = lyra_amd.LyraHip(max_streams=B)
+    for name, k in (("ENC_S0", 3), ("ENC_S1", 2), ("ENC_S2", 5), ("DEC_S0", 2), ("DEC_S1", 3), ("DEC_S2", 7)):
+        monkeypatch.setenv("LYRA_HIP_TILE_DIV_" + name, str(k))
+    sliced = lyra_amd.LyraHip(max_streams=B)
+    try:
+        for t in range(T):
+            pa, pb = plain.encode(pcm[t], bits), sliced.encode(pcm[t], bits)
+            assert np.array_equal(pa, pb), f"packets differ at hop {t}"
+            assert np.array_equal(plain.decode(pa, bits), sliced.decode(pb, bits)), f"PCM differs at hop {t}"
+    finally:
+        plain.close(); sliced.close()
