@@ -995,7 +995,7 @@ int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, cons
   if (n_out > 960) return fail(c, LYRA_HIP_EINVAL, "resample: %d output samples per stream exceed 960", n_out);
   hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
   { ProfScope ps(c, K_RESAMPLE, st_);
-    hipLaunchKernelGGL(resample_kernel, dim3(B), dim3(256), (size_t)(st::RS_TAPS - 1 + n_in) * 4, st_, P, d_ids, B,
+    hipLaunchKernelGGL(resample_kernel, dim3(cdiv(B, resample_streams_per_wg())), dim3(256), resample_lds_bytes(n_in), st_, P, d_ids, B,
                        c->sm.base[side == 0 ? st::R_RS_E : st::R_RS_D], d_in, n_in, in_stride > 0 ? in_stride : n_in, d_out,
                        n_out, out_stride > 0 ? out_stride : n_out); }
   HIPCHK(c, hipGetLastError());

@@ -105,6 +105,8 @@ __global__ void noise_update_kernel(NoiseP P, const int32_t* ids, int B, uint8_t
                                     int32_t* is_noise_out, int32_t* masked_ids);
 // Resampler (lyra/resampler.cc): out/in = up/down, coef[phase][tap] oldest tap first (oracle lo_resampler_design)
 struct ResampleP { int up, down; float coef[3][40]; };
+int resample_streams_per_wg();
+size_t resample_lds_bytes(int n_in);
 // in_stride / out_stride: samples between consecutive streams' rows (>= n_in / n_out: a chunk of longer rows)
 __global__ void resample_kernel(ResampleP P, const int32_t* ids, int B, uint8_t* state, const int16_t* in, int n_in,
                                 int in_stride, int16_t* out, int n_out, int out_stride);

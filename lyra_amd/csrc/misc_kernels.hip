@@ -572,39 +572,77 @@ __global__ __launch_bounds__(256) void noise_read_kernel(const int32_t* __restri
 // =============================================================================================
 // Resampler::Resample (lyra/resampler.cc:57-62): audio_dsp::QResampler<float> restated as a polyphase FIR sampled from
 // a Kaiser-windowed sinc (oracle/lyra_oracle.c lo_resampler_design builds the same table; parity statement there).
-// One workgroup per stream: [34 history samples | n_in new samples] as floats in LDS, one output per thread and
-// iteration, taps oldest first in float -- bitwise the oracle's loop.  up-sampling: `up` outputs per input sample;
-// down-sampling: one output per `down` inputs, phase carried in the stream's slot.
+// One wavefront per stream, four streams per workgroup: [34 history samples | n_in new samples] as floats in LDS, taps
+// oldest first in float with separately rounded products -- bitwise the oracle's loop.  up-sampling: `up` outputs per
+// input sample; down-sampling: one output per `down` inputs, phase carried in the stream's slot.
 // =============================================================================================
+int resample_streams_per_wg() { return 4; }
+size_t resample_lds_bytes(int n_in) { return (size_t)4 * ((st::RS_TAPS - 1 + n_in + 3) & ~3) * 4; }
+
 __global__ __launch_bounds__(256) void resample_kernel(ResampleP P, const int32_t* __restrict__ ids, int B,
                                                         uint8_t* __restrict__ state, const int16_t* __restrict__ in,
                                                         int n_in, int in_stride, int16_t* __restrict__ out, int n_out,
                                                         int out_stride) {
-  extern __shared__ __attribute__((aligned(16))) float rsb[];   // [RS_TAPS - 1 + n_in]
+  extern __shared__ __attribute__((aligned(16))) float rsb_all[];   // [4][RS_TAPS - 1 + n_in, padded to 4]
   constexpr int H = st::RS_TAPS - 1;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  uint8_t* slot = state + (size_t)ids[b] * st::RS_BYTES;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x * 4 + w;
+  const bool on = b < B;
+  const int bb = on ? b : B - 1;
+  float* rsb = rsb_all + w * ((H + n_in + 3) & ~3);
+  const int16_t* src = in + (size_t)bb * in_stride;
+  // the new samples do not wait for the stream id; 16-byte items when the rows allow it
+  const bool vec = ((in_stride | n_in) & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  if (vec) {
+    for (int c = lane; c * 8 < n_in; c += 64) {
+      const i32x4 raw = *reinterpret_cast<const i32x4*>(src + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rsb[H + c * 8 + e] = (float)(int16_t)((raw[e >> 1] >> ((e & 1) * 16)) & 0xffff);
+    }
+  } else {
+    for (int i = lane; i < n_in; i += 64) rsb[H + i] = (float)src[i];
+  }
+  uint8_t* slot = state + (size_t)ids[bb] * st::RS_BYTES;
   float* hist = reinterpret_cast<float*>(slot + st::RS_HIST);
   const int in_pos = *reinterpret_cast<const int*>(slot + st::RS_IN_POS);
-  for (int i = tid; i < H + n_in; i += 256) rsb[i] = i < H ? hist[i] : (float)in[(size_t)b * in_stride + (i - H)];
+  if (lane < H) rsb[lane] = hist[lane];
   __syncthreads();
-  // first input index (0-based in this call) that yields an output when decimating
-  const int first = P.down == 1 ? 0 : ((P.down - in_pos % P.down) % P.down);
-  for (int o = tid; o < n_out; o += 256) {
-    int k, p;
-    if (P.down == 1) { k = o / P.up; p = o - k * P.up; }
-    else { k = first + o * P.down; p = 0; }
-    float acc = 0.f;
-#pragma unroll 5
-    for (int j = 0; j < st::RS_TAPS; ++j) acc = acc + P.coef[p][j] * rsb[k + j];
-    acc = acc < -32768.f ? -32768.f : (acc > 32767.f ? 32767.f : acc);   // ClipToInt16 (dsp_utils.h:56-72)
-    out[(size_t)b * out_stride + o] = (int16_t)acc;
+  if (!on) return;
+  int16_t* dst = out + (size_t)b * out_stride;
+  auto clip = [](float acc) { return (int16_t)(acc < -32768.f ? -32768.f : (acc > 32767.f ? 32767.f : acc)); };   // ClipToInt16 (dsp_utils.h:56-72)
+  if (P.down == 1) {
+    // interpolation: output k * up + ph is phase ph of the window at input k -- a lane takes input positions
+    // k = lane, lane + 64, ...: one window of 35 samples in registers feeds all `up` phases, coefficients are scalars
+    for (int k = lane; k < n_in; k += 64) {
+      float win[st::RS_TAPS];
+#pragma unroll
+      for (int j = 0; j < st::RS_TAPS; ++j) win[j] = rsb[k + j];
+#pragma unroll
+      for (int ph = 0; ph < 3; ++ph) {
+        if (ph < P.up) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < st::RS_TAPS; ++j) acc = acc + P.coef[ph][j] * win[j];
+          dst[k * P.up + ph] = clip(acc);
+        }
+      }
+    }
+  } else {
+    // decimation: the first input index (0-based in this call) that yields an output follows from the carried phase
+    const int first = (P.down - in_pos % P.down) % P.down;
+    for (int o = lane; o < n_out; o += 64) {
+      const int k = first + o * P.down;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < st::RS_TAPS; ++j) acc = acc + P.coef[0][j] * rsb[k + j];
+      dst[o] = clip(acc);
+    }
   }
-  __syncthreads();
-  for (int i = tid; i < H; i += 256) hist[i] = rsb[n_in + i];
+  // (same wavefront wrote and read this row: no barrier needed before the history leaves it)
+  if (lane < H) hist[lane] = rsb[n_in + lane];
   // only the decimation phase is ever used: kept modulo 6 = lcm of the possible `down` factors (1, 2, 3), so the
   // counter never wraps out of phase however long the stream runs (the oracle keeps an unbounded counter)
-  if (tid == 0) *reinterpret_cast<int*>(slot + st::RS_IN_POS) = (in_pos + n_in) % 6;
+  if (lane == 0) *reinterpret_cast<int*>(slot + st::RS_IN_POS) = (in_pos + n_in) % 6;
 }
 
 // =============================================================================================
