@@ -70,6 +70,10 @@ struct lyra_hip_ctx {
   int32_t* d_ids = nullptr;      // encode-side staging of host ids
   int32_t* d_ids_dec = nullptr;  // decode-side staging of host ids
   int16_t* d_pcm_in = nullptr;
+  int16_t* d_rs16[2] = {};        // run_steps: the input resampler's 16 kHz hops, by step parity (resample_in_ahead)
+  hipEvent_t ev_rs_in[2] = {};     // ... and the end of the launch that filled each
+  hipEvent_t ev_rs_order = nullptr;
+  long n_rs_in = 0;               // input resamplers enqueued on the quantizer stream so far
   float* d_e0 = nullptr;     // [cap][4][128]
   float* d_e1 = nullptr;     // [cap][2][256]
   float* d_feat = nullptr;   // [cap][64]
@@ -164,6 +168,7 @@ void free_scratch(lyra_hip_ctx* c) {
   c->d_d0 = nullptr; c->d_d1 = nullptr; c->d_pcm_out = nullptr; c->d_mel = nullptr; c->d_mel_enc = nullptr;
   c->d_flag_enc = nullptr; c->d_flag_dec = nullptr; c->d_live_ids = nullptr; c->d_live_ids2 = nullptr; c->d_pkt_bytes = nullptr;
   c->d_rs_in = nullptr; c->d_rs_out = nullptr;
+  for (auto& p : c->d_rs16) { if (p) (void)hipFree(p); p = nullptr; }
   c->cap = 0;
 }
 
@@ -196,6 +201,8 @@ int ensure_scratch(lyra_hip_ctx* c, int B) {
   HIPCHK(c, dalloc(&c->d_pkt_bytes, n));
   HIPCHK(c, dalloc(&c->d_rs_in, n * 960));
   HIPCHK(c, dalloc(&c->d_rs_out, n * 960));
+  HIPCHK(c, dalloc(&c->d_rs16[0], n * 320));
+  HIPCHK(c, dalloc(&c->d_rs16[1], n * 320));
   c->cap = B;
   return 0;
 }
@@ -698,7 +705,10 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipStreamCreateWithPriority(&c->sn, hipStreamNonBlocking, prio_lo) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_noise[0], evflags) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_noise[1], evflags) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_noise[1], evflags) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_rs_in[0], evflags) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_rs_in[1], evflags) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_rs_order, evflags) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
@@ -769,6 +779,9 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   }
   for (hipEvent_t e : c->ev_noise)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_rs_in)
+    if (e) (void)hipEventDestroy(e);
+  if (c->ev_rs_order) (void)hipEventDestroy(c->ev_rs_order);
   if (c->sn) (void)hipStreamDestroy(c->sn);
   if (c->d_state) (void)hipFree(c->d_state);
   free_model(&c->model);
@@ -984,8 +997,19 @@ static bool resample_design(int in_rate, int out_rate, ResampleP* P) {
 }
 
 // side 0: the encoder's resampler slot (external rate -> 16 kHz, encode-side stream); 1: the decoder's (16 kHz -> external)
+// The decoder-side resampler's slots may have been touched last on the noise stream (run_steps puts the output resampler
+// there, resample_deferred below): a decode-stream launch is ordered after everything enqueued on sn.
+int wait_noise_stream(lyra_hip_ctx* c) {
+  if (c->n_noise_calls > c->noise_done_dec) {
+    HIPCHK(c, hipStreamWaitEvent(c->sd[0], c->ev_noise[(c->n_noise_calls - 1) & 1], 0));
+    if (c->nsub == 1) c->noise_done_dec = c->n_noise_calls;
+  }
+  return 0;
+}
+
 int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
-                    int out_rate, int16_t* d_out, int* n_out_p, int in_stride = 0, int out_stride = 0) {
+                    int out_rate, int16_t* d_out, int* n_out_p, int in_stride = 0, int out_stride = 0,
+                    hipStream_t on_stream = nullptr) {
   ResampleP P;
   if (!resample_design(in_rate, out_rate, &P))
     return fail(c, LYRA_HIP_EINVAL, "unsupported resampling %d -> %d Hz (one side must be 16000; 8000/16000/32000/48000)", in_rate, out_rate);
@@ -993,7 +1017,8 @@ int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, cons
     return fail(c, LYRA_HIP_EINVAL, "resample: %d input samples per stream (must be 1..960 and a multiple of %d)", n_in, P.down);
   const int n_out = n_in * P.up / P.down;
   if (n_out > 960) return fail(c, LYRA_HIP_EINVAL, "resample: %d output samples per stream exceed 960", n_out);
-  hipStream_t st_ = side == 0 ? c->se[0] : c->sd[0];
+  hipStream_t st_ = on_stream ? on_stream : side == 0 ? c->se[0] : c->sd[0];
+  if (side == 1 && !on_stream) { int rc = wait_noise_stream(c); if (rc) return rc; }
   { ProfScope ps(c, K_RESAMPLE, st_);
     hipLaunchKernelGGL(resample_kernel, dim3(cdiv(B, resample_streams_per_wg())), dim3(256), resample_lds_bytes(n_in), st_, P, d_ids, B,
                        c->sm.base[side == 0 ? st::R_RS_E : st::R_RS_D], d_in, n_in, in_stride > 0 ? in_stride : n_in, d_out,
@@ -1005,10 +1030,7 @@ int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, cons
 
 int launch_cng(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_features, int16_t* d_pcm) {
   // reads the decoder-side noise estimate: after every decoder-side `_dev` noise call (they run on sn)
-  if (!d_features && c->n_noise_calls > c->noise_done_dec) {
-    HIPCHK(c, hipStreamWaitEvent(c->sd[0], c->ev_noise[(c->n_noise_calls - 1) & 1], 0));
-    if (c->nsub == 1) c->noise_done_dec = c->n_noise_calls;
-  }
+  if (!d_features) { int rc = wait_noise_stream(c); if (rc) return rc; }
   { ProfScope ps(c, K_CNG, c->sd[0]);
     hipLaunchKernelGGL(cng_kernel, dim3(B), dim3(256), cng_lds_bytes(), c->sd[0], c->model.d_mel, c->cng_seed, d_ids, B,
                        c->sm.base[st::R_CNG], (const uint8_t*)c->sm.base[st::R_NOISE_D], d_features, d_pcm); }
@@ -1024,6 +1046,7 @@ int lyra_hip_resample_dev(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B
   DEVSCOPE(c);
   if (side == 0) {
     if ((rc = enc_side_begin(c, 0))) return rc;
+    if (c->n_rs_in) HIPCHK(c, hipStreamWaitEvent(c->se[0], c->ev_rs_in[(c->n_rs_in - 1) & 1], 0));   // (same slots)
     rc = launch_resample(c, 0, d_ids, B, d_in, n_in, in_rate, out_rate, d_out, nullptr);
     if (!rc) rc = enc_side_done(c, 0);
     return rc;
@@ -1033,6 +1056,38 @@ int lyra_hip_resample_dev(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B
   if (!rc) rc = dec_side_done(c, 0, 1);
   c->n_dec_calls++;
   return rc;
+}
+
+// run_steps' output resampler (lyra_decoder.cc:107-113): like the decoder-side noise estimator it only consumes the hop
+// the decoder has just written, so it runs on the noise stream behind the decoder's last stage, underneath the next step,
+// instead of lengthening the decoder's chain.  Same bookkeeping as a decoder-side noise call: its input obeys the
+// two-buffer rule through dec_side_begin's wait for all noise-stream calls but the most recent one.
+int resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
+                      int out_rate, int16_t* d_out) {
+  DEVSCOPE(c);
+  int rc = noise_dev_begin(c);
+  if (rc) return rc;
+  rc = launch_resample(c, 1, d_ids, B, d_in, n_in, in_rate, out_rate, d_out, nullptr, 0, 0, c->sn);
+  if (!rc) rc = noise_dev_done(c);
+  return rc;
+}
+
+// run_steps' input resampler (lyra_encoder.cc:119-122) only depends on the caller's ring, so the hop of step i+1 is
+// resampled on the quantizer stream AHEAD of rvq_encode(i), underneath step i's feature extractor, into the buffer of its
+// parity; the extractor of step i+1 waits for its event.  The buffer it overwrites was last read by the extractor of step
+// i-1, which rvq_encode(i-1) -- earlier on the same stream -- has waited for.
+int resample_in_ahead(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate, long step,
+                      bool first_of_call) {
+  if (first_of_call) {   // after whatever the encode stream did to the resampler's slots before this call
+    HIPCHK(c, hipEventRecord(c->ev_rs_order, c->se[0]));
+    HIPCHK(c, hipStreamWaitEvent(c->sq[0], c->ev_rs_order, 0));
+  }
+  const int p = (int)(step & 1);
+  int rc = launch_resample(c, 0, d_ids, B, d_in, n_in, in_rate, 16000, c->d_rs16[p], nullptr, 0, 0, c->sq[0]);
+  if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev_rs_in[p], c->sq[0]));
+  c->n_rs_in++;
+  return 0;
 }
 
 int lyra_hip_resample(lyra_hip_ctx* c, int side, const int32_t* ids, int B, const int16_t* in, int n_in, int in_rate,
@@ -1370,9 +1425,18 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
     const int set = (int)(step & 1);
     if (enc) {
       const int16_t* in = S->d_pcm_ring + (size_t)(step % S->ring) * B * (size_t)n_ext;
-      if (rs) {   // lyra_encoder.cc:119-122: external rate -> 16 kHz, the encoder's own resampler
+      if (rs && c->serial) {   // lyra_encoder.cc:119-122: external rate -> 16 kHz, the encoder's own resampler
         if ((rc = lyra_hip_resample_dev(c, LYRA_HIP_SIDE_ENCODER, S->d_stream_ids, S->B, in, n_ext, ext, 16000, c->d_pcm_in))) return rc;
         in = c->d_pcm_in;
+      } else if (rs) {         // ... one step ahead, on the quantizer stream (resample_in_ahead)
+        DEVSCOPE(c);
+        if (i == 0 && (rc = resample_in_ahead(c, S->d_stream_ids, S->B, in, n_ext, ext, step, true))) return rc;
+        if (i + 1 < S->n_steps) {
+          const int16_t* nxt = S->d_pcm_ring + (size_t)((step + 1) % S->ring) * B * (size_t)n_ext;
+          if ((rc = resample_in_ahead(c, S->d_stream_ids, S->B, nxt, n_ext, ext, step + 1, false))) return rc;
+        }
+        for (int k = 0; k < c->nsub; ++k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_rs_in[step & 1], 0));
+        in = c->d_rs16[step & 1];
       }
       if (F & LYRA_HIP_STEP_DTX)
         rc = lyra_hip_encode_dtx_dev(c, S->d_stream_ids, S->B, in, S->num_bits, S->d_packets[set], S->d_packet_bytes[set]);
@@ -1392,7 +1456,7 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
       if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
         if ((rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise))) return rc;
       if (rs)     // lyra_decoder.cc:107-113 / buffered_resampler.cc: 16 kHz -> external rate
-        if ((rc = lyra_hip_resample_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set]))) return rc;
+        if ((rc = resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set]))) return rc;
     }
   }
   return 0;
