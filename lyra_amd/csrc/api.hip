@@ -72,8 +72,8 @@ struct lyra_hip_ctx {
   int16_t* d_pcm_in = nullptr;
   int16_t* d_rs16[2] = {};        // run_steps: the input resampler's 16 kHz hops, by step parity (resample_in_ahead)
   hipEvent_t ev_rs_in[2] = {};     // ... and the end of the launch that filled each
-  hipEvent_t ev_rs_order = nullptr;
-  long n_rs_in = 0;               // input resamplers enqueued on the quantizer stream so far
+  hipEvent_t ev_ahead_order = nullptr, ev_ahead_last = nullptr;
+  bool ahead_unseen = false;      // something ran ahead on sq[0] that se[0] has not been ordered after yet (wait_ahead)
   float* d_e0 = nullptr;     // [cap][4][128]
   float* d_e1 = nullptr;     // [cap][2][256]
   float* d_feat = nullptr;   // [cap][64]
@@ -708,7 +708,8 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       hipEventCreateWithFlags(&c->ev_noise[1], evflags) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_rs_in[0], evflags) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_rs_in[1], evflags) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_rs_order, evflags) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_ahead_order, evflags) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ahead_last, evflags) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
@@ -781,7 +782,8 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_rs_in)
     if (e) (void)hipEventDestroy(e);
-  if (c->ev_rs_order) (void)hipEventDestroy(c->ev_rs_order);
+  if (c->ev_ahead_order) (void)hipEventDestroy(c->ev_ahead_order);
+  if (c->ev_ahead_last) (void)hipEventDestroy(c->ev_ahead_last);
   if (c->sn) (void)hipStreamDestroy(c->sn);
   if (c->d_state) (void)hipFree(c->d_state);
   free_model(&c->model);
@@ -997,9 +999,29 @@ static bool resample_design(int in_rate, int out_rate, ResampleP* P) {
 }
 
 // side 0: the encoder's resampler slot (external rate -> 16 kHz, encode-side stream); 1: the decoder's (16 kHz -> external)
+// Work launched AHEAD on sq[0] by run_steps (see resample_in_ahead below).
+// ahead_begin: first launch of a run_steps call -- after whatever se[0] did to the same slots before; ahead_end: the next
+// per-call encoder-side launch that touches those slots on se[0] waits for it (wait_ahead).
+static int ahead_begin(lyra_hip_ctx* c) {
+  HIPCHK(c, hipEventRecord(c->ev_ahead_order, c->se[0]));
+  HIPCHK(c, hipStreamWaitEvent(c->sq[0], c->ev_ahead_order, 0));
+  return 0;
+}
+static int ahead_end(lyra_hip_ctx* c) {
+  HIPCHK(c, hipEventRecord(c->ev_ahead_last, c->sq[0]));
+  c->ahead_unseen = true;
+  return 0;
+}
+static int wait_ahead(lyra_hip_ctx* c) {
+  if (c->ahead_unseen) {
+    HIPCHK(c, hipStreamWaitEvent(c->se[0], c->ev_ahead_last, 0));
+    c->ahead_unseen = false;
+  }
+  return 0;
+}
 // The decoder-side resampler's slots may have been touched last on the noise stream (run_steps puts the output resampler
 // there, resample_deferred below): a decode-stream launch is ordered after everything enqueued on sn.
-int wait_noise_stream(lyra_hip_ctx* c) {
+static int wait_noise_stream(lyra_hip_ctx* c) {
   if (c->n_noise_calls > c->noise_done_dec) {
     HIPCHK(c, hipStreamWaitEvent(c->sd[0], c->ev_noise[(c->n_noise_calls - 1) & 1], 0));
     if (c->nsub == 1) c->noise_done_dec = c->n_noise_calls;
@@ -1007,7 +1029,7 @@ int wait_noise_stream(lyra_hip_ctx* c) {
   return 0;
 }
 
-int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
+static int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
                     int out_rate, int16_t* d_out, int* n_out_p, int in_stride = 0, int out_stride = 0,
                     hipStream_t on_stream = nullptr) {
   ResampleP P;
@@ -1028,7 +1050,7 @@ int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B, cons
   return 0;
 }
 
-int launch_cng(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_features, int16_t* d_pcm) {
+static int launch_cng(lyra_hip_ctx* c, const int32_t* d_ids, int B, const float* d_features, int16_t* d_pcm) {
   // reads the decoder-side noise estimate: after every decoder-side `_dev` noise call (they run on sn)
   if (!d_features) { int rc = wait_noise_stream(c); if (rc) return rc; }
   { ProfScope ps(c, K_CNG, c->sd[0]);
@@ -1046,7 +1068,7 @@ int lyra_hip_resample_dev(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B
   DEVSCOPE(c);
   if (side == 0) {
     if ((rc = enc_side_begin(c, 0))) return rc;
-    if (c->n_rs_in) HIPCHK(c, hipStreamWaitEvent(c->se[0], c->ev_rs_in[(c->n_rs_in - 1) & 1], 0));   // (same slots)
+    if ((rc = wait_ahead(c))) return rc;
     rc = launch_resample(c, 0, d_ids, B, d_in, n_in, in_rate, out_rate, d_out, nullptr);
     if (!rc) rc = enc_side_done(c, 0);
     return rc;
@@ -1062,7 +1084,7 @@ int lyra_hip_resample_dev(lyra_hip_ctx* c, int side, const int32_t* d_ids, int B
 // the decoder has just written, so it runs on the noise stream behind the decoder's last stage, underneath the next step,
 // instead of lengthening the decoder's chain.  Same bookkeeping as a decoder-side noise call: its input obeys the
 // two-buffer rule through dec_side_begin's wait for all noise-stream calls but the most recent one.
-int resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
+static int resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate,
                       int out_rate, int16_t* d_out) {
   DEVSCOPE(c);
   int rc = noise_dev_begin(c);
@@ -1072,24 +1094,19 @@ int resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_
   return rc;
 }
 
-// run_steps' input resampler (lyra_encoder.cc:119-122) only depends on the caller's ring, so the hop of step i+1 is
-// resampled on the quantizer stream AHEAD of rvq_encode(i), underneath step i's feature extractor, into the buffer of its
-// parity; the extractor of step i+1 waits for its event.  The buffer it overwrites was last read by the extractor of step
-// i-1, which rvq_encode(i-1) -- earlier on the same stream -- has waited for.
-int resample_in_ahead(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate, long step,
-                      bool first_of_call) {
-  if (first_of_call) {   // after whatever the encode stream did to the resampler's slots before this call
-    HIPCHK(c, hipEventRecord(c->ev_rs_order, c->se[0]));
-    HIPCHK(c, hipStreamWaitEvent(c->sq[0], c->ev_rs_order, 0));
-  }
+// Work run_steps launches AHEAD on the quantizer stream sq[0]: the encoder's input resampler (lyra_encoder.cc:119-122)
+// only depends on the caller's input ring and on slots nothing else touches, so the hop of step i+1 is resampled in front
+// of rvq_encode(i), underneath step i's feature extractor instead of lengthening the extractor's chain, into the buffer
+// of its parity; the extractor of step i+1 waits for its event.  The buffer it overwrites was last read by the extractor
+// of step i-1, which rvq_encode(i-1) -- earlier on the same stream -- has waited for.  (The DTX NoiseEstimator was tried
+// there too: no gain -- +31 us per step in front of the extractor or ahead -- and not kept.)
+static int resample_in_ahead(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate, long step) {
   const int p = (int)(step & 1);
   int rc = launch_resample(c, 0, d_ids, B, d_in, n_in, in_rate, 16000, c->d_rs16[p], nullptr, 0, 0, c->sq[0]);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->ev_rs_in[p], c->sq[0]));
-  c->n_rs_in++;
-  return 0;
+  return ahead_end(c);
 }
-
 int lyra_hip_resample(lyra_hip_ctx* c, int side, const int32_t* ids, int B, const int16_t* in, int n_in, int in_rate,
                       int out_rate, int16_t* out) {
   PROLOGUE(c, B);
@@ -1101,6 +1118,7 @@ int lyra_hip_resample(lyra_hip_ctx* c, int side, const int32_t* ids, int B, cons
   HIPCHK(c, hipMemcpyAsync(dids, ids, (size_t)B * 4, hipMemcpyHostToDevice, st_));
   HIPCHK(c, hipMemcpyAsync(c->d_rs_in, in, (size_t)B * n_in * 2, hipMemcpyHostToDevice, st_));
   int n_out = 0;
+  if (side == 0 && (rc = wait_ahead(c))) return rc;
   if ((rc = launch_resample(c, side, dids, B, c->d_rs_in, n_in, in_rate, out_rate, c->d_rs_out, &n_out))) return rc;
   HIPCHK(c, hipMemcpyAsync(out, c->d_rs_out, (size_t)B * n_out * 2, hipMemcpyDeviceToHost, st_));
   if (side == 0 && (rc = enc_side_done(c, 0))) return rc;
@@ -1195,7 +1213,6 @@ int lyra_hip_encode_dtx_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const 
   c->n_encq_calls++;
   return rc;
 }
-
 int lyra_hip_noise_receive(lyra_hip_ctx* c, int side, const int32_t* ids, int B, const int16_t* pcm, int32_t* is_noise) {
   PROLOGUE(c, B);
   if ((side != 0 && side != 1) || !pcm || !is_noise) return fail(c, LYRA_HIP_EINVAL, "bad side or null pointer");
@@ -1430,10 +1447,13 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
         in = c->d_pcm_in;
       } else if (rs) {         // ... one step ahead, on the quantizer stream (resample_in_ahead)
         DEVSCOPE(c);
-        if (i == 0 && (rc = resample_in_ahead(c, S->d_stream_ids, S->B, in, n_ext, ext, step, true))) return rc;
+        if (i == 0) {
+          if ((rc = ahead_begin(c))) return rc;
+          if ((rc = resample_in_ahead(c, S->d_stream_ids, S->B, in, n_ext, ext, step))) return rc;
+        }
         if (i + 1 < S->n_steps) {
           const int16_t* nxt = S->d_pcm_ring + (size_t)((step + 1) % S->ring) * B * (size_t)n_ext;
-          if ((rc = resample_in_ahead(c, S->d_stream_ids, S->B, nxt, n_ext, ext, step + 1, false))) return rc;
+          if ((rc = resample_in_ahead(c, S->d_stream_ids, S->B, nxt, n_ext, ext, step + 1))) return rc;
         }
         for (int k = 0; k < c->nsub; ++k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_rs_in[step & 1], 0));
         in = c->d_rs16[step & 1];
