@@ -73,6 +73,7 @@ struct lyra_hip_ctx {
   int16_t* d_rs16[2] = {};        // run_steps: the input resampler's 16 kHz hops, by step parity (resample_in_ahead)
   hipEvent_t ev_rs_in[2] = {};     // ... and the end of the launch that filled each
   hipEvent_t ev_ahead_order = nullptr, ev_ahead_last = nullptr;
+  bool rs_sn_pending = false;     // run_steps put an output resampler on the noise stream that sd[0] has not been ordered after yet
   bool ahead_unseen = false;      // something ran ahead on sq[0] that se[0] has not been ordered after yet (wait_ahead)
   float* d_e0 = nullptr;     // [cap][4][128]
   float* d_e1 = nullptr;     // [cap][2][256]
@@ -1040,7 +1041,11 @@ static int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int 
   const int n_out = n_in * P.up / P.down;
   if (n_out > 960) return fail(c, LYRA_HIP_EINVAL, "resample: %d output samples per stream exceed 960", n_out);
   hipStream_t st_ = on_stream ? on_stream : side == 0 ? c->se[0] : c->sd[0];
-  if (side == 1 && !on_stream) { int rc = wait_noise_stream(c); if (rc) return rc; }
+  if (side == 1 && !on_stream && c->rs_sn_pending) {   // (same slots; other noise-stream work does not touch them)
+    int rc = wait_noise_stream(c);
+    if (rc) return rc;
+    c->rs_sn_pending = false;
+  }
   { ProfScope ps(c, K_RESAMPLE, st_);
     hipLaunchKernelGGL(resample_kernel, dim3(cdiv(B, resample_streams_per_wg())), dim3(256), resample_lds_bytes(n_in), st_, P, d_ids, B,
                        c->sm.base[side == 0 ? st::R_RS_E : st::R_RS_D], d_in, n_in, in_stride > 0 ? in_stride : n_in, d_out,
@@ -1090,6 +1095,7 @@ static int resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const
   int rc = noise_dev_begin(c);
   if (rc) return rc;
   rc = launch_resample(c, 1, d_ids, B, d_in, n_in, in_rate, out_rate, d_out, nullptr, 0, 0, c->sn);
+  c->rs_sn_pending = true;
   if (!rc) rc = noise_dev_done(c);
   return rc;
 }
