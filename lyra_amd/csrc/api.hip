@@ -1014,6 +1014,9 @@ static int ahead_end(lyra_hip_ctx* c) {
   return 0;
 }
 static int wait_ahead(lyra_hip_ctx* c) {
+#ifdef LYRA_MUTATE_NO_AHEAD_WAIT   // mutation build: tests/test_gpu_round3.py must FAIL without these edges
+  return 0;
+#endif
   if (c->ahead_unseen) {
     HIPCHK(c, hipStreamWaitEvent(c->se[0], c->ev_ahead_last, 0));
     c->ahead_unseen = false;
@@ -1041,6 +1044,9 @@ static int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int 
   const int n_out = n_in * P.up / P.down;
   if (n_out > 960) return fail(c, LYRA_HIP_EINVAL, "resample: %d output samples per stream exceed 960", n_out);
   hipStream_t st_ = on_stream ? on_stream : side == 0 ? c->se[0] : c->sd[0];
+#ifdef LYRA_MUTATE_NO_AHEAD_WAIT
+  c->rs_sn_pending = false;
+#endif
   if (side == 1 && !on_stream && c->rs_sn_pending) {   // (same slots; other noise-stream work does not touch them)
     int rc = wait_noise_stream(c);
     if (rc) return rc;

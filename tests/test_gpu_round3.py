@@ -370,3 +370,74 @@ def test_sliced_stage_launches_are_invisible(monkeypatch):
             assert np.array_equal(plain.decode(pa, bits), sliced.decode(pb, bits)), f"PCM differs at hop {t}"
     finally:
         plain.close(); sliced.close()
+
+
+def test_run_steps_48k_interleaved_with_per_call_resamplers(golden_dir):
+    """run_steps keeps the input resampler one step ahead on the quantizer stream and the output resampler on the noise
+    stream; the per-call resample_dev entry points use the encode / decode streams and the SAME per-stream slots.  One
+    context alternates the two without any synchronisation -- run_steps x4, one step by individual calls, run_steps x4,
+    one step by individual calls, ... -- at a batch whose kernels are long enough to overlap; a second context does every
+    step by individual calls with a full synchronise after each.  Packets and PCM at both rates must agree at every step
+    that is still in a buffer at the end, and the resamplers' state must (two more steps by run_steps on both).
+    The test is sensitive: a library built with -DLYRA_MUTATE_NO_AHEAD_WAIT (api.hip: the noise-stream -> decode-stream edge
+    removed) fails it at the extra decoder-side hop, every time tried."""
+    import torch
+    import lyra_amd
+    B, bits, ext, T = 2048, 184, 48000, 24
+    base = _speech_noise_silence(golden_dir, T, 64)
+    pcm48 = np.repeat(base[:, np.arange(B) % 64], 3, axis=2).copy()
+    dev = torch.device("cuda", 0)
+    ids = torch.from_numpy(np.random.default_rng(3).permutation(B).astype(np.int32)).to(dev)
+    ring = torch.from_numpy(pcm48).to(dev)
+    nb = lyra_amd.packet_size(bits)
+    A, Bc = lyra_amd.LyraHip(max_streams=B), lyra_amd.LyraHip(max_streams=B)
+    A.torch_order = Bc.torch_order = False
+
+    def bufs():
+        return dict(pk=[torch.zeros((B, nb), device=dev, dtype=torch.uint8) for _ in range(2)],
+                    out=[torch.zeros((B, 320), device=dev, dtype=torch.int16) for _ in range(2)],
+                    ext=[torch.zeros((B, 960), device=dev, dtype=torch.int16) for _ in range(2)],
+                    in16=[torch.zeros((B, 320), device=dev, dtype=torch.int16) for _ in range(2)])
+    a, b = bufs(), bufs()
+    torch.cuda.synchronize()
+
+    def per_call(ctx, bf, t, sync):
+        s = t & 1
+        ctx.resample_dev(ids, ring[t % T], ext, 16000, bf["in16"][s], side="encoder")
+        if sync: ctx.synchronize()
+        ctx.encode_dev(ids, bf["in16"][s], bits, bf["pk"][s])
+        if sync: ctx.synchronize()
+        ctx.decode_dev(ids, bf["pk"][s], bits, bf["out"][s])
+        if sync: ctx.synchronize()
+        ctx.resample_dev(ids, bf["out"][s], 16000, ext, bf["ext"][s], side="decoder")
+        if sync: ctx.synchronize()
+
+    def steps(ctx, bf, first, n):
+        ctx.run_steps_dev(ids, bits, n, first_step=first, d_pcm_ring=ring, d_packets=bf["pk"], d_pcm_out=bf["out"],
+                          external_rate=ext, d_ext_out=bf["ext"], encode=True, decode=True)
+    try:
+        t = 0
+        extra_in = torch.from_numpy(base[0][np.arange(B) % 64].copy()).to(dev)
+        xa, xb = torch.zeros((B, 960), device=dev, dtype=torch.int16), torch.zeros((B, 960), device=dev, dtype=torch.int16)
+        for _ in range(4):
+            steps(A, a, t, 4)
+            # straight behind run_steps' last output resampler (noise stream): one more hop through the decoder-side
+            # resampler by the per-call entry point (decode stream) -- same slots, nothing in between
+            A.resample_dev(ids, extra_in, 16000, ext, xa, side="decoder")
+            per_call(A, a, t + 4, sync=False)
+            for u in range(t, t + 4):
+                per_call(Bc, b, u, sync=True)
+            Bc.resample_dev(ids, extra_in, 16000, ext, xb, side="decoder"); Bc.synchronize()
+            per_call(Bc, b, t + 4, sync=True)
+            A.synchronize()
+            assert torch.equal(xa, xb), f"extra decoder-side hop differs after step {t + 4}"
+            t += 5
+        steps(A, a, t, 2)
+        steps(Bc, b, t, 2)
+        A.synchronize(); Bc.synchronize()
+        for s in range(2):
+            assert torch.equal(a["pk"][s], b["pk"][s]), f"packets differ (buffer {s})"
+            assert torch.equal(a["out"][s], b["out"][s]), f"16 kHz PCM differs (buffer {s})"
+            assert torch.equal(a["ext"][s], b["ext"][s]), f"48 kHz PCM differs (buffer {s})"
+    finally:
+        A.close(); Bc.close()
