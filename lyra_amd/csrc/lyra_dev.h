@@ -222,6 +222,9 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[sl][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c + PF));
     }
+#ifdef LYRA_GEMM_SCHED_BARRIER   // experiment: keep the prefetch loads above this chunk's MFMAs (the scheduler sinks them otherwise)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const int cur = c % (PF + 1);
     LYRA_MFMA_BEGIN();
 #pragma unroll
