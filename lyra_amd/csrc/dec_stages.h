@@ -96,7 +96,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   const auto warm = l2_warm<NTD0, 1>(P.warm);
   const auto warm_code = code_warm<NTD0>(code_bytes);
   const auto warm_cb = l2_warm<NTD0, 1>(feats ? WarmRange{nullptr, 0} : WarmRange{reinterpret_cast<const uint8_t*>(cb), 46 * 16 * 64 * 4});
-  __syncthreads();
+  LYRA_SYNC_KEEP();
   TileCtx cx{state, sids, sphase, B - b0, st::D0_BYTES};
   // overlap tails / carried rows read by dependent loads further down the chain (state_touch, resblocks.h)
   const uint32_t touch0 = state_touch<SD0, NTD0>(cx, st::D_UP0, 4 * 2 * 64 * 4 + 2 * 256);   // D_UP0 .. D_R0_0
@@ -459,7 +459,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   }
   const auto warm = l2_warm<NTD1, 2>(P.warm);
   const auto warm_code = code_warm<NTD1>(code_bytes);
-  __syncthreads();
+  LYRA_SYNC_KEEP();
   TileCtx cx{state, sids, sphase, B - b0, st::D1_BYTES};
   const auto H0 = hist128_prefetch<SD1, NTD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
@@ -531,7 +531,7 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NTD2, 1>(P.warm);
   const auto warm_code = code_warm<NTD2>(code_bytes);
-  __syncthreads();
+  LYRA_SYNC_KEEP();
   TileCtx cx{state, sids, nullptr, B - b0, st::D2_BYTES};   // T = 20 >= every 2*dilation: no ring, no phase
   const int wn = wave & 3, wm = wave >> 2;
   const int pcol = at16(wn * 16 + (lane & 15));

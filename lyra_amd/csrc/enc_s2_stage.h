@@ -66,7 +66,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   load_luts<NT2>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
   const auto warm = l2_warm<NT2, 1>(P.warm);
   const auto warm_code = code_warm<NT2>(code_bytes);
-  __syncthreads();
+  LYRA_SYNC_KEEP();
   TileCtx cx{state, sids, sphase, B - b0, st::E2_BYTES};
   const RbqPre pre1 = resblock_q_prefetch<S2>(cx, 3, st::E_R2_1, P.dwq[0], P.pwq[0], P.cvq[0]);
   // rows read by dependent loads further down the chain (depthwise history of block 0; strided-conv and bottleneck rows)

@@ -54,7 +54,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   if (tid < S0) sids[tid] = ids[min(b0 + tid, B - 1)];
   const auto warm = l2_warm<NT0, 1>(P.warm);
   const auto warm_code = code_warm<NT0>(code_bytes);
-  __syncthreads();
+  LYRA_SYNC_KEEP();
   auto sbase = [&](int s) -> uint8_t* { return state + (size_t)max(sids[s], 0) * st::E0_BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B && sids[s] >= 0; };   // id -1 = masked slot (TileCtx::valid)
 
@@ -201,7 +201,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   }
   const auto warm = l2_warm<NT1, 2>(P.warm);
   const auto warm_code = code_warm<NT1>(code_bytes);
-  __syncthreads();
+  LYRA_SYNC_KEEP();
   auto sbase = [&](int s) -> uint8_t* { return state + (size_t)max(sids[s], 0) * st::E1_BYTES; };
   auto valid = [&](int s) -> bool { return b0 + s < B && sids[s] >= 0; };
 

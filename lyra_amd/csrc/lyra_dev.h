@@ -17,6 +17,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// LYRA_SYNC_KEEP(): the barrier behind which the stream ids / ring phases sit (addresses depend on it).
+// -DLYRA_NO_BARRIER is a TIMING-ONLY ablation (results are garbage): every OTHER workgroup barrier becomes a wave barrier --
+// how much of a stage kernel is waiting for its slowest wave?
+#define LYRA_SYNC_KEEP() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#ifdef LYRA_NO_BARRIER
+#define __syncthreads() __builtin_amdgcn_wave_barrier()
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
