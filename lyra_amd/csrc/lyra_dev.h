@@ -59,7 +59,16 @@ namespace lyra {
 
 __host__ __device__ constexpr int at16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
 
-__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : x * LYRA_LRELU_ALPHA; }
+// x > 0 ? x : alpha * x  ==  max(x, alpha * x) for 0 < alpha < 1, bit for bit (signed zeros included; activations are never
+// NaN): one multiply + one v_max_f32 instead of multiply + compare + select -- on this part every vector instruction is
+// issue time that does not hide under the MFMAs, and the float LeakyReLU is a fifth of the fp32 stages'
+// vector work.  Spelled as an instruction: fmaxf() would add a canonicalisation of x in IEEE mode.
+__device__ __forceinline__ float lrelu(float x) {
+  const float ax = x * LYRA_LRELU_ALPHA;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(ax));
+  return r;
+}
 __device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
   f32x4 r;
   r[0] = lrelu(v[0]); r[1] = lrelu(v[1]); r[2] = lrelu(v[2]); r[3] = lrelu(v[3]);
