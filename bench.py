@@ -317,6 +317,9 @@ def step_roofline(mode, legs, frames_per_s_per_gpu, traffic_table):
               "traffic": traffic, "traffic_unit": "HBM bytes per stream-frame",
               "traffic_source": "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json), "
                                 "2*FETCH_SIZE + WRITE_SIZE per the gfx950 note in MI355X_MICROARCH.md"}
+    issue = load_issue_time(names)
+    if issue:
+        common["issue_time"] = issue
     if t_mfma >= t_hbm:
         ach = 2 * f32 * frames_per_s_per_gpu / 1e12
         return dict(common, bound="mfma", achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -326,6 +329,37 @@ def step_roofline(mode, legs, frames_per_s_per_gpu, traffic_table):
     return dict(common, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                 frac=round(ach / PEAK_HBM_GBS, 4),
                 mfma_frac=round(2 * f32 * frames_per_s_per_gpu / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+
+
+def load_issue_time(names):
+    """Offline SQ counters (profiles/r03_pmc_sq.txt, B = 4096): per SIMD, the time the matrix pipe is busy and the time the
+    vector instructions take to issue, summed over the step's kernels.  On this part vector instructions do not hide under
+    the MFMAs (tools/mfma_valu_overlap_probe.hip), so the two add up; informational, not the roofline."""
+    try:
+        cur, tab = None, {}
+        for line in open(os.path.join(ROOT, "profiles", "r03_pmc_sq.txt")):
+            if line.strip() and not line.startswith(" "):
+                cur = line.strip()
+                tab[cur] = {}
+            else:
+                p = line.split()
+                if cur and len(p) == 2:
+                    try:
+                        tab[cur][p[0]] = float(p[1])
+                    except ValueError:
+                        pass
+        simds, clk = 1024.0, 2.06e9     # 256 CUs x 4; the clock the chip sustains under this load (DESIGN.md 4.1)
+        matrix = vector = 0.0
+        for k in names:
+            c = tab[k]
+            matrix += c["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / clk
+            per = 2.6 if k == "rvq_encode_kernel" else 4.3   # cycles per wave instruction: fp32 chains | integer / mixed
+            vector += (c["SQ_INSTS_VALU"] - c.get("SQ_INSTS_MFMA", 0.0)) * per / simds / clk
+        return {"matrix_pipe_us_per_step_at_B4096": round(matrix * 1e6, 1), "vector_issue_us_per_step_at_B4096": round(vector * 1e6, 1),
+                "source": "offline: SQ counters of profiles/r03_pmc_sq.txt at 2.06 GHz; vector instructions do not hide under "
+                          "MFMAs on gfx950 (profiles/r03_mfma_valu_overlap_probe.txt), so a SIMD's time is the sum"}
+    except Exception:
+        return None
 
 
 def load_traffic():
