@@ -73,6 +73,12 @@ struct lyra_hip_ctx {
   int16_t* d_rs16[2] = {};        // run_steps: the input resampler's 16 kHz hops, by step parity (resample_in_ahead)
   hipEvent_t ev_rs_in[2] = {};     // ... and the end of the launch that filled each
   hipEvent_t ev_ahead_order = nullptr, ev_ahead_last = nullptr;
+  // sub-batches (nsub > 1) only: a call that is split differently from the previous call of its side joins that call's
+  // streams first (cross_begin / dec_side_begin) -- e.g. an unsplit resample_dev behind a split decode_dev
+  int dec_nk_slot[2] = {0, 0};    // chunks of the decode-side call recorded in ev_dec[slot]
+  int enc_last_nk = 0;            // chunks of the previous encode-side call
+  hipEvent_t ev_se_last[KMAX] = {};  // end of the latest encode-side work on se[k]
+  bool se_last_set[KMAX] = {};
   bool rs_sn_pending = false;     // run_steps put an output resampler on the noise stream that sd[0] has not been ordered after yet
   bool ahead_unseen = false;      // something ran ahead on sq[0] that se[0] has not been ordered after yet (wait_ahead)
   float* d_e0 = nullptr;     // [cap][4][128]
@@ -312,16 +318,32 @@ struct ProfScope {
 //  * encode-side work on chunk k waits for every decode-side call except the most recent one, so a caller that
 //    alternates two buffers never has a buffer rewritten while a pending decode still reads it.
 // These edges ARE the encode -> decode dependency: every record / wait is checked, a failure fails the call.
-int enc_side_begin(lyra_hip_ctx* c, int k) {
+int enc_cross_begin(lyra_hip_ctx* c, int k, int nk_now) {
+  if (c->nsub > 1 && c->enc_last_nk && c->enc_last_nk != nk_now)
+    for (int j = 0; j < c->nsub; ++j)
+      if (c->se_last_set[j] && j != k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_se_last[j], 0));
+  return 0;
+}
+int enc_cross_done(lyra_hip_ctx* c, int k) {
+  if (c->nsub > 1) {
+    HIPCHK(c, hipEventRecord(c->ev_se_last[k], c->se[k]));
+    c->se_last_set[k] = true;
+  }
+  return 0;
+}
+int enc_side_begin(lyra_hip_ctx* c, int k, int nk_now = 1) {
+  int rc = enc_cross_begin(c, k, nk_now);
+  if (rc) return rc;
   if (c->n_dec_calls >= 2) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_dec[c->n_dec_calls & 1][k], 0));
   if (c->serial && c->n_dec_calls >= 1)
     HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_dec[(c->n_dec_calls - 1) & 1][k], 0));
   return 0;
 }
-int enc_side_done(lyra_hip_ctx* c, int k) {
+int enc_side_done(lyra_hip_ctx* c, int k, int nk = 1) {   // nk > 1: the caller sets enc_last_nk after its last chunk
   HIPCHK(c, hipEventRecord(c->ev_encs[2][k], c->se[k]));
   c->seq_se[k]++;
-  return 0;
+  if (nk == 1) c->enc_last_nk = 1;
+  return enc_cross_done(c, k);
 }
 // The `_dev` encode calls (lyra_hip_encode_dev, lyra_hip_encode_dtx_dev) run the feature extractor on se[k] and the
 // quantizer on a third stream sq[k]: rvq_encode is a 46-stage dependent chain on one wavefront per SIMD that leaves
@@ -330,7 +352,9 @@ int enc_side_done(lyra_hip_ctx* c, int k) {
 // decoder stages on sd[k] it lengthened the chain that paces the pipeline.  On its own stream it runs underneath the
 // next call's extractor and the previous call's decoder stages, which then are two chains of equal length that never
 // wait for each other (B = 4096: 0.338 -> 0.315 ms per step).  The features travel through two alternating buffers.
-int encq_begin(lyra_hip_ctx* c, int k) {
+int encq_begin(lyra_hip_ctx* c, int k, int nk_now = 1) {
+  int rc = enc_cross_begin(c, k, nk_now);
+  if (rc) return rc;
   if (c->serial && c->n_dec_calls >= 1)
     HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_dec[(c->n_dec_calls - 1) & 1][k], 0));
   return 0;
@@ -351,6 +375,7 @@ EventList encq_buffer_free(lyra_hip_ctx* c, int k, int nk_now) {
 float* encq_features(lyra_hip_ctx* c) { return (c->n_encq_calls & 1) ? c->d_feat2 : c->d_feat; }
 int encq_handoff(lyra_hip_ctx* c, int k) {   // extractor done on se[k] -> quantizer may start on sq[k]
   HIPCHK(c, hipEventRecord(c->ev_feat[k], c->se[k]));
+  { int rc = enc_cross_done(c, k); if (rc) return rc; }
   HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_feat[k], 0));
   // the packets: the two-buffer rule of include/lyra_hip.h "Streams" (2), as enc_side_begin does it for se[k]
   if (c->n_dec_calls >= 2) HIPCHK(c, hipStreamWaitEvent(c->sq[k], c->ev_dec[c->n_dec_calls & 1][k], 0));
@@ -393,9 +418,14 @@ int wait_encode_side(lyra_hip_ctx* c, hipStream_t s, int who) {
 // which has slack: the quantizer of a `_dev` encode call waits for all noise calls but the most recent one
 // (encq_handoff), and the decoder stages wait for that quantizer anyway; a decode-side call that is not covered that way
 // (decode-only loops, generate_dev) waits itself.  noise_done_dec / cover_sq[] do the bookkeeping.
-int dec_side_begin(lyra_hip_ctx* c, int k) {
+int dec_side_begin(lyra_hip_ctx* c, int k, int nk_now = 1) {
   int rc = wait_encode_side(c, c->sd[k], k);
   if (rc) return rc;
+  if (c->nsub > 1 && c->n_dec_calls >= 1) {   // split differently from the previous decode-side call: after all of it
+    const int prev = (int)((c->n_dec_calls - 1) & 1);
+    if (c->dec_nk_slot[prev] != nk_now)
+      for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_dec[prev][j], 0));
+  }
   const long required = c->n_noise_calls - 1;   // all decoder-side noise calls but the most recent one
   if (required > c->noise_done_dec) {
     long covered = 0;
@@ -424,6 +454,7 @@ int noise_dev_done(lyra_hip_ctx* c) {
 }
 int dec_side_done(lyra_hip_ctx* c, int k, int nk = 0) {
   const int slot = (int)(c->n_dec_calls & 1);
+  c->dec_nk_slot[slot] = nk;
   if (nk == 1) {  // an unsplit call stands for every chunk
     for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipEventRecord(c->ev_dec[slot][j], c->sd[0]));
   } else {
@@ -710,6 +741,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       hipEventCreateWithFlags(&c->ev_rs_in[0], evflags) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_rs_in[1], evflags) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_ahead_order, evflags) != hipSuccess ||
+      (c->nsub > 1 && [&] { for (int k = 0; k < c->nsub; ++k) if (hipEventCreateWithFlags(&c->ev_se_last[k], evflags) != hipSuccess) return true; return false; }()) ||
       hipEventCreateWithFlags(&c->ev_ahead_last, evflags) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
@@ -784,6 +816,8 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   for (hipEvent_t e : c->ev_rs_in)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_ahead_order) (void)hipEventDestroy(c->ev_ahead_order);
+  for (hipEvent_t e : c->ev_se_last)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_ahead_last) (void)hipEventDestroy(c->ev_ahead_last);
   if (c->sn) (void)hipStreamDestroy(c->sn);
   if (c->d_state) (void)hipFree(c->d_state);
@@ -840,10 +874,11 @@ int lyra_hip_extract_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    if ((rc = enc_side_begin(c, k))) break;
+    if ((rc = enc_side_begin(c, k, nk))) break;
     rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, d_feat + (size_t)lo * 64);
-    if (!rc) rc = enc_side_done(c, k);
+    if (!rc) rc = enc_side_done(c, k, nk);
   }
+  c->enc_last_nk = nk;
   return rc;
 }
 
@@ -882,7 +917,7 @@ int lyra_hip_generate_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const fl
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    if ((rc = dec_side_begin(c, k))) break;
+    if ((rc = dec_side_begin(c, k, nk))) break;
     rc = launch_generate(c, k, lo, d_ids + lo, n, d_feat + (size_t)lo * 64, d_pcm + (size_t)lo * 320);
     if (!rc) rc = dec_side_done(c, k, nk);
   }
@@ -916,7 +951,7 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    if ((rc = encq_begin(c, k))) break;
+    if ((rc = encq_begin(c, k, nk))) break;
     float* feat = encq_features(c) + (size_t)lo * 64;
     rc = launch_extract(c, k, lo, d_ids + lo, n, d_pcm + (size_t)lo * 320, feat, encq_buffer_free(c, k, nk));
     if (!rc) rc = encq_handoff(c, k);
@@ -926,6 +961,7 @@ int lyra_hip_encode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int1
   }
   c->encq_nk[c->n_encq_calls & 1] = nk;
   c->n_encq_calls++;
+  c->enc_last_nk = nk;
   return rc;
 }
 
@@ -943,7 +979,7 @@ int lyra_hip_decode_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint
     int lo = 0, n = B;
     if (nk > 1) chunk_of(c, B, k, &lo, &n);
     if (n <= 0) continue;
-    if ((rc = dec_side_begin(c, k))) break;
+    if ((rc = dec_side_begin(c, k, nk))) break;
     rc = launch_generate(c, k, lo, d_ids + lo, n, nullptr, d_pcm + (size_t)lo * 320,
                          d_packets + (size_t)lo * nbytes, num_bits / 4);
     if (!rc) rc = dec_side_done(c, k, nk);
@@ -1223,6 +1259,7 @@ int lyra_hip_encode_dtx_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const 
   if (!rc) rc = encq_done(c, 0);
   c->encq_nk[c->n_encq_calls & 1] = 1;
   c->n_encq_calls++;
+  c->enc_last_nk = 1;
   return rc;
 }
 int lyra_hip_noise_receive(lyra_hip_ctx* c, int side, const int32_t* ids, int B, const int16_t* pcm, int32_t* is_noise) {
@@ -1449,14 +1486,24 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
     if ((rc = ensure_scratch(c, S->B))) return rc;
   }
   const size_t B = (size_t)S->B;
+  // the resamplers leave the codec's chains (resample_in_ahead / resample_deferred) in the default, unsplit configuration;
+  // with sub-batches or strict call order they stay where the individual calls put them
+  const bool rs_off_chain = rs && !c->serial && c->nsub == 1;
   for (int i = 0; i < S->n_steps; ++i) {
     const long step = S->first_step + i;
     const int set = (int)(step & 1);
     if (enc) {
       const int16_t* in = S->d_pcm_ring + (size_t)(step % S->ring) * B * (size_t)n_ext;
-      if (rs && c->serial) {   // lyra_encoder.cc:119-122: external rate -> 16 kHz, the encoder's own resampler
+      if (rs && !rs_off_chain) {   // lyra_encoder.cc:119-122: external rate -> 16 kHz, the encoder's own resampler
         if ((rc = lyra_hip_resample_dev(c, LYRA_HIP_SIDE_ENCODER, S->d_stream_ids, S->B, in, n_ext, ext, 16000, c->d_pcm_in))) return rc;
         in = c->d_pcm_in;
+        {   // the chunks of a split encode run on se[1..]: they read what se[0] has just written
+          DEVSCOPE(c);
+          if (c->nsub > 1) {
+            HIPCHK(c, hipEventRecord(c->ev_ahead_order, c->se[0]));
+            for (int k = 1; k < c->nsub; ++k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_ahead_order, 0));
+          }
+        }
       } else if (rs) {         // ... one step ahead, on the quantizer stream (resample_in_ahead)
         DEVSCOPE(c);
         if (i == 0) {
@@ -1488,7 +1535,10 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
       if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
         if ((rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise))) return rc;
       if (rs)     // lyra_decoder.cc:107-113 / buffered_resampler.cc: 16 kHz -> external rate
-        if ((rc = resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set]))) return rc;
+        if ((rc = rs_off_chain ? resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set])
+                               : lyra_hip_resample_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000,
+                                                       ext, S->d_ext_out[set])))
+          return rc;
     }
   }
   return 0;

@@ -372,18 +372,23 @@ def test_sliced_stage_launches_are_invisible(monkeypatch):
         plain.close(); sliced.close()
 
 
-def test_run_steps_48k_interleaved_with_per_call_resamplers(golden_dir):
+@pytest.mark.parametrize("sub_batches", [1, 2])
+def test_run_steps_48k_interleaved_with_per_call_resamplers(golden_dir, monkeypatch, sub_batches):
     """run_steps keeps the input resampler one step ahead on the quantizer stream and the output resampler on the noise
     stream; the per-call resample_dev entry points use the encode / decode streams and the SAME per-stream slots.  One
     context alternates the two without any synchronisation -- run_steps x4, one step by individual calls, run_steps x4,
     one step by individual calls, ... -- at a batch whose kernels are long enough to overlap; a second context does every
     step by individual calls with a full synchronise after each.  Packets and PCM at both rates must agree at every step
     that is still in a buffer at the end, and the resamplers' state must (two more steps by run_steps on both).
+    With LYRA_HIP_SUBBATCHES=2 encode_dev / decode_dev split the batch over two stream pairs while the resamplers do not:
+    an unsplit call must then join every stream of the split call before it (api.hip dec_side_begin / enc_cross_begin) --
+    this case failed before that edge existed.
     The test is sensitive: a library built with -DLYRA_MUTATE_NO_AHEAD_WAIT (api.hip: the noise-stream -> decode-stream edge
     removed) fails it at the extra decoder-side hop, every time tried."""
     import torch
     import lyra_amd
     B, bits, ext, T = 2048, 184, 48000, 24
+    monkeypatch.setenv("LYRA_HIP_SUBBATCHES", str(sub_batches))
     base = _speech_noise_silence(golden_dir, T, 64)
     pcm48 = np.repeat(base[:, np.arange(B) % 64], 3, axis=2).copy()
     dev = torch.device("cuda", 0)
