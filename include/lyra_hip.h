@@ -101,7 +101,10 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  * either way; each exists for an A/B recorded in DESIGN.md):
  *   LYRA_HIP_SUBBATCHES=<n>  split every `_dev` call into n sub-batches on stream
  *                            sets of their own (pays when only one side is driven:
- *                            decode-only at B = 8192 +6 % with n = 2; default 1);
+ *                            decode-only at B = 8192 +6 % with n = 2; default 1).
+ *                            Calls that are not split (resample, noise estimator,
+ *                            small batches ...) are ordered after every chunk of
+ *                            the split call before them and vice versa;
  *   LYRA_HIP_FUSED=<mask>    bit 0: the encoder side (extract / encode) as one
  *                            launch instead of three, bit 1: the decoder side
  *                            likewise (slower at B = 4096; default 0);
