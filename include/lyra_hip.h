@@ -111,7 +111,10 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  *   LYRA_HIP_RVQ_WIDE=1      the 104 KB / 244-VGPR quantizer kernel;
  *   LYRA_HIP_FLAT_PRIO=1     all library streams at the same priority;
  *   LYRA_HIP_EVENT_FENCE=1   internal events with system-scope fences;
- *   LYRA_HIP_NO_CODE_WARM=1  skip the stage kernels' instruction pre-fetch. */
+ *   LYRA_HIP_NO_CODE_WARM=1  skip the stage kernels' instruction pre-fetch;
+ *   LYRA_HIP_PRIO=e,d,q      stream priorities of the encode / decode / quantizer streams (0 lowest .. 2 highest);
+ *   LYRA_HIP_TILE_DIV_<K>=k  launch stage kernel K (ENC_S0 .. DEC_S2) as k slices of its tiles,
+ *   LYRA_HIP_LDS_PAD_<K>=b   give its workgroups b extra bytes of LDS (occupancy experiments). */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
 /* The same from an in-memory lyra_v1.lyrapack image (e.g. read once by rank 0 and broadcast to the other GPUs' ranks
  * over RCCL); the image is copied, the caller keeps ownership. */
