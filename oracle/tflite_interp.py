@@ -22,10 +22,36 @@ are a restatement of its published reference kernels:
                         (ruy / XNNPACK behaviour; default),
       "gemmlowp_double" SaturatingRoundingDoublingHighMul + RoundingDivideByPOT
                         (TFLite reference-kernel behaviour);
-  * int8 LEAKY_RELU and ADD always use the gemmlowp double-rounding
-    MultiplyByQuantizedMultiplier (their builtin kernels have no other path).
+  * int8 LEAKY_RELU and ADD use the gemmlowp double-rounding
+    MultiplyByQuantizedMultiplier in those two modes (their builtin kernels
+    have no other path).
+
+Third mode, requant="xnnpack" (round 4): the arithmetic of XNNPACK's QS8 / F32
+operators, which is what the reference actually runs for these two graphs
+(use_xnn=true: soundstream_encoder.cc:39-40, lyra_gan_model.cc:39-40,
+tflite_model_wrapper.cc:63-85).  Every formula below is held against REAL
+XNNPACK code run here (the one torch's libtorch_cpu.so exports;
+oracle/xnn_witness.c, tests/test_xnnpack_witness.py) -- 0 differing outputs:
+  * int8 conv / depthwise / transpose-conv: fp32 requantisation
+    q = RNE(min(max(float(acc) * scale_c, -128 - z), 127 - z)) + z with
+    scale_c = (s_in * s_w[c]) / s_out evaluated in fp32;
+  * int8 LEAKY_RELU: Q8 multipliers, (v * m + (z_out << 8) + 0x80) >> 8 with
+    m = lrintf(256 * s_in / s_out) for v >= 0 and lrintf(256 * (s_in / s_out *
+    alpha)) otherwise;
+  * int8 ADD: integer multipliers a * ma + b * mb + bias, arithmetic shift;
+  * QUANTIZE: RNE(x * (1 / s)) (reciprocal multiply, ties to even);
+  * fp32 conv / depthwise / transpose-conv: acc starts from the BIAS, then one
+    fused multiply-add per (tap ascending, input channel ascending) -- exactly
+    what XNNPACK's GEMM / IGEMM / DWCONV micro-kernels compute on an FMA target
+    (fp32="chain", oracle/chain_f32.c; for a transpose-conv, taps ascending is
+    input rows newest first).
+fp32="chain" is available in every mode (and is what tools/make_golden.py
+uses since round 4): the canonical fp32 order of oracle/lyra_oracle.c.
 """
+import ctypes
 import math
+import os
+
 import numpy as np
 
 from . import tflite_reader as tr
@@ -98,12 +124,132 @@ def round_half_away(x):
 
 
 # ----------------------------------------------------------------------------
+# XNNPACK QS8 arithmetic (mode "xnnpack"); float32 arithmetic spelled out
+# ----------------------------------------------------------------------------
+F32 = np.float32
+
+
+def xnn_requant(acc, s_in, w_scales, s_out, z_out):
+    """qs8 / qs8_qc8w conv, dwconv, deconv: fp32 requantisation.  acc int64 [..., C]."""
+    scale = ((F32(s_in) * np.asarray(w_scales, F32)).astype(F32) / F32(s_out)).astype(F32)
+    v = (acc.astype(F32) * scale).astype(F32)
+    v = np.minimum(np.maximum(v, F32(-128 - z_out)), F32(127 - z_out))
+    return (np.rint(v).astype(np.int64) + z_out).astype(np.int8)      # np.rint: ties to even
+
+
+def xnn_lrelu(x, s_in, z_in, s_out, z_out, alpha):
+    pos = F32(s_in) / F32(s_out)
+    neg = F32(pos * F32(alpha))
+    mp = int(np.rint(F32(256.0) * pos))
+    mn = int(np.rint(F32(256.0) * neg))
+    v = x.astype(np.int64) - z_in
+    acc = (z_out << 8) + 0x80 + v * np.where(v >= 0, mp, mn)
+    return np.clip(acc >> 8, -128, 127).astype(np.int8)
+
+
+def xnn_add(a, b, s1, z1, s2, z2, so, zo):
+    ao = F32(s1) / F32(so)
+    bo = F32(s2) / F32(so)
+    mx = max(abs(ao), abs(bo))
+    shift = 20 - ((int(np.array(mx, F32).view(np.uint32)) >> 23) - 127)
+
+    def mult(x):
+        return int(np.rint(np.array(np.array(x, F32).view(np.uint32) + np.uint32(shift << 23)).view(F32)))
+
+    ma, mb = mult(ao), mult(bo)
+    bias = (1 << (shift - 1)) - ma * z1 - mb * z2
+    acc = bias + a.astype(np.int64) * ma + b.astype(np.int64) * mb
+    return (np.clip(acc >> shift, -128 - zo, 127 - zo) + zo).astype(np.int8)
+
+
+def xnn_quantize(x, s, z):
+    inv = F32(1.0) / F32(s)
+    v = (x.astype(F32) * inv).astype(F32)
+    v = np.minimum(np.maximum(v, F32(-128 - z)), F32(127 - z))
+    return (np.rint(v).astype(np.int64) + z).astype(np.int8)
+
+
+# ----------------------------------------------------------------------------
+# fp32 layers as explicit fmaf chains (oracle/chain_f32.c)
+# ----------------------------------------------------------------------------
+_CHAIN = None
+
+
+def chain_lib():
+    global _CHAIN
+    if _CHAIN is None:
+        L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libchain_f32.so"))
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.cf_conv.argtypes = [ci] * 8 + [vp] * 4
+        L.cf_dwconv.argtypes = [ci] * 5 + [vp] * 4
+        L.cf_deconv.argtypes = [ci] * 7 + [vp] * 4
+        L.cf_deconv_c4.argtypes = [ci] * 5 + [vp] * 4
+        for f in (L.cf_conv, L.cf_dwconv, L.cf_deconv, L.cf_deconv_c4):
+            f.restype = None
+        _CHAIN = L
+    return _CHAIN
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def chain_conv(x, w, b, stride, dil, bias_first=True):
+    """x [H, Cin], w [Cout, KH, 1, Cin/g], b [Cout] -> [Hout, Cout]"""
+    x = np.ascontiguousarray(x, F32); w = np.ascontiguousarray(w, F32); b = np.ascontiguousarray(b, F32)
+    H, cin = x.shape
+    cout, kh, _, gic = w.shape
+    g = cin // gic
+    hout = (H - (kh - 1) * dil - 1) // stride + 1
+    y = np.zeros((hout, cout), F32)
+    chain_lib().cf_conv(int(bias_first), H, kh, stride, dil, g, gic, cout // g, _p(w), _p(b), _p(x), _p(y))
+    return y
+
+
+def chain_dwconv(x, w, b, dil, bias_first=True):
+    """x [H, C], w [1, KH, 1, C]"""
+    x = np.ascontiguousarray(x, F32); w = np.ascontiguousarray(w, F32); b = np.ascontiguousarray(b, F32)
+    H, c = x.shape
+    kh = w.shape[1]
+    y = np.zeros((H - (kh - 1) * dil, c), F32)
+    chain_lib().cf_dwconv(int(bias_first), H, kh, dil, c, _p(w), _p(b), _p(x), _p(y))
+    return y
+
+
+def chain_deconv(x, w, b, stride, bias_first=True, tap_order=0):
+    """x [H, Cin], w [Cout, KH, 1, Cin]"""
+    x = np.ascontiguousarray(x, F32); w = np.ascontiguousarray(w, F32)
+    b = None if b is None else np.ascontiguousarray(b, F32)
+    H, cin = x.shape
+    cout, kh = w.shape[0], w.shape[1]
+    y = np.zeros(((H - 1) * stride + kh, cout), F32)
+    chain_lib().cf_deconv(int(bias_first), tap_order, H, kh, stride, cin, cout, _p(w), _p(b), _p(x), _p(y))
+    return y
+
+
+def chain_deconv_c4(x, w, b, stride, fused=False):
+    """cout == 1 transposed conv as XNNPACK's x86 nr2 kernel (4x2c4 SSE) sums it; see oracle/chain_f32.c"""
+    x = np.ascontiguousarray(x, F32); w = np.ascontiguousarray(w, F32)
+    b = None if b is None else np.ascontiguousarray(b, F32)
+    H, cin = x.shape
+    assert w.shape[0] == 1
+    kh = w.shape[1]
+    y = np.zeros(((H - 1) * stride + kh, 1), F32)
+    chain_lib().cf_deconv_c4(int(fused), H, kh, stride, cin, _p(w), _p(b), _p(x), _p(y))
+    return y
+
+
+# ----------------------------------------------------------------------------
 class Interpreter:
-    def __init__(self, path, requant="exact", acc64=False):
-        assert requant in ("exact", "gemmlowp_double")
+    def __init__(self, path, requant="exact", acc64=False, fp32=None):
+        assert requant in ("exact", "gemmlowp_double", "xnnpack")
         self.model = tr.load(path)
         self.requant = requant
         self.acc64 = acc64
+        # fp32 layer evaluation: "numpy" (a @ b, or float64 accumulation with acc64=True) or "chain" (bias-first fmaf
+        # chains, oracle/chain_f32.c -- XNNPACK's order).  Mode "xnnpack" implies "chain".
+        self.fp32 = fp32 if fp32 is not None else ("chain" if requant == "xnnpack" else "numpy")
+        assert self.fp32 in ("numpy", "chain")
         self.vars = {}
         self.called_once = set()
         self.trace = None  # optional dict: tensor index -> value (subgraph 0 only)
@@ -269,6 +415,11 @@ class Interpreter:
         """acc: int64 [..., Cout] -> int8."""
         s_in = np.float64(in_t.scale[0])
         s_out = np.float64(out_t.scale[0])
+        if self.requant == "xnnpack":
+            wsc = w_t.scale.astype(np.float32)
+            if len(wsc) == 1:
+                wsc = np.repeat(wsc, cout_axis_len)
+            return xnn_requant(acc, in_t.scale[0], wsc, out_t.scale[0], int(out_t.zero_point[0]))
         ws = w_t.scale.astype(np.float64)
         if len(ws) == 1:
             ws = np.repeat(ws, cout_axis_len)
@@ -292,6 +443,8 @@ class Interpreter:
         Cog = Cout // g
         Hout = (H - K) // stride + 1
         is_q = x.dtype == np.int8
+        if not is_q and self.fp32 == "chain":
+            return chain_conv(x.reshape(H, Cin), w, b, stride, 1).reshape(1, Hout, 1, Cout)
         if is_q:
             xx = x.astype(np.int64) - int(in_t.zero_point[0])
             ww = w.astype(np.int64)
@@ -321,6 +474,8 @@ class Interpreter:
         K = w.shape[1]
         Hout = H - (K - 1) * dil
         is_q = x.dtype == np.int8
+        if not is_q and self.fp32 == "chain":
+            return chain_dwconv(x.reshape(H, C), w, b, dil).reshape(1, Hout, 1, C)
         if is_q:
             xx = (x.astype(np.int64) - int(in_t.zero_point[0])).reshape(H, C)
             ww = w.astype(np.int64).reshape(K, C)
@@ -350,6 +505,8 @@ class Interpreter:
         Hout = (H - 1) * stride + K
         assert tuple(int(v) for v in oshape) == (1, Hout, 1, Cout), (oshape, Hout, Cout)
         is_q = x.dtype == np.int8
+        if not is_q and self.fp32 == "chain":
+            return chain_deconv(x.reshape(H, Cin), w, b, stride).reshape(1, Hout, 1, Cout)
         if is_q:
             xx = (x.astype(np.int64) - int(in_t.zero_point[0])).reshape(H, Cin)
             ww = w.astype(np.int64)
@@ -374,6 +531,8 @@ class Interpreter:
     def _lrelu(self, in_t, out_t, x, alpha):
         if x.dtype != np.int8:
             return np.where(x > 0, x, x * np.float32(alpha)).astype(np.float32)
+        if self.requant == "xnnpack":
+            return xnn_lrelu(x, in_t.scale[0], int(in_t.zero_point[0]), out_t.scale[0], int(out_t.zero_point[0]), alpha)
         s_in = np.float64(in_t.scale[0])
         s_out = np.float64(out_t.scale[0])
         Mi, si = quantize_multiplier(s_in / s_out)
@@ -386,6 +545,9 @@ class Interpreter:
         a, b = ins
         if a.dtype != np.int8:
             return a + b
+        if self.requant == "xnnpack":
+            return xnn_add(a, b, t1.scale[0], int(t1.zero_point[0]), t2.scale[0], int(t2.zero_point[0]), out_t.scale[0],
+                           int(out_t.zero_point[0]))
         s1, s2, so = np.float64(t1.scale[0]), np.float64(t2.scale[0]), np.float64(out_t.scale[0])
         twice = 2.0 * max(s1, s2)
         M1, h1 = quantize_multiplier(s1 / twice)
@@ -400,6 +562,8 @@ class Interpreter:
 
     def _quantize(self, in_t, out_t, x):
         assert x.dtype == np.float32, "only float->int8 QUANTIZE appears in these graphs"
+        if self.requant == "xnnpack":
+            return xnn_quantize(x, out_t.scale[0], int(out_t.zero_point[0]))
         s = np.float32(out_t.scale[0])
         q = round_half_away((x / s).astype(np.float32)).astype(np.int64) + int(out_t.zero_point[0])
         return np.clip(q, -128, 127).astype(np.int8)
