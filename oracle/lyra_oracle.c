@@ -33,22 +33,42 @@
  * level the reference itself tests (LSD < 2.0, lyra_integration_test.cc:
  * 131-142): no reference test holds an expected feature/packet/PCM value.
  *
- * Canonical fp32 order (so "bit-exact vs oracle" is well defined; it is the
- * TFLite reference-kernel loop order with fused multiply-add):
- *   conv      acc = 0; for tap (outer) for in-channel (inner):
- *                 acc = fmaf(x, w, acc);            y = acc + bias
- *   depthwise acc = 0; for tap: acc = fmaf(x, w, acc);  y = acc + bias
- *   tconv     per output element acc = 0; for in-pos t ascending, for
- *             in-channel ascending: acc = fmaf(x, w, acc);  y = acc + bias
- *   RVQ       d = r - c; dist = sum_{d=0..63} (d*d) sequential, separate
+ * Canonical fp32 order (round 4: the order XNNPACK's f32 GEMM / IGEMM / DWCONV /
+ * deconvolution micro-kernels compute on an FMA target -- held against real
+ * XNNPACK code, 0 differing outputs on every fp32 layer of both graphs but the
+ * last, tests/test_xnnpack_witness.py, profiles/r04_xnnpack_witness.txt):
+ *   conv      acc = bias; for tap (outer) for in-channel (inner):
+ *                 acc = fmaf(x, w, acc)
+ *   depthwise acc = bias; for tap: acc = fmaf(x, w, acc)
+ *   tconv     per output element acc = bias; for tap k ascending (= input
+ *             position t DEscending: newest input row first), in-channel
+ *             ascending: acc = fmaf(x, w, acc)
+ *   RVQ       (quantizer.tflite runs WITHOUT XNNPACK, residual_vector_quantizer.cc:
+ *             39-40) d = r - c; dist = sum_{d=0..63} (d*d) sequential, separate
  *             mul and add (SQUARED_DIFFERENCE then SUM); first minimum wins.
- * gfx950's v_mfma_f32_16x16x4_f32 is bitwise a k-ordered fmaf chain, which is
- * why the fused order was chosen as canonical.
+ * Rounds 1-3 started the chains from 0 and added the bias last (TFLite's
+ * reference-kernel order) and ran a tconv's input rows oldest first.
+ * The one-output-channel transposed conv that ends lyragan.tflite is the
+ * exception: the x86 XNNPACK here gives it to its "nr2" kernel (4x2c4 SSE: four
+ * lane sums, unfused), an ARM build to a 2-column NEON-FMA kernel; the canonical
+ * order keeps the fused chain there and the witness test bounds the difference
+ * (< 1e-8 absolute on the float output, i.e. at most a rare 1-LSB PCM flip).
+ * gfx950's v_mfma_f32_16x16x4_f32 is bitwise a k-ordered fmaf chain starting
+ * from its C operand, so the GPU reproduces these chains bit for bit.
  *
- * Requantisation modes for int8 conv/depthwise/transpose-conv:
- *   0 "exact"            (int64(acc)*M + 2^(30-shift)) >> (31-shift)
- *   1 "gemmlowp_double"  RoundingDivideByPOT(SRDHM(acc << left, M), right)
- * int8 LEAKY_RELU and ADD always use the gemmlowp form.
+ * Arithmetic modes of the int8 regions:
+ *   0 "exact"            conv/dw/tconv (int64(acc)*M + 2^(30-shift)) >> (31-shift)
+ *   1 "gemmlowp_double"  conv/dw/tconv RoundingDivideByPOT(SRDHM(acc << left, M), right)
+ *     in both, int8 LEAKY_RELU / ADD / QUANTIZE are TFLite's builtin kernels
+ *     (gemmlowp fixed point, round-half-away division) -- what the graphs compute
+ *     if the XNNPACK delegate is NOT applied (tflite_model_wrapper.cc:76-78
+ *     "continuing without").
+ *   2 "xnnpack"          what the reference runs (use_xnn=true): XNNPACK's QS8
+ *     operators -- conv/dw/tconv q = RNE(float(acc) * ((s_in*s_w[c])/s_out)) + z;
+ *     LEAKY_RELU (v*m + (z_out<<8) + 0x80) >> 8 with Q8 multipliers; ADD
+ *     (a*ma + b*mb + bias) >> shift; QUANTIZE RNE(x * (1/s)).  Each formula equals
+ *     real XNNPACK exhaustively / on 80 M random outputs (same test).  Default
+ *     since round 4.
  *
  * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off).
  */
@@ -161,11 +181,25 @@ static inline int32_t mbqm_exact(int32_t x, qmul q) {
 
 static inline int8_t clamp8(int32_t v) { return (int8_t)(v < -128 ? -128 : (v > 127 ? 127 : v)); }
 
-static inline int8_t quantize_f(float x, float s, int32_t z) {
+static inline int8_t quantize_f(float x, float s, int32_t z, int mode) {
+  if (mode == 2) {
+    /* XNNPACK f32 -> qs8 convert: multiply by the reciprocal, clamp, round to nearest even */
+    float v = x * (1.0f / s);
+    v = fmaxf(v, (float)(-128 - z));
+    v = fminf(v, (float)(127 - z));
+    return (int8_t)((int32_t)lrintf(v) + z);
+  }
   /* TFLite AffineQuantize: round-half-away(x / s) + z, clamped */
   float r = roundf(x / s);
   int32_t q = (int32_t)r + z;
   return clamp8(q);
+}
+/* XNNPACK QS8 fp32 requantisation (conv / dwconv / deconv): scale = (s_in * s_w) / s_out in fp32 */
+static inline int8_t xnn_requant(int32_t acc, float scale, int32_t zout) {
+  float v = (float)acc * scale;
+  v = fmaxf(v, (float)(-128 - zout));
+  v = fminf(v, (float)(127 - zout));
+  return (int8_t)((int32_t)lrintf(v) + zout);
 }
 static inline float dequantize_f(int8_t q, float s, int32_t z) {
   return (float)((double)s * (double)((int32_t)q - z));
@@ -188,6 +222,7 @@ typedef struct {
   int32_t zin, zout;
   float sin, sout;
   qmul* q; /* [cout] */
+  float* fs; /* [cout] mode 2 */
 } conv_q;
 
 typedef struct { int c, k, dil; const float* w; const float* b; } dw_f;
@@ -198,6 +233,7 @@ typedef struct {
   int32_t zin, zout;
   float sin, sout;
   qmul* q;
+  float* fs;
 } dw_q;
 
 typedef struct {
@@ -213,10 +249,11 @@ typedef struct {
   int32_t zin, zout;
   float sin, sout;
   qmul q;
+  float fs;
 } tconv_q;
 
-typedef struct { int32_t zin, zout; float sin, sout; qmul pos, neg; } lrelu_q;
-typedef struct { int32_t z1, z2, zo; float s1, s2, so; qmul m1, m2, mo; } add_q;
+typedef struct { int32_t zin, zout; float sin, sout; qmul pos, neg; int32_t xmp, xmn; } lrelu_q;
+typedef struct { int32_t z1, z2, zo; float s1, s2, so; qmul m1, m2, mo; int32_t xma, xmb, xbias, xshift; } add_q;
 
 static void load_conv_f(const pk_file* pk, const char* pre, int idx, conv_f* L) {
   const int32_t* opt = PKI(pre, "conv", idx, "opt");
@@ -256,8 +293,12 @@ static void load_conv_q(const pk_file* pk, const char* pre, int idx, conv_q* L) 
       for (int co = 0; co < L->cog; ++co)
         L->wt[((size_t)g * K + kk) * L->cog + co] = w[((size_t)(g * L->cog + co)) * K + kk];
   L->q = (qmul*)malloc(sizeof(qmul) * L->cout);
-  for (int c = 0; c < L->cout; ++c)
+  L->fs = (float*)malloc(sizeof(float) * L->cout);
+  for (int c = 0; c < L->cout; ++c) {
     L->q[c] = quantize_multiplier((double)L->sin * (double)ws[c] / (double)L->sout);
+    const float sw = L->sin * ws[c];
+    L->fs[c] = sw / L->sout;
+  }
 }
 
 static void load_dw_f(const pk_file* pk, const char* pre, int idx, dw_f* L) {
@@ -284,8 +325,12 @@ static void load_dw_q(const pk_file* pk, const char* pre, int idx, dw_q* L) {
   const float* ws = PKF(pre, "dw", idx, "wscale");
   L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
   L->q = (qmul*)malloc(sizeof(qmul) * L->c);
-  for (int c = 0; c < L->c; ++c)
+  L->fs = (float*)malloc(sizeof(float) * L->c);
+  for (int c = 0; c < L->c; ++c) {
     L->q[c] = quantize_multiplier((double)L->sin * (double)ws[c] / (double)L->sout);
+    const float sw = L->sin * ws[c];
+    L->fs[c] = sw / L->sout;
+  }
 }
 
 static void load_tconv_f(const pk_file* pk, const char* pre, int idx, tconv_f* L) {
@@ -322,6 +367,7 @@ static void load_tconv_q(const pk_file* pk, const char* pre, int idx, tconv_q* L
   const float* ws = PKF(pre, "tconv", idx, "wscale");
   L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
   L->q = quantize_multiplier((double)L->sin * (double)ws[0] / (double)L->sout);
+  { const float sw = L->sin * ws[0]; L->fs = sw / L->sout; }
 }
 
 static void load_lrelu_q(const pk_file* pk, const char* pre, int idx, lrelu_q* L) {
@@ -329,6 +375,9 @@ static void load_lrelu_q(const pk_file* pk, const char* pre, int idx, lrelu_q* L
   L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
   L->pos = quantize_multiplier((double)L->sin / (double)L->sout);
   L->neg = quantize_multiplier((double)L->sin * (double)LRELU_ALPHA / (double)L->sout);
+  /* XNNPACK qs8 leaky relu: Q8 multipliers from fp32 scales */
+  { const float pos = L->sin / L->sout; const float neg = pos * LRELU_ALPHA;
+    L->xmp = (int32_t)lrintf(256.0f * pos); L->xmn = (int32_t)lrintf(256.0f * neg); }
 }
 
 static void load_add_q(const pk_file* pk, const char* pre, int idx, add_q* L) {
@@ -339,6 +388,15 @@ static void load_add_q(const pk_file* pk, const char* pre, int idx, add_q* L) {
   L->m1 = quantize_multiplier((double)L->s1 / twice);
   L->m2 = quantize_multiplier((double)L->s2 / twice);
   L->mo = quantize_multiplier(twice / ((double)(1 << 20) * (double)L->so));
+  /* XNNPACK qs8 add: multipliers a/out and b/out scaled by 2^shift so that the larger is in [2^20, 2^21) */
+  { const float ao = L->s1 / L->so, bo = L->s2 / L->so;
+    const float mx = ao > bo ? ao : bo;
+    uint32_t bits; memcpy(&bits, &mx, 4);
+    const int32_t shift = 20 - ((int32_t)(bits >> 23) - 127);
+    L->xshift = shift;
+    L->xma = (int32_t)lrintf(ldexpf(ao, shift));
+    L->xmb = (int32_t)lrintf(ldexpf(bo, shift));
+    L->xbias = (int32_t)(1 << (shift - 1)) - L->xma * L->z1 - L->xmb * L->z2; }
 }
 
 /* out[Tout][Cout]; in[Tin][Cin]; Tout = (Tin-k)/stride+1 */
@@ -349,7 +407,7 @@ static void conv_f_run(const conv_f* L, const float* in, int Tin, float* out) {
   for (int t = 0; t < Tout; ++t) {
     for (int g = 0; g < L->groups; ++g) {
       const float* wt = L->wt + (size_t)g * K * L->cog;
-      for (int co = 0; co < L->cog; ++co) acc[co] = 0.f;
+      for (int co = 0; co < L->cog; ++co) acc[co] = L->b[g * L->cog + co];
       for (int tap = 0; tap < L->k; ++tap) {
         const float* xr = in + (size_t)(t * L->stride + tap) * Cin + g * L->cig;
         for (int c = 0; c < L->cig; ++c) {
@@ -359,8 +417,7 @@ static void conv_f_run(const conv_f* L, const float* in, int Tin, float* out) {
         }
       }
       float* o = out + (size_t)t * L->cout + g * L->cog;
-      const float* b = L->b + g * L->cog;
-      for (int co = 0; co < L->cog; ++co) o[co] = acc[co] + b[co];
+      for (int co = 0; co < L->cog; ++co) o[co] = acc[co];
     }
   }
 }
@@ -385,6 +442,7 @@ static void conv_q_run(const conv_q* L, const int8_t* in, int Tin, int8_t* out, 
       for (int co = 0; co < L->cog; ++co) {
         int c = g * L->cog + co;
         int32_t a = acc[co] + L->b[c];
+        if (mode == 2) { o[co] = xnn_requant(a, L->fs[c], L->zout); continue; }
         int32_t r = mode ? mbqm_double(a, L->q[c]) : mbqm_exact(a, L->q[c]);
         o[co] = clamp8(r + L->zout);
       }
@@ -396,9 +454,9 @@ static void conv_q_run(const conv_q* L, const int8_t* in, int Tin, int8_t* out, 
 static void dw_f_run(const dw_f* L, const float* in, int Tout, float* out) {
   for (int t = 0; t < Tout; ++t)
     for (int c = 0; c < L->c; ++c) {
-      float acc = 0.f;
+      float acc = L->b[c];
       for (int k = 0; k < L->k; ++k) acc = fmaf(in[(size_t)(t + k * L->dil) * L->c + c], L->w[k * L->c + c], acc);
-      out[(size_t)t * L->c + c] = acc + L->b[c];
+      out[(size_t)t * L->c + c] = acc;
     }
 }
 
@@ -409,21 +467,22 @@ static void dw_q_run(const dw_q* L, const int8_t* in, int Tout, int8_t* out, int
       for (int k = 0; k < L->k; ++k)
         acc += ((int32_t)in[(size_t)(t + k * L->dil) * L->c + c] - L->zin) * (int32_t)L->w[k * L->c + c];
       acc += L->b[c];
+      if (mode == 2) { out[(size_t)t * L->c + c] = xnn_requant(acc, L->fs[c], L->zout); continue; }
       int32_t r = mode ? mbqm_double(acc, L->q[c]) : mbqm_exact(acc, L->q[c]);
       out[(size_t)t * L->c + c] = clamp8(r + L->zout);
     }
 }
 
-/* out[(Tin-1)*s+k][Cout] (bias included).  Polyphase form of the scatter loop: output block b
- * (rows b*s..b*s+s-1) receives input rows t = b-(k/s-1) .. b in ascending order, channels ascending --
- * per output element exactly the canonical chain; vectorises over the s*Cout outputs of a block. */
+/* out[(Tin-1)*s+k][Cout].  Polyphase form: output block b (rows b*s..b*s+s-1) starts from the bias and receives
+ * input rows t = b, b-1, .. b-(k/s-1) (taps ascending = newest input first), channels ascending -- per output
+ * element exactly the canonical chain; vectorises over the s*Cout outputs of a block. */
 static void tconv_f_run(const tconv_f* L, const float* in, int Tin, float* out) {
   int taps = L->k / L->stride, N = L->stride * L->cout;
   int blocks = Tin + taps - 1;
   float acc[512];
   for (int b = 0; b < blocks; ++b) {
-    for (int n = 0; n < N; ++n) acc[n] = 0.f;
-    for (int i = taps - 1; i >= 0; --i) {
+    for (int n = 0; n < N; ++n) acc[n] = L->b[n % L->cout];
+    for (int i = 0; i < taps; ++i) {
       int t = b - i;
       if (t < 0 || t >= Tin) continue;
       const float* x = in + (size_t)t * L->cin;
@@ -435,7 +494,7 @@ static void tconv_f_run(const tconv_f* L, const float* in, int Tin, float* out) 
     }
     float* o = out + (size_t)b * N;
     for (int j = 0; j < L->stride; ++j)
-      for (int co = 0; co < L->cout; ++co) o[j * L->cout + co] = acc[j * L->cout + co] + L->b[co];
+      for (int co = 0; co < L->cout; ++co) o[j * L->cout + co] = acc[j * L->cout + co];
   }
 }
 
@@ -452,21 +511,33 @@ static void tconv_q_run(const tconv_q* L, const int8_t* in, int in_stride, int T
         for (int c = 0; c < L->cin; ++c) acc += ((int32_t)x[c] - L->zin) * (int32_t)w[c];
       }
       acc += L->b[co];
+      if (mode == 2) { out[(size_t)tau * L->cout + co] = xnn_requant(acc, L->fs, L->zout); continue; }
       int32_t r = mode ? mbqm_double(acc, L->q) : mbqm_exact(acc, L->q);
       out[(size_t)tau * L->cout + co] = clamp8(r + L->zout);
     }
 }
 
-static inline int8_t lrelu_q_run1(const lrelu_q* L, int8_t x) {
+static inline int8_t lrelu_q_run1(const lrelu_q* L, int8_t x, int mode) {
   int32_t v = (int32_t)x - L->zin;
+  if (mode == 2) {   /* arithmetic shift of a possibly negative value: gcc's >> on int32_t is arithmetic */
+    int32_t acc = (L->zout << 8) + 0x80 + v * (v >= 0 ? L->xmp : L->xmn);
+    return clamp8(acc >> 8);
+  }
   int32_t r = v >= 0 ? mbqm_double(v, L->pos) : mbqm_double(v, L->neg);
   return clamp8(r + L->zout);
 }
-static void lrelu_q_run(const lrelu_q* L, const int8_t* in, int n, int8_t* out) {
-  for (int i = 0; i < n; ++i) out[i] = lrelu_q_run1(L, in[i]);
+static void lrelu_q_run(const lrelu_q* L, const int8_t* in, int n, int8_t* out, int mode) {
+  for (int i = 0; i < n; ++i) out[i] = lrelu_q_run1(L, in[i], mode);
 }
-static void add_q_run(const add_q* L, const int8_t* a, const int8_t* b, int n, int8_t* out) {
+static void add_q_run(const add_q* L, const int8_t* a, const int8_t* b, int n, int8_t* out, int mode) {
   for (int i = 0; i < n; ++i) {
+    if (mode == 2) {
+      int32_t acc = L->xbias + (int32_t)a[i] * L->xma + (int32_t)b[i] * L->xmb;
+      int32_t r = acc >> L->xshift;
+      r = r < -128 - L->zo ? -128 - L->zo : (r > 127 - L->zo ? 127 - L->zo : r);
+      out[i] = (int8_t)(r + L->zo);
+      continue;
+    }
     int32_t va = ((int32_t)a[i] - L->z1) * (1 << 20);
     int32_t vb = ((int32_t)b[i] - L->z2) * (1 << 20);
     int32_t sa = mbqm_double(va, L->m1);
@@ -662,11 +733,11 @@ static void resblock_f(const dw_f* dw, const conv_f* pw, const conv_f* cv, float
 }
 
 /* int8 state plumbing: float state, dequantised new rows, re-quantised concat (graph ops 108-114) */
-static void push_state_q(float* state, int S, const int8_t* a, int T, int C, float s, int32_t z, int8_t* buf8) {
+static void push_state_q(float* state, int S, const int8_t* a, int T, int C, float s, int32_t z, int8_t* buf8, int mode) {
   float tmp[20 * 512];
   memcpy(tmp, state, sizeof(float) * (size_t)S * C);
   for (int i = 0; i < T * C; ++i) tmp[(size_t)S * C + i] = dequantize_f(a[i], s, z);
-  for (int i = 0; i < (S + T) * C; ++i) buf8[i] = quantize_f(tmp[i], s, z);
+  for (int i = 0; i < (S + T) * C; ++i) buf8[i] = quantize_f(tmp[i], s, z, mode);
   for (int i = 0; i < S * C; ++i) state[i] = dequantize_f(buf8[(size_t)T * C + i], s, z);
 }
 
@@ -708,32 +779,32 @@ void lo_encode_frame(const lo_model* m, lo_stream* s, const int16_t* pcm, float*
   conv_f_run(&E->pw[6], s0, 2, s2);
   tap(s, s2, 2 * 256);
   int8_t a8[20 * 256], b8[20 * 256], c8[2 * 512], X[2 * 256], X2[2 * 256];
-  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(s2[i], E->q_r0_s, E->q_r0_z);
-  lrelu_q_run(&E->lr[0], a8, 512, b8);
+  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(s2[i], E->q_r0_s, E->q_r0_z, m->mode);
+  lrelu_q_run(&E->lr[0], a8, 512, b8, m->mode);
   conv_q_run(&E->r0b, b8, 2, a8, m->mode);
   for (int i = 0; i < 512; ++i) {
     float v = dequantize_f(a8[i], E->dq_r0_s, E->dq_r0_z) + z[i];
-    X[i] = quantize_f(v, E->q_x1_s, E->q_x1_z);
+    X[i] = quantize_f(v, E->q_x1_s, E->q_x1_z, m->mode);
   }
   tap8(s, X, 512);
   for (int r = 0; r < 2; ++r) {
     const lrelu_q* la = &E->lr[1 + 2 * r];
-    lrelu_q_run(la, X, 512, a8);
+    lrelu_q_run(la, X, 512, a8, m->mode);
     int S = 2 * E->dwq[r].dil;
-    push_state_q(s->e_r2[1 + r], S, a8, 2, 256, la->sout, la->zout, b8);
+    push_state_q(s->e_r2[1 + r], S, a8, 2, 256, la->sout, la->zout, b8, m->mode);
     dw_q_run(&E->dwq[r], b8, 2, a8, m->mode);
     conv_q_run(&E->pwq[r], a8, 2, b8, m->mode);
-    lrelu_q_run(&E->lr[2 + 2 * r], b8, 512, a8);
+    lrelu_q_run(&E->lr[2 + 2 * r], b8, 512, a8, m->mode);
     conv_q_run(&E->cvq[r], a8, 2, b8, m->mode);
-    add_q_run(&E->add[r], b8, X, 512, X2);
+    add_q_run(&E->add[r], b8, X, 512, X2, m->mode);
     memcpy(X, X2, 512);
     tap8(s, X, 512);
   }
-  lrelu_q_run(&E->lr[5], X, 512, a8);
-  push_state_q(s->e_d2, 2, a8, 2, 256, E->lr[5].sout, E->lr[5].zout, b8);
+  lrelu_q_run(&E->lr[5], X, 512, a8, m->mode);
+  push_state_q(s->e_d2, 2, a8, 2, 256, E->lr[5].sout, E->lr[5].zout, b8, m->mode);
   conv_q_run(&E->down2, b8, 4, c8, m->mode);              /* [1][512] */
-  lrelu_q_run(&E->lr[6], c8, 512, a8);
-  push_state_q(s->e_bott, 2, a8, 1, 512, E->lr[6].sout, E->lr[6].zout, b8);
+  lrelu_q_run(&E->lr[6], c8, 512, a8, m->mode);
+  push_state_q(s->e_bott, 2, a8, 1, 512, E->lr[6].sout, E->lr[6].zout, b8, m->mode);
   int8_t f8[64];
   conv_q_run(&E->bott, b8, 3, f8, m->mode);               /* [1][64] */
   tap8(s, f8, 64);
@@ -817,7 +888,7 @@ void lo_decode_frame(const lo_model* m, lo_stream* s, const float* feat, int16_t
   conv_f_run(&D->head, in, 3, h);
   tap(s, h, 512);
   int8_t h8[512], t8[6 * 64];
-  for (int i = 0; i < 512; ++i) h8[i] = quantize_f(lrelu_f(h[i]), D->q0_s, D->q0_z);
+  for (int i = 0; i < 512; ++i) h8[i] = quantize_f(lrelu_f(h[i]), D->q0_s, D->q0_z, m->mode);
   float x164[2 * 256];
   for (int g = 0; g < 4; ++g) {
     float y[4 * 64];
@@ -828,32 +899,32 @@ void lo_decode_frame(const lo_model* m, lo_stream* s, const float* feat, int16_t
   }
   tap(s, x164, 512);
   int8_t a8[20 * 256], b8[20 * 256], X[512], X2[512];
-  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(lrelu_f(x164[i]), D->q1_s, D->q1_z);
+  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(lrelu_f(x164[i]), D->q1_s, D->q1_z, m->mode);
   /* resblock 0 (skip is the float x164) */
-  push_state_q(s->d_r0[0], 2, a8, 2, 256, D->q1_s, D->q1_z, b8);
+  push_state_q(s->d_r0[0], 2, a8, 2, 256, D->q1_s, D->q1_z, b8, m->mode);
   dw_q_run(&D->dwq[0], b8, 2, a8, m->mode);
   conv_q_run(&D->pwq[0], a8, 2, b8, m->mode);
-  lrelu_q_run(&D->lr[0], b8, 512, a8);
+  lrelu_q_run(&D->lr[0], b8, 512, a8, m->mode);
   conv_q_run(&D->cvq[0], a8, 2, b8, m->mode);
   for (int i = 0; i < 512; ++i) {
     float v = dequantize_f(b8[i], D->cvq[0].sout, D->cvq[0].zout) + x164[i];
-    X[i] = quantize_f(v, D->q3_s, D->q3_z);
+    X[i] = quantize_f(v, D->q3_s, D->q3_z, m->mode);
   }
   tap8(s, X, 512);
   for (int r = 1; r < 3; ++r) {
     const lrelu_q* la = &D->lr[2 * r - 1];
-    lrelu_q_run(la, X, 512, a8);
+    lrelu_q_run(la, X, 512, a8, m->mode);
     int S = 2 * D->dwq[r].dil;
-    push_state_q(s->d_r0[r], S, a8, 2, 256, la->sout, la->zout, b8);
+    push_state_q(s->d_r0[r], S, a8, 2, 256, la->sout, la->zout, b8, m->mode);
     dw_q_run(&D->dwq[r], b8, 2, a8, m->mode);
     conv_q_run(&D->pwq[r], a8, 2, b8, m->mode);
-    lrelu_q_run(&D->lr[2 * r], b8, 512, a8);
+    lrelu_q_run(&D->lr[2 * r], b8, 512, a8, m->mode);
     conv_q_run(&D->cvq[r], a8, 2, b8, m->mode);
-    add_q_run(&D->add[r - 1], b8, X, 512, X2);
+    add_q_run(&D->add[r - 1], b8, X, 512, X2, m->mode);
     memcpy(X, X2, 512);
     tap8(s, X, 512);
   }
-  lrelu_q_run(&D->lr[5], X, 512, a8); /* [2][256] */
+  lrelu_q_run(&D->lr[5], X, 512, a8, m->mode); /* [2][256] */
   float x231[4 * 128];
   for (int g = 0; g < 2; ++g) {
     float y[6 * 64];

@@ -31,3 +31,10 @@ def oracle_double():
     from oracle import lyra_oracle
     lyra_oracle.build()
     return lyra_oracle.Oracle(mode="gemmlowp_double")
+
+
+@pytest.fixture(scope="session")
+def oracle_xnnpack():
+    from oracle import lyra_oracle
+    lyra_oracle.build()
+    return lyra_oracle.Oracle(mode="xnnpack")

@@ -21,7 +21,11 @@ from oracle.logmel_np import LogMelExtractor
 SHA = {  # mode -> bits -> sha256[:16] of the first 150 packets of sample1_16kHz.wav
     "exact": {64: "a460adeb4ac4f1c8", 120: "8ddf7e64edc74415", 184: "afe043bd95a159ca"},
     "gemmlowp_double": {64: "ad3f6cb809f3699f", 120: "134112ecd23c4d0f", 184: "9f575b7344f402eb"},
+    # round 4, mode "xnnpack" (default): the same 150 hops through oracle/tflite_interp.py executing the flatbuffers with
+    # XNNPACK's arithmetic, every op of which equals real XNNPACK (tests/test_xnnpack_witness.py)
+    "xnnpack": {64: "6d4759d9ca14c62a", 120: "446e2075921b6970", 184: "6045429471825364"},
 }
+MODES = ["xnnpack", "exact", "gemmlowp_double"]
 
 
 def hops_of(golden_dir, name):
@@ -47,9 +51,9 @@ def lsd_per_hop(pcm_in, pcm_out):
 # ------------------------------------------------------------------------------------------------------------------
 # oracle (CPU)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["exact", "gemmlowp_double"])
-def test_oracle_whole_file_packets(golden_dir, oracle_exact, oracle_double, mode):
-    o = oracle_exact if mode == "exact" else oracle_double
+@pytest.mark.parametrize("mode", MODES)
+def test_oracle_whole_file_packets(golden_dir, oracle_exact, oracle_double, oracle_xnnpack, mode):
+    o = {"exact": oracle_exact, "gemmlowp_double": oracle_double, "xnnpack": oracle_xnnpack}[mode]
     hops = hops_of(golden_dir, "sample1_16kHz")
     assert hops.shape[0] == 172
     for bits in (64, 120, 184):
@@ -61,11 +65,13 @@ def test_oracle_whole_file_packets(golden_dir, oracle_exact, oracle_double, mode
         assert sha16(pk[:150]) == SHA[mode][bits]
 
 
-def test_oracle_lsd_both_wavs(golden_dir, oracle_exact):
+@pytest.mark.parametrize("mode", ["xnnpack", "exact"])
+def test_oracle_lsd_both_wavs(golden_dir, oracle_exact, oracle_xnnpack, mode):
+    o = oracle_exact if mode == "exact" else oracle_xnnpack
     for name in ("sample1_16kHz", "sample2_16kHz"):
         hops = hops_of(golden_dir, name)
         for bits in (64, 120, 184):
-            r = lyra_oracle.run_batch(oracle_exact, hops[:, None, :], bits // 4, do_decode=True)
+            r = lyra_oracle.run_batch(o, hops[:, None, :], bits // 4, do_decode=True)
             lsd = lsd_per_hop(hops[:150], r["pcm"][:150, 0])
             assert lsd.max() < 2.0, (name, bits, lsd.max())
 
@@ -88,7 +94,7 @@ def ctx_by_mode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["exact", "gemmlowp_double"])
+@pytest.mark.parametrize("mode", MODES)
 def test_gpu_whole_file_packets_b1(golden_dir, ctx_by_mode, mode):
     ctx = ctx_by_mode(mode)
     hops = hops_of(golden_dir, "sample1_16kHz")
@@ -101,14 +107,14 @@ def test_gpu_whole_file_packets_b1(golden_dir, ctx_by_mode, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["exact", "gemmlowp_double"])
-def test_gpu_whole_file_b4096_all_hops(golden_dir, ctx_by_mode, oracle_exact, oracle_double, mode):
+@pytest.mark.parametrize("mode", MODES)
+def test_gpu_whole_file_b4096_all_hops(golden_dir, ctx_by_mode, oracle_exact, oracle_double, oracle_xnnpack, mode):
     """The whole file on 4096 streams at once (device-pointer pipeline as benchmarked), every stream a replica:
     packets hash to the known answer, PCM is bit-exact versus the oracle, all replicas agree, over all 172 hops."""
     import torch
     import lyra_amd
     ctx = ctx_by_mode(mode)
-    o = oracle_exact if mode == "exact" else oracle_double
+    o = {"exact": oracle_exact, "gemmlowp_double": oracle_double, "xnnpack": oracle_xnnpack}[mode]
     hops = hops_of(golden_dir, "sample1_16kHz")
     B, bits = 4096, 184
     ref = lyra_oracle.run_batch(o, hops[:, None, :], bits // 4, do_decode=True)
@@ -137,7 +143,7 @@ def test_gpu_whole_file_b4096_all_hops(golden_dir, ctx_by_mode, oracle_exact, or
 @pytest.mark.gpu
 def test_gpu_lsd_below_two(golden_dir, ctx_by_mode):
     """The reference's acceptance test on GPU output (lyra_integration_test.cc:131-142), both 16 kHz wavs x 3 bitrates."""
-    ctx = ctx_by_mode("exact")
+    ctx = ctx_by_mode("xnnpack")
     for name in ("sample1_16kHz", "sample2_16kHz"):
         hops = hops_of(golden_dir, name)
         ids = np.array([5, 6, 7], np.int32)

@@ -6,11 +6,13 @@ oracle and the HIP path against on the GPU box.
 
     python tools/make_golden.py
 
-Float accumulation in the interpreter is float64 (acc64=True), the closest to
-exact arithmetic; SURVEY.md 8(c): int8 codes downstream of a float layer can
-flip by one LSB when a pre-quantisation value sits within ~1e-6 of a rounding
-boundary, so fixtures are only kept for inputs where fp32 and fp64 accumulation
-agree on every int8 code (checked below).
+Round 4: the interpreter evaluates the fp32 layers as bias-first fmaf chains
+(fp32="chain", oracle/chain_f32.c) -- the order real XNNPACK computes
+(tests/test_xnnpack_witness.py) and the canonical order of oracle/lyra_oracle.c --
+so the C oracle and the GPU reproduce these fixtures bit for bit, floats
+included.  (Rounds 1-3 accumulated in float64 and compared PCM to <= 1 LSB.)
+Three arithmetic modes of the int8 regions: "xnnpack" (what the reference runs,
+default), "exact", "gemmlowp_double" (TFLite builtin kernels).
 """
 import hashlib
 import os
@@ -38,9 +40,9 @@ def synth_pcm(stream_id, steps):
     return np.trunc(v).astype(np.int16).reshape(steps, 320)
 
 
-def run_codec(pcm_frames, mode, acc64):
-    enc = Interpreter(MC + "soundstream_encoder.tflite", requant=mode, acc64=acc64)
-    gan = Interpreter(MC + "lyragan.tflite", requant=mode, acc64=acc64)
+def run_codec(pcm_frames, mode, acc64=False, fp32="chain"):
+    enc = Interpreter(MC + "soundstream_encoder.tflite", requant=mode, acc64=acc64, fp32=fp32)
+    gan = Interpreter(MC + "lyragan.tflite", requant=mode, acc64=acc64, fp32=fp32)
     q = Interpreter(MC + "quantizer.tflite")
     feats, idxs, lossy_all, pcm_out, pcm_f = [], [], [], [], []
     for hop in pcm_frames:
@@ -67,44 +69,41 @@ def main():
     # --- 1. real speech -----------------------------------------------------
     w = wave.open(REF + "/testdata/sample1_16kHz.wav")
     pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16)
-    NF = 50  # (hop 53 of this file flips an int8 code between fp32 and fp64 accumulation in gemmlowp_double mode)
+    NF = 50
     frames = pcm[:NF * 320].reshape(NF, 320)
     g = {}
-    for mode in ("exact", "gemmlowp_double"):
-        r64 = run_codec(frames, mode, True)
-        r32 = run_codec(frames, mode, False)
-        assert np.array_equal(r64["feats"], r32["feats"]) and np.array_equal(r64["idx"], r32["idx"]), mode
-        d = np.abs(r64["pcm"].astype(int) - r32["pcm"].astype(int)).max()
-        print(mode, "speech: fp32-vs-fp64 accumulation pcm max diff", d)
-        assert d <= 1, "pick another excerpt: float order flips an int8 code here"
-        g[mode] = r64
+    for mode in ("xnnpack", "exact", "gemmlowp_double"):
+        g[mode] = run_codec(frames, mode)
+        r64 = run_codec(frames, mode, True, "numpy")      # information only: sensitivity to the fp32 summation order
+        print(mode, "speech: chain vs float64 accumulation: feature codes differing", int((r64["feats"] != g[mode]["feats"]).sum()),
+              "indices", int((r64["idx"] != g[mode]["idx"]).sum()), "pcm max diff",
+              int(np.abs(r64["pcm"].astype(int) - g[mode]["pcm"].astype(int)).max()))
     # known answers from BASELINE.md section 4 (first 150 hops) are checked in tests via hashes of
     # the first 60; here we just record.
     np.savez_compressed(os.path.join(OUT, "speech_sample1.npz"),
                         pcm_in=frames,
+                        feats_xnnpack=g["xnnpack"]["feats"], idx_xnnpack=g["xnnpack"]["idx"],
+                        lossy_xnnpack=g["xnnpack"]["lossy"], pcm_xnnpack=g["xnnpack"]["pcm"],
+                        pcmf_xnnpack=g["xnnpack"]["pcm_f"],
                         feats_exact=g["exact"]["feats"], idx_exact=g["exact"]["idx"],
                         lossy_exact=g["exact"]["lossy"], pcm_exact=g["exact"]["pcm"],
                         pcmf_exact=g["exact"]["pcm_f"],
                         feats_double=g["gemmlowp_double"]["feats"], idx_double=g["gemmlowp_double"]["idx"],
-                        pcm_double=g["gemmlowp_double"]["pcm"])
-    for n in (16, 30, 46):
-        h = hashlib.sha256(packets_of(g["exact"]["idx"], n).tobytes()).hexdigest()[:16]
-        print("speech exact", n * 4, "bits sha256[:16] of first", NF, "packets", h)
+                        pcm_double=g["gemmlowp_double"]["pcm"], pcmf_double=g["gemmlowp_double"]["pcm_f"])
+    for mode in ("xnnpack", "exact"):
+        for n in (16, 30, 46):
+            h = hashlib.sha256(packets_of(g[mode]["idx"], n).tobytes()).hexdigest()[:16]
+            print("speech", mode, n * 4, "bits sha256[:16] of first", NF, "packets", h)
     # --- 2. synthetic white noise (bench input), 4 streams x 6 steps ---------
     S, T = 4, 6
     pin = np.stack([synth_pcm(s, T) for s in range(S)], axis=1)  # [T][S][320]
-    outs = []
-    for s in range(S):
-        r64 = run_codec(pin[:, s], "exact", True)
-        r32 = run_codec(pin[:, s], "exact", False)
-        assert np.array_equal(r64["feats"], r32["feats"]) and np.array_equal(r64["idx"], r32["idx"])
-        d = np.abs(r64["pcm"].astype(int) - r32["pcm"].astype(int)).max()
-        print("noise stream", s, "fp32-vs-fp64 pcm max diff", d)
-        assert d <= 1
-        outs.append(r64)
+    outs = [run_codec(pin[:, s], "exact") for s in range(S)]
+    outx = [run_codec(pin[:, s], "xnnpack") for s in range(S)]
     np.savez_compressed(os.path.join(OUT, "noise_4x6.npz"), pcm_in=pin,
                         feats=np.stack([o["feats"] for o in outs], 1), idx=np.stack([o["idx"] for o in outs], 1),
-                        pcm=np.stack([o["pcm"] for o in outs], 1), pcmf=np.stack([o["pcm_f"] for o in outs], 1))
+                        pcm=np.stack([o["pcm"] for o in outs], 1), pcmf=np.stack([o["pcm_f"] for o in outs], 1),
+                        feats_xnnpack=np.stack([o["feats"] for o in outx], 1), idx_xnnpack=np.stack([o["idx"] for o in outx], 1),
+                        pcm_xnnpack=np.stack([o["pcm"] for o in outx], 1), pcmf_xnnpack=np.stack([o["pcm_f"] for o in outx], 1))
     # --- 3. RVQ fixture of the reference test --------------------------------
     src = open(REF + "/residual_vector_quantizer_test.cc").read()
     m = re.search(r"features_\{([^}]*)\}", src, re.S)
