@@ -226,7 +226,7 @@ def cpu_baseline(bits, mode):
     """Oracle (CPU port of the same arithmetic) on the host cores, bounded to ~12 s."""
     from oracle import lyra_oracle
     lyra_oracle.build()
-    o = lyra_oracle.Oracle(mode="exact")
+    o = lyra_oracle.Oracle(mode="xnnpack")
     cores = usable_cores()
     rng = np.random.Generator(np.random.PCG64(SEED))
     streams = cores * 2
@@ -390,7 +390,7 @@ class Shard:
         self.dev = torch.device("cuda", device)
         self.wl, self.args = wl, args
         B, bits = wl["B"], wl["bits"]
-        self.ctx = lyra_amd.LyraHip(device=device, max_streams=B, requant="exact", weights_image=weights_image,
+        self.ctx = lyra_amd.LyraHip(device=device, max_streams=B, requant="xnnpack", weights_image=weights_image,
                                     sub_batches=wl.get("sub_batches"))
         self.ctx.torch_order = False   # this harness synchronises explicitly around every region it times
         gen = torch.Generator(device=self.dev)
@@ -653,7 +653,7 @@ def result_line(args, wl, world, secs, frames, res, launcher):
                    "baseline_config": wl["config"], "streams_per_gpu": B, "total_streams": wl["total"],
                    "num_bits": bits,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective ({launcher})",
-                   "requant_mode": "exact", "sub_batches": wl.get("sub_batches") or 1,
+                   "requant_mode": "xnnpack", "sub_batches": wl.get("sub_batches") or 1,
                    "driver": "python, one `_dev` call per codec call" if (args.per_call or args.with_logmel)
                    else "lyra_hip_run_steps_dev: one C call per timed region"},
         "xrt_per_stream": round(value / 50.0 / wl["total"], 3),

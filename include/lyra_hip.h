@@ -81,9 +81,20 @@ extern "C" {
 #define LYRA_HIP_EHIP (-4)     /* HIP runtime error */
 #define LYRA_HIP_ENOMEM (-5)
 
-/* requantisation flavour of the int8 conv layers (oracle/lyra_oracle.c) */
+/* Arithmetic flavour of the graphs' int8 regions (oracle/lyra_oracle.c header):
+ *   XNNPACK          what the reference runs -- it executes both graphs through TFLite's XNNPACK delegate
+ *                    (soundstream_encoder.cc:39-40, lyra_gan_model.cc:39-40, tflite_model_wrapper.cc:63-85): QS8 convolutions
+ *                    requantised in fp32, XNNPACK's own int8 LeakyReLU / ADD / QUANTIZE kernels.  Every formula is held
+ *                    against real XNNPACK code (tests/test_xnnpack_witness.py).  The default.
+ *   EXACT, GEMMLOWP_DOUBLE
+ *                    TFLite's builtin kernels (what the reference falls back to when the delegate cannot be applied,
+ *                    tflite_model_wrapper.cc:76-78): Q31 single-rounding or gemmlowp double-rounding convolutions, gemmlowp
+ *                    LeakyReLU / ADD, round-half-away QUANTIZE.
+ * The fp32 layers are the same in all three: bias-first fused chains (XNNPACK's order). */
 #define LYRA_HIP_REQUANT_EXACT 0
 #define LYRA_HIP_REQUANT_GEMMLOWP_DOUBLE 1
+#define LYRA_HIP_REQUANT_XNNPACK 2
+#define LYRA_HIP_REQUANT_DEFAULT LYRA_HIP_REQUANT_XNNPACK
 
 typedef struct lyra_hip_ctx lyra_hip_ctx;
 

@@ -146,7 +146,7 @@ def _np(a, dtype, shape):
 class LyraHip:
     """One GPU context: weights + per-stream state for `max_streams` streams."""
 
-    def __init__(self, model_dir=None, device=0, max_streams=4096, requant="exact", weights_image=None,
+    def __init__(self, model_dir=None, device=0, max_streams=4096, requant="xnnpack", weights_image=None,
                  sub_batches=None, library=None):
         """sub_batches: split every `_dev` call into that many independent sub-batches on stream pairs of their own
         (the library's LYRA_HIP_SUBBATCHES switch, read when the context is created).  Pays when only ONE side is
@@ -154,7 +154,7 @@ class LyraHip:
         overlap."""
         self.L = _load(library)   # library: path of a build variant (experiments); default liblyra_hip.so
         h = C.c_void_p()
-        mode = {"exact": 0, "gemmlowp_double": 1}[requant]
+        mode = {"exact": 0, "gemmlowp_double": 1, "xnnpack": 2}[requant]
         saved = os.environ.get("LYRA_HIP_SUBBATCHES")
         if sub_batches is not None:
             os.environ["LYRA_HIP_SUBBATCHES"] = str(int(sub_batches))

@@ -499,7 +499,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   if (c->fused & 1) {   // the whole side in one launch (enc_side_kernel.hip)
     for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
     { ProfScope ps(c, K_ENC_SIDE, st_);
-      hipLaunchKernelGGL(c->mode ? enc_side_dr_kernel : enc_side_kernel, dim3(cdiv(B, 8)), dim3(512), enc_side_lds_bytes(), st_,
+      hipLaunchKernelGGL(c->mode == 2 ? enc_side_xn_kernel : c->mode ? enc_side_dr_kernel : enc_side_kernel, dim3(cdiv(B, 8)), dim3(512), enc_side_lds_bytes(), st_,
                          M.d_enc0, M.d_enc1, M.d_enc2, d_pcm, d_ids, B, c->sm.base[st::R_E0], c->sm.base[st::R_E1],
                          c->sm.base[st::R_E2], e0, e1, d_feat, codes, c->cw[K_ENC_SIDE]); }
     HIPCHK(c, hipGetLastError());
@@ -518,7 +518,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
   { ProfScope ps(c, K_ENC_S2, st_);
     for (int nt = cdiv(B, enc_s2_streams_per_wg()), g = cdiv(nt, c->tile_div[2]), t0 = 0; t0 < nt; t0 += g)
-      hipLaunchKernelGGL(c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(std::min(g, nt - t0)), dim3(512),
+      hipLaunchKernelGGL(c->mode == 2 ? enc_s2_xn_kernel : c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(std::min(g, nt - t0)), dim3(512),
                          enc_s2_lds_bytes() + c->lds_pad[2], st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
                          c->cw[K_ENC_S2], t0); }
   HIPCHK(c, hipGetLastError());
@@ -561,7 +561,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
 #ifdef LYRA_PARKED
   if (c->fused & 2) {   // the whole side in one launch (dec_side_kernel.hip)
     { ProfScope ps(c, K_DEC_SIDE, st_);
-      hipLaunchKernelGGL(c->mode ? dec_side_dr_kernel : dec_side_kernel, dim3(cdiv(B, 8)), dim3(512), dec_side_lds_bytes(), st_,
+      hipLaunchKernelGGL(c->mode == 2 ? dec_side_xn_kernel : c->mode ? dec_side_dr_kernel : dec_side_kernel, dim3(cdiv(B, 8)), dim3(512), dec_side_lds_bytes(), st_,
                          M.d_dec0, M.d_dec1, M.d_dec2, d_feat, d_ids, B, c->sm.base[st::R_D0], c->sm.base[st::R_D1],
                          c->sm.base[st::R_D2], d0, d1, d_pcm, d_pkt, num_stages, M.cb, c->cw[K_DEC_SIDE]); }
     HIPCHK(c, hipGetLastError());
@@ -571,7 +571,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
 #endif
   { ProfScope ps(c, K_DEC_S0, st_);
     for (int nt = cdiv(B, dec_s0_streams_per_wg()), g = cdiv(nt, c->tile_div[3]), t0 = 0; t0 < nt; t0 += g)
-      hipLaunchKernelGGL(c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(std::min(g, nt - t0)), dim3(512),
+      hipLaunchKernelGGL(c->mode == 2 ? dec_s0_xn_kernel : c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(std::min(g, nt - t0)), dim3(512),
                          dec_s0_lds_bytes() + c->lds_pad[3], st_,
                          M.d_dec0, d_feat, d_ids, B, c->sm.base[st::R_D0], d0, d_pkt, num_stages, M.cb,
                          c->cw[K_DEC_S0], t0); }
@@ -663,7 +663,7 @@ int lyra_hip_create_from_image(const void* image, size_t image_bytes, int device
 
 static int create_impl(const char* model_dir, const void* image, size_t image_bytes, int device, int max_streams,
                        int requant_mode, lyra_hip_ctx** out) {
-  if (!out || max_streams <= 0 || (requant_mode != 0 && requant_mode != 1))
+  if (!out || max_streams <= 0 || (requant_mode < 0 || requant_mode > 2))
     return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create: bad argument");
   *out = nullptr;
   int ndev = 0;
@@ -765,16 +765,21 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       set_lds(enc_side_kernel, enc_side_lds_bytes()) != hipSuccess ||
       set_lds(enc_side_dr_kernel, enc_side_lds_bytes()) != hipSuccess || set_lds(dec_side_kernel, dec_side_lds_bytes()) != hipSuccess ||
       set_lds(dec_side_dr_kernel, dec_side_lds_bytes()) != hipSuccess ||
+      set_lds(enc_side_xn_kernel, enc_side_lds_bytes()) != hipSuccess || set_lds(dec_side_xn_kernel, dec_side_lds_bytes()) != hipSuccess ||
 #endif
       set_lds(dec_s0_kernel, dec_s0_lds_bytes() + c->lds_pad[3]) != hipSuccess ||
       set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||
+      set_lds(enc_s2_xn_kernel, enc_s2_lds_bytes() + c->lds_pad[2]) != hipSuccess || set_lds(dec_s0_xn_kernel, dec_s0_lds_bytes() + c->lds_pad[3]) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes() + c->lds_pad[4]) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes() + c->lds_pad[5]) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, cng_lds_bytes()) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipFuncSetAttribute(dynamic LDS) failed");
   for (int i = 0; i < K_COUNT; ++i) c->cw[i] = code_warm_bytes(kKernelNames[i]);
-  if (c->mode) {
+  if (c->mode == 1) {
     c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_dr_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_dr_kernel");
     c->cw[K_ENC_SIDE] = code_warm_bytes("enc_side_dr_kernel"); c->cw[K_DEC_SIDE] = code_warm_bytes("dec_side_dr_kernel");
+  } else if (c->mode == 2) {
+    c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_xn_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_xn_kernel");
+    c->cw[K_ENC_SIDE] = code_warm_bytes("enc_side_xn_kernel"); c->cw[K_DEC_SIDE] = code_warm_bytes("dec_side_xn_kernel");
   }
 #ifdef LYRA_PARKED   // parked experiments: only in the `make EXTRA=-DLYRA_PARKED` variant
   if (const char* f = getenv("LYRA_HIP_FUSED")) c->fused = atoi(f);

@@ -42,6 +42,13 @@ __global__ __launch_bounds__(512, 4) void dec_side_dr_kernel(const DecS0P* P0, c
                                                             const float* cb, int code_bytes) {
   dec_side_body<1>(P0, P1, P2, feats, ids, B, st0, st1, st2, d0, d1, pcm, packets, num_stages, cb, code_bytes);
 }
+__global__ __launch_bounds__(512, 4) void dec_side_xn_kernel(const DecS0P* P0, const DecS1P* P1, const DecS2P* P2,
+                                                            const float* feats, const int32_t* ids, int B, uint8_t* st0,
+                                                            uint8_t* st1, uint8_t* st2, float* d0, float* d1,
+                                                            int16_t* pcm, const uint8_t* packets, int num_stages,
+                                                            const float* cb, int code_bytes) {
+  dec_side_body<2>(P0, P1, P2, feats, ids, B, st0, st1, st2, d0, d1, pcm, packets, num_stages, cb, code_bytes);
+}
 
 
 }  // namespace lyra

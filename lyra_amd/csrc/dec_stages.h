@@ -7,10 +7,10 @@
 //   dec_s1  8 streams/WG  3 fp32 resblocks @128ch x 4 rows -> tconv k10/s5 (two chained GEMM passes) -> [20][64]
 //   dec_s2  4 streams/WG  3 fp32 resblocks @64ch x 20 rows -> tconv k64/s16 -> 320 samples -> int16 PCM
 //
-// Transposed convs run in polyphase form: output block b (s rows) = [x[b-taps+1] .. x[b]] (K = taps*Cin,
-// oldest input first) times W[K][s*Cout] -- per output element exactly the oracle's chain (input position
-// ascending, channel ascending).  The tail rows that belong to the next frame are carried in the state with
-// the bias removed, as the graph does.
+// Transposed convs run in polyphase form: output block b (s rows) = bias + [x[b] .. x[b-taps+1]] (K = taps*Cin,
+// NEWEST input first = taps ascending) times W[K][s*Cout] -- per output element exactly the oracle's chain, which is
+// the order XNNPACK's subconvolution computes.  The tail rows that belong to the next frame are carried in the
+// state with the bias removed, as the graph does.
 #ifndef LYRA_AMD_CSRC_DEC_STAGES_H_
 #define LYRA_AMD_CSRC_DEC_STAGES_H_
 #include "resblock_q.h"
@@ -69,7 +69,6 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = tile * SD0;
-  constexpr int mode = MODE;
   wg_schedule_hint();
   LYRA_TSTAMP(80);
   LYRA_WSTAMP(120);
@@ -145,15 +144,15 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     f32x4 acc[1][4];
     const int g = wave >> 1;
     auto aoff = [&](int i, int c) { return (c * 16 + m) * FS + g * 16 + q * 4; };
-    gemm_f32<1, 4, 3>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, acc);
+    acc_bias(acc, P.head.b, wave * 4 * 16);
+    gemm_f32<1, 4, 3, 3, false>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, acc);
     fold_rows8<2>(acc[0]);   // rows = 8 streams: lanes 32-63 take over N tiles 2, 3
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 4 + j + 2 * (lane >> 5)) * 16 + (lane & 15);
-      float bias = as_global(P.head.b)[n];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        H8[((q & 1) * 4 + e) * QS5 + n] = (int8_t)quantize_f(lrelu(acc[0][j][e] + bias), P.q0);
+        H8[((q & 1) * 4 + e) * QS5 + n] = (int8_t)quantize_code<MODE>(lrelu(acc[0][j][e]), P.q0);
     }
   }
   __syncthreads();
@@ -190,7 +189,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       for (int e = 0; e < 4; ++e) {
         const int s = (q & 1) * 4 + e;
         float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP0 + g * 512);
-        int c8 = clamp8(requant(acc[0][tap][e] + zf + bias, U.M, U.sh, mode) + U.zout);
+        int c8 = conv_code<MODE>(acc[0][tap][e] + zf + bias, U.M, U.sh, U.zout);
         float y = dequantize_f(c8, P.up0_dq[g].s, P.up0_dq[g].z);
         if (tap < 2) {
           y = y + told[tap < 2 ? tap : 0][e];
@@ -225,7 +224,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       int c8[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        c8[e] = quantize_f(lrelu(XF[(t * SD0 + s) * CS2 + at16(w4 * 4 + e)]), P.q1);
+        c8[e] = quantize_code<MODE>(lrelu(XF[(t * SD0 + s) * CS2 + at16(w4 * 4 + e)]), P.q1);
       a[t] = pack8(c8[0], c8[1], c8[2], c8[3]);
     }
     const int x[2][3] = {{h0, h1, a[0]}, {h1, a[0], a[1]}};
@@ -237,7 +236,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
         int acc = db[e];                                  // zero point folded into dq.b
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc += sx8(x[t][j], e) * sx8(ww[j], e);
-        o[e] = clamp8(requant(acc, dM[e], dsh[e], mode) + dq.zout);
+        o[e] = conv_code<MODE>(acc, dM[e], dsh[e], dq.zout);
       }
       *reinterpret_cast<int*>(&QD[(t * SD0 + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
       if (cx.valid(s)) *reinterpret_cast<int*>(hp + t * 256) = a[t];
@@ -256,7 +255,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
         for (int i = 0; i < MTD0; ++i)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.pwq[0].zout);
+            int c8 = conv_code<MODE>(acc[i][j][e] + bias, M, sh, P.pwq[0].zout);
             QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lut8(LQ, c8);
           }
       }
@@ -277,9 +276,9 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             int row = i * 16 + q * 4 + e;
-            int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.cvq[0].zout);
+            int c8 = conv_code<MODE>(acc[i][j][e] + bias, M, sh, P.cvq[0].zout);
             float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + pc];
-            QX[row * QS + n] = (int8_t)quantize_f(v, P.q3);
+            QX[row * QS + n] = (int8_t)quantize_code<MODE>(v, P.q3);
           }
       }
     }
@@ -287,10 +286,10 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   }
   LYRA_TSTAMP(85);
   const RbqPre pre2 = resblock_q_prefetch<SD0>(cx, 9, st::D_R0_2, P.dwq[2], P.pwq[2], P.cvq[2]);
-  resblock_q256<SD0>(QX, QD, QP, cx, 3, st::D_R0_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[1], P.pwq[1], P.cvq[1],
-                     P.add[0], LA, mode, pre1, 90);
-  resblock_q256<SD0>(QX, QD, QP, cx, 9, st::D_R0_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[2], P.pwq[2], P.cvq[2],
-                     P.add[1], LA + 512, mode, pre2, 94);
+  resblock_q256<SD0, MODE>(QX, QD, QP, cx, 3, st::D_R0_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[1], P.pwq[1], P.cvq[1],
+                           P.add[0], LA, pre1, 90);
+  resblock_q256<SD0, MODE>(QX, QD, QP, cx, 9, st::D_R0_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[2], P.pwq[2], P.cvq[2],
+                           P.add[1], LA + 512, pre2, 94);
   LYRA_TSTAMP(86);
   // a = int8 LeakyReLU(X3), laid out for the up1 GEMM as [t][16 rows][QS] (rows s >= S are padding)
   for (int idx = tid; idx < 2 * SD0 * 64; idx += NTD0) {
@@ -329,7 +328,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       float y[6];
 #pragma unroll
       for (int tau = 0; tau < 6; ++tau) {
-        int c8 = clamp8(requant(o[tau] + bias, U.M, U.sh, mode) + U.zout);
+        int c8 = conv_code<MODE>(o[tau] + bias, U.M, U.sh, U.zout);
         y[tau] = dequantize_f(c8, P.up1_dq[g].s, P.up1_dq[g].z);
       }
       y[0] = y[0] + stp[co];
@@ -371,11 +370,13 @@ constexpr int CS1 = 136;
 constexpr int NTD1 = LYRA_S1_THREADS;
 }  // namespace
 
-// tconv k10/s5, polyphase: output block b (5 rows x 64 ch = N 320) = x[b-1] . W[taps 5..9] then x[b] . W[taps 0..4],
-// ONE fp32 chain per output (earlier input first).  Pass 1 runs every input row t against taps 5..9 (the
-// partial chains of block t+1), the C tiles are shifted down by one input row (8 of a tile's 16 rows:
-// a 32-lane rotation) and become pass 2's initial accumulators; block 4 = x[3] alone is the carried tail.
-// A wave computes NTW of the 20 N tiles starting at tile0.
+// tconv k10/s5, polyphase: output block b (5 rows x 64 ch = N 320) = bias, then x[b] . W[taps 0..4], then
+// x[b-1] . W[taps 5..9]: ONE fp32 chain per output, taps ascending = NEWEST input first (XNNPACK's subconvolution
+// order, tests/test_xnnpack_witness.py).  Pass 1 runs every input row t against taps 0..4 from the bias (the head of
+// block t's chain; block 0 is complete after it, its older input being the previous frame's carried tail); the C
+// tiles are then shifted UP by one input row (8 of a tile's 16 rows: a 32-lane rotation) so that C row (b, s) sits on
+// A row (b - 1, s), block 4 enters as the bare bias, and pass 2 continues the chains with taps 5..9.
+// Block 4 = bias + x[3] . W[5..9] is the carried tail.  A wave computes NTW of the 20 N tiles starting at tile0.
 template <int NTW>
 __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, const DecS1P& P, const TileCtx& cx,
                                              int b0, float* __restrict__ out1, int tile0) {
@@ -386,21 +387,28 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
     int R = i * 16 + m, t = R / SD1, s = R & (SD1 - 1);
     return (t * SD1 + s) * CS1 + c * 16 + q * 4;
   };
-  const f32x4* wfrag = P.up.w + tile0 * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 5..9, 8-15 taps 0..4
-  gemm_f32<2, NTW, 8, 16>(XB, aoff, wfrag, acc);
+  const f32x4* wfrag = P.up.w + tile0 * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 0..4, 8-15 taps 5..9
+  float biasv[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    biasv[j] = as_global(P.up.b)[((tile0 + j) * 16 + (lane & 15)) & 63];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i][j] = (f32x4){biasv[j], biasv[j], biasv[j], biasv[j]};
+  }
+  gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag, acc);
   LYRA_TSTAMP(54);
   LYRA_WSTAMP(114);
-  f32x4 tail[NTW];
+  f32x4 head[NTW];
   const bool lo = lane < 32;
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float a = acc[0][j][e], bb = acc[1][j][e];
-      rot32_pair(a, bb);                       // a = [Y(t1), Y(t0)], bb = [Y(t3), Y(t2)]
-      acc[0][j][e] = lo ? 0.f : a;             // blocks 0 | 1  <-  0     | Y(t0)
-      acc[1][j][e] = lo ? a : bb;              // blocks 2 | 3  <-  Y(t1) | Y(t2)
-      tail[j][e] = bb;                         // lanes 0-31: block 4 = Y(t3)
+      float a = acc[0][j][e], bb = acc[1][j][e];   // a = [Y(b0) | Y(b1)], bb = [Y(b2) | Y(b3)]  (lanes 0-31 | 32-63)
+      head[j][e] = a;                              // lanes 0-31: block 0, complete
+      rot32_pair(a, bb);                           // a = [Y(b1) | Y(b0)], bb = [Y(b3) | Y(b2)]
+      acc[0][j][e] = lo ? a : bb;                  // blocks 1 | 2
+      acc[1][j][e] = lo ? bb : biasv[j];           // blocks 3 | 4 (block 4 starts from the bare bias)
     }
   gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
   LYRA_TSTAMP(55);
@@ -409,25 +417,25 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
   for (int j = 0; j < NTW; ++j) {
     const int n = (tile0 + j) * 16 + (lane & 15);
     const int jj = n >> 6, co = n & 63;
-    const float bias = as_global(P.up.b)[co], sub = as_global(P.up_sub)[co];
+    const float sub = as_global(P.up_sub)[co];
     const int pc = at16(co);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int R = i * 16 + q * 4 + e, b = R / SD1, s = R & (SD1 - 1);
-        const int tau = 5 * b + jj;
-        float y = acc[i][j][e] + bias;
-        y = y + (tau < 5 ? SB[(tau * SD1 + s) * 72 + co] : 0.f);
-        if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + tau) * 64 + pc] = y;
+        const int R = i * 16 + q * 4 + e, b = 1 + R / SD1, s = R & (SD1 - 1);
+        float y = acc[i][j][e];
+        y = y + 0.f;
+        if (!cx.valid(s)) continue;
+        if (b < 4) out1[((size_t)(b0 + s) * 20 + 5 * b + jj) * 64 + pc] = y;
+        else reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y - sub;
       }
     if (lo) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = q * 4 + e;
-        float y = tail[j][e] + bias;
-        y = y + 0.f;
-        if (cx.valid(s)) reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y - sub;
+        const float y = head[j][e] + SB[(jj * SD1 + s) * 72 + co];
+        if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + jj) * 64 + pc] = y;
       }
     }
   }
@@ -562,17 +570,20 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
     for (int e = 0; e < 4; ++e)
       XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
   __syncthreads();
-  // tconv k64/s16, polyphase: blocks b = 0..22 (+1 of padding), rows (b, s); K = 4 x 64 (oldest input first);
-  // N = 16 phases.  24*S rows = 6 M tiles per 4 streams: waves 0..(3 * S / 4 - 1) take two each.
+  // tconv k64/s16, polyphase: blocks b = 0..22 (+1 of padding), rows (b, s); K = 4 x 64 (newest input first: chunk
+  // group g reads input block b - g = LDS row b + 3 - g); N = 16 phases; every chain starts from the bias.
+  // 24*S rows = 6 M tiles per 4 streams: waves 0..(3 * S / 4 - 1) take two each.
   if (wave < 3 * SD2 / 4) {
     f32x4 acc[2][1];
     auto aoff = [&](int i, int c) {
       int R = (2 * wave + i) * 16 + m, b = R / SD2, s = R & (SD2 - 1);
-      return ((b + (c >> 2)) * SD2 + s) * CS0 + (c & 3) * 16 + q * 4;
+      return ((b + 3 - (c >> 2)) * SD2 + s) * CS0 + (c & 3) * 16 + q * 4;
     };
-    gemm_f32<2, 1, 16>(XB, aoff, P.up.w, acc);
-    const int j = lane & 15;
     const float bias = as_global(P.up.b)[0];
+    acc[0][0] = (f32x4){bias, bias, bias, bias};
+    acc[1][0] = acc[0][0];
+    gemm_f32<2, 1, 16, 16, false>(XB, aoff, P.up.w, acc);
+    const int j = lane & 15;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -580,7 +591,7 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
         const int R = (2 * wave + i) * 16 + q * 4 + e, b = R / SD2, s = R & (SD2 - 1);
         if (b > 22) continue;
         const int tau = 16 * b + j;
-        float y = acc[i][0][e] + bias;
+        float y = acc[i][0][e];
         y = y + (tau < 48 ? SB[s * 48 + tau] : 0.f);
         if (!cx.valid(s)) continue;
         if (tau < 320) {

@@ -30,7 +30,7 @@ static_assert(4 * S2 * QS + 16 * QS <= XF_BYTES && 3 * S2 * QS5 + 16 * QS5 <= XF
 
 __host__ __device__ constexpr size_t enc_s2_lds() { return (size_t)2 * XF_BYTES + 3 * QB_BYTES + 2 * S2 * 4 + NLR * 256 + NADD * 2048; }
 
-// MODE: requantisation flavour of the int8 conv layers (0 exact / 1 gemmlowp double rounding), a compile-time constant:
+// MODE: arithmetic flavour of the int8 region (0 exact / 1 gemmlowp double rounding / 2 xnnpack), a compile-time constant:
 // as a run-time value every requantisation carried both arithmetic paths and a (uniform) branch -- a third of this
 // kernel's instructions -- which costs issue slots and, the code being executed once per workgroup, instruction fetch.
 template <int MODE>
@@ -53,7 +53,6 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int b0 = tile * S2;
-  constexpr int mode = MODE;
   wg_schedule_hint();
   LYRA_TSTAMP(0);
   LYRA_WSTAMP(100);
@@ -86,7 +85,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   // ---- resblock 0, fp32 half: depthwise (dil 1, history 2 rows, replaced) + pointwise 256->256 ----
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(&as_global(P.dw0.b)[p4 * 4]);   // chain starts from the bias
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int tau = t - (2 - j);
@@ -95,8 +94,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
       else v = *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::E_R2_0 + ((2 + tau) * 256 + p4 * 4) * 4);
       acc = fma4(v, *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(&as_global(P.dw0.w)[j * 256 + p4 * 4]), acc);
     }
-    f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(&as_global(P.dw0.b)[p4 * 4]);
-    *reinterpret_cast<f32x4*>(&DF[(t * S2 + s) * CS2 + p4 * 4]) = acc + bb;
+    *reinterpret_cast<f32x4*>(&DF[(t * S2 + s) * CS2 + p4 * 4]) = acc;
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
@@ -109,16 +107,16 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   {  // pointwise fp32 -> QUANTIZE -> int8 LeakyReLU -> QP
     f32x4 acc[MT2][2];
     auto aoff = [&](int i, int c) { return (i * 16 + m) * CS2 + c * 16 + q * 4; };
-    gemm_f32<MT2, 2, 16>(DF, aoff, P.pw0.w + (wave * 2) * 16 * 64, acc);
+    acc_bias(acc, P.pw0.b, wave * 2 * 16);
+    gemm_f32<MT2, 2, 16, 16, false>(DF, aoff, P.pw0.w + (wave * 2) * 16 * 64, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
-      float bias = as_global(P.pw0.b)[n];
 #pragma unroll
       for (int i = 0; i < MT2; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          int q8 = quantize_f(acc[i][j][e] + bias, P.q_r0);
+          int q8 = quantize_code<MODE>(acc[i][j][e], P.q_r0);
           QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lut8(LQ, q8);
         }
     }
@@ -140,9 +138,9 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int row = i * 16 + q * 4 + e;
-          int c8 = clamp8(requant(acc[i][j][e] + bias, M, sh, mode) + P.r0b.zout);
+          int c8 = conv_code<MODE>(acc[i][j][e] + bias, M, sh, P.r0b.zout);
           float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + pc];
-          QX[row * QS + n] = (int8_t)quantize_f(v, P.q_x1);
+          QX[row * QS + n] = (int8_t)quantize_code<MODE>(v, P.q_x1);
         }
     }
   }
@@ -151,11 +149,11 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   LYRA_TSTAMP(4);
   // ---- int8 resblocks 1, 2 (dilation 3 / 9; ring histories of 6 / 18 rows, T = 2) ---------------
   const RbqPre pre2 = resblock_q_prefetch<S2>(cx, 9, st::E_R2_2, P.dwq[1], P.pwq[1], P.cvq[1]);
-  resblock_q256<S2>(QX, QD, QP, cx, 3, st::E_R2_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[0], P.pwq[0], P.cvq[0], P.add[0],
-                    LA, mode, pre1, 20);
+  resblock_q256<S2, MODE>(QX, QD, QP, cx, 3, st::E_R2_1, LQ + 1 * 256, LQ + 2 * 256, P.dwq[0], P.pwq[0], P.cvq[0],
+                          P.add[0], LA, pre1, 20);
   LYRA_TSTAMP(5);
-  resblock_q256<S2>(QX, QD, QP, cx, 9, st::E_R2_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[1], P.pwq[1], P.cvq[1], P.add[1],
-                    LA + 512, mode, pre2, 30);
+  resblock_q256<S2, MODE>(QX, QD, QP, cx, 9, st::E_R2_2, LQ + 3 * 256, LQ + 4 * 256, P.dwq[1], P.pwq[1], P.cvq[1],
+                          P.add[1], LA + 512, pre2, 30);
 
   LYRA_TSTAMP(6);
   // ---- int8 LeakyReLU, 2-row history (replaced), conv k4/s2 g4 -> [1][512] --------------------------
@@ -197,7 +195,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = (q & 1) * 4 + e;
-      int c8 = clamp8(requant(dacc[0][j][e] + bias, M, sh, mode) + P.down2.zout);
+      int c8 = conv_code<MODE>(dacc[0][j][e] + bias, M, sh, P.down2.zout);
       QC[(2 * S2 + s) * QS5 + n] = (int8_t)lut8(LQ + 6 * 256, c8);
     }
   }
@@ -221,7 +219,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = q * 4 + e;
-      int c8 = clamp8(requant(acc[0][0][e] + bias, M, sh, mode) + P.bott.zout);
+      int c8 = conv_code<MODE>(acc[0][0][e] + bias, M, sh, P.bott.zout);
       if (s < S2 && cx.valid(s)) {
         feats[(size_t)(b0 + s) * 64 + n] = dequantize_f(c8, P.out);
         if (codes_dbg) codes_dbg[(size_t)(b0 + s) * 64 + n] = (float)c8;

@@ -44,6 +44,12 @@ __global__ __launch_bounds__(512, 4) void enc_side_dr_kernel(const EncS0P* P0, c
                                                             float* feats, float* codes_dbg, int code_bytes) {
   enc_side_body<1>(P0, P1, P2, pcm, ids, B, st0, st1, st2, e0, e1, feats, codes_dbg, code_bytes);
 }
+__global__ __launch_bounds__(512, 4) void enc_side_xn_kernel(const EncS0P* P0, const EncS1P* P1, const EncS2P* P2,
+                                                            const int16_t* pcm, const int32_t* ids, int B, uint8_t* st0,
+                                                            uint8_t* st1, uint8_t* st2, float* e0, float* e1,
+                                                            float* feats, float* codes_dbg, int code_bytes) {
+  enc_side_body<2>(P0, P1, P2, pcm, ids, B, st0, st1, st2, e0, e1, feats, codes_dbg, code_bytes);
+}
 
 
 }  // namespace lyra

@@ -4,7 +4,8 @@
 //   enc_s0  S0 streams/WG  PCM -> first conv k64/s16 -> 3 resblocks @64ch x 20 rows -> conv k10/s5   (fp32)
 //   enc_s1  8 streams/WG   3 resblocks @128ch x 4 rows (2nd conv g=2) -> conv k4/s2 g=2               (fp32)
 //
-// Every fp32 dot product runs on v_mfma_f32_16x16x4_f32 in ascending-k order (== the oracle's fmaf chain);
+// Every fp32 dot product runs on v_mfma_f32_16x16x4_f32 in ascending-k order starting from the bias (== the oracle's
+// fmaf chain == XNNPACK's micro-kernel order);
 // everything between two GEMMs (LeakyReLU, depthwise dilated conv, residual add, history update) is fused
 // around them in LDS/registers.  The stages are launched as kernels of their own (enc_kernels.hip: stage 0 with
 // 4 streams / 256 threads / 29 KB LDS, four tiles per CU; stage 1 with 8 streams / 512 threads / 35 KB, two per CU) or
@@ -108,12 +109,8 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
       int R = (wm * 5 + i) * 16 + m;
       return (R & (S0 - 1)) * PBS + (R / S0 + c) * 16 + q * 4;
     };
-    gemm_f32<5, 1, 4>(PB, aoff, P.first.w + wn * 4 * 64, xr);
-    float bias = as_global(P.first.b)[ncol];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xr[i][0][e] = xr[i][0][e] + bias;
+    acc_bias(xr, P.first.b, wn * 16);
+    gemm_f32<5, 1, 4, 4, false>(PB, aoff, P.first.w + wn * 4 * 64, xr);
   }
   __syncthreads();  // PCM staging area is free again
 #pragma unroll
@@ -153,19 +150,19 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
       int R = i * 16 + m;
       return ((5 * (R / S0) + tap) * S0 + (R & (S0 - 1))) * CS0 + c16 * 16 + q * 4;
     };
-    gemm_f32<MTW, NTW, 40>(XB, aoff, P.down.w + (wave * NTW) * 40 * 64, acc);
+    acc_bias(acc, P.down.b, wave * NTW * 16);
+    gemm_f32<MTW, NTW, 40, 40, false>(XB, aoff, P.down.w + (wave * NTW) * 40 * 64, acc);
     LYRA_TSTAMP(5);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       int n = (wave * NTW + j) * 16 + (lane & 15);
-      float bias = as_global(P.down.b)[n];
       int pc = at16(n);
 #pragma unroll
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int R = i * 16 + q * 4 + e, tau = R / S0, s = R & (S0 - 1);
-          if (valid(s)) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = acc[i][j][e] + bias;
+          if (valid(s)) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = acc[i][j][e];
         }
     }
   }
@@ -246,18 +243,18 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
       int R = i * 16 + m;
       return ((2 * (R / S1) + tap) * S1 + (R & (S1 - 1))) * CS1 + g * 64 + c16 * 16 + q * 4;
     };
-    gemm_f32<MTW, NTW, 16>(XB, aoff, P.down.w + nt0 * 16 * 64, acc);
+    acc_bias(acc, P.down.b, nt0 * 16);
+    gemm_f32<MTW, NTW, 16, 16, false>(XB, aoff, P.down.w + nt0 * 16 * 64, acc);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       int n = (nt0 + j) * 16 + (lane & 15);
-      float bias = as_global(P.down.b)[n];
       int pc = at16(n);
 #pragma unroll
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int R = i * 16 + q * 4 + e, tau = R / S1, s = R & (S1 - 1);
-          if (valid(s)) out1[((size_t)(b0 + s) * 2 + tau) * 256 + pc] = acc[i][j][e] + bias;
+          if (valid(s)) out1[((size_t)(b0 + s) * 2 + tau) * 256 + pc] = acc[i][j][e];
         }
     }
   }

@@ -8,7 +8,9 @@
 //    v_mfma_f32_16x16x4_f32 holds A[m = lane&15][k = lane>>4]; with AT16 one ds_read_b128 returns
 //    the lane's A operands for four consecutive MFMAs (k = q, 4+q, 8+q, 12+q ... i.e. kk*4+q), so the
 //    K loop runs in strictly ascending k -- bitwise the fmaf chain the oracle defines
-//    (oracle/lyra_oracle.c header) -- at one LDS read per four MFMAs.
+//    (oracle/lyra_oracle.c header) -- at one LDS read per four MFMAs.  The chains START FROM THE BIAS
+//    (acc_bias below): that is the order XNNPACK's f32 micro-kernels compute (tests/test_xnnpack_witness.py),
+//    and it removes the epilogues' "+ bias" vector add.
 //  * fp32 rows are padded by 8 floats (stride C+8): conflict-free for that ds_read_b128 pattern.
 //  * int8 activations keep natural channel order, row stride C+32 bytes.
 //  * Weights are pre-packed on the host into per-lane MFMA B fragments (one 16-byte global load
@@ -151,6 +153,41 @@ __device__ __forceinline__ int32_t add_q(int32_t a, int32_t b, const AddQ& L) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// MODE 2 "xnnpack": XNNPACK's QS8 arithmetic (what the reference runs, use_xnn=true; every formula held against real
+// XNNPACK code, tests/test_xnnpack_witness.py).  Cheaper on this ISA than TFLite's fixed-point emulation as well.
+// ---------------------------------------------------------------------------------------------
+// conv / depthwise / transpose-conv: q = RNE(clamp(float(acc) * scale)) + z.  `Mbits` carries the fp32 scale
+// (s_in * s_w[c]) / s_out in mode 2 and the Q31 multiplier otherwise (model.hip).  The clamp bounds are integers, so
+// clamp-then-round == round-then-clamp; v_rndne_f32 is round-to-nearest-even like lrintf / cvtps2dq.
+__device__ __forceinline__ int32_t xnn_requant(int32_t acc, int32_t Mbits, int32_t zout) {
+  const float v = (float)acc * __int_as_float(Mbits);
+  return clamp8((int32_t)__builtin_rintf(v) + zout);
+}
+// the layers' requantisation in any mode -> clamped int8 code (as int)
+template <int MODE>
+__device__ __forceinline__ int32_t conv_code(int32_t acc, int32_t M, int sh, int32_t zout) {
+  if constexpr (MODE == 2) return xnn_requant(acc, M, zout);
+  else return clamp8(requant(acc, M, sh, MODE) + zout);
+}
+// f32 -> qs8 convert: RNE(x * (1 / s)) + z, clamped (reciprocal multiply, ties to even)
+__device__ __forceinline__ int32_t xnn_quantize(float x, const QP& Q) {
+  const float v = x * Q.rs;
+  const float lim = __builtin_fminf(__builtin_fmaxf(v, -1024.f), 1024.f);   // keep the int conversion in range
+  return clamp8((int32_t)__builtin_rintf(lim) + Q.z);
+}
+template <int MODE>
+__device__ __forceinline__ int32_t quantize_code(float x, const QP& Q) {
+  if constexpr (MODE == 2) return xnn_quantize(x, Q);
+  else return quantize_f(x, Q);
+}
+// qs8 add: (a * ma + b * mb + bias) >> shift, clamped around the zero point.  AddQ in mode 2 (model.hip):
+// m1 = ma, m2 = mb, mo = bias (rounding term and both zero points folded in), so = shift.
+__device__ __forceinline__ int32_t xnn_add(int32_t a, int32_t b, const AddQ& L) {
+  const int32_t acc = L.mo + a * L.m1 + b * L.m2;
+  return clamp8((acc >> L.so) + L.zo);
+}
+
+// ---------------------------------------------------------------------------------------------
 // MFMA tile GEMMs: A from LDS, B fragments from global (L2-resident weights), C in registers.
 //   a_off(i, c)  -> offset (floats / bytes) of this lane's 16-byte A fragment for the wave's i-th
 //                   M tile and K chunk c (lane-specific part included by the caller's lambda)
@@ -253,6 +290,19 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
         for (int j = 0; j < NTW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], acc[i][j], 0, 0, 0);
     LYRA_MFMA_END();
+  }
+}
+
+// Start the chains from the bias: C layout col = lane & 15, so one value per N tile fills a lane's four rows.
+//   bias: logical channel order; n0 = first output channel of the wave's first N tile
+template <int MTW, int NTW>
+__device__ __forceinline__ void acc_bias(f32x4 (&acc)[MTW][NTW], const float* bias, int n0) {
+  const float LYRA_GLOBAL* b = as_global(bias) + n0 + (threadIdx.x & 15);
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const float v = b[j * 16];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[i][j] = (f32x4){v, v, v, v};
   }
 }
 

@@ -140,8 +140,20 @@ class Arena {
   std::vector<uint8_t> buf_;
 };
 
+// XNNPACK QS8 fp32 requantisation scale, evaluated in fp32 as XNNPACK does: (s_in * s_w) / s_out.  The product is
+// stored to a float before the division (no contraction, no excess precision: model.hip is built -ffp-contract=off).
+int32_t xnn_scale_bits(float s_in, float s_w, float s_out) {
+  volatile float prod = s_in * s_w;
+  volatile float sc = prod / s_out;
+  float f = sc;
+  int32_t bits;
+  memcpy(&bits, &f, 4);
+  return bits;
+}
+
 struct Builder {
   const Pack& pk;
+  int mode;                                      // 0 exact / 1 gemmlowp_double / 2 xnnpack
   Arena arena;
   std::vector<std::pair<void*, size_t>> fixups;  // (address of a device-pointer field, arena offset)
   std::string stride_mismatch;                   // first transposed conv whose stride is not the kernels'
@@ -181,31 +193,8 @@ struct Builder {
     put(&out->b, std::vector<float>(b, b + cout));
   }
 
-  // ---- fp32 1x1 conv [64][1][64] for the wave-private residual blocks (resblocks_w.h): the WEIGHTS are the MFMA A
-  //      operand.  Fragment (c, j), lane (m = lane & 15, q = lane >> 4), element kk:
-  //        W[out = 16j + 4(m & 3) + (m >> 2)][in = 16c + 4kk + q]        (output channels AT16-permuted inside a tile)
-  //      stored [(c * 4 + j) * 64 + lane]; bias in AT16 channel order.
-  void conv_f_sw(const char* pre, int idx, ConvF* out) {
-    const uint32_t C = 64;
-    const float* w = pk.f32(key(pre, "conv", idx, "w"), {C, 1, C});
-    const float* b = pk.f32(key(pre, "conv", idx, "b"), {C});
-    if (!w || !b) return;
-    std::vector<float> frag((size_t)16 * 64 * 4), bp(C);
-    for (int c = 0; c < 4; ++c)
-      for (int j = 0; j < 4; ++j)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int kk = 0; kk < 4; ++kk) {
-            const int m = lane & 15, q = lane >> 4;
-            const int o = 16 * j + 4 * (m & 3) + (m >> 2), i = 16 * c + 4 * kk + q;
-            frag[(((size_t)c * 4 + j) * 64 + lane) * 4 + kk] = w[(size_t)o * C + i];
-          }
-    for (int ch = 0; ch < (int)C; ++ch) bp[at16(ch)] = b[ch];
-    put(&out->w, frag);
-    put(&out->b, bp);
-  }
-
   // ---- fp32 transposed conv [cout][k][cin], stride s -> polyphase B fragments ---------------------
-  //   K = (k/s)*cin with the OLDEST input block first, N = s*cout (n = phase*cout + co)
+  //   K = (k/s)*cin with the NEWEST input block first (taps ascending: XNNPACK's order), N = s*cout (n = phase*cout + co)
   void tconv_f(const char* pre, int idx, ConvF* out, uint32_t cout, uint32_t k, uint32_t cin, int s) {
     const float* w = pk.f32(key(pre, "tconv", idx, "w"), {cout, k, cin});
     const float* b = pk.f32(key(pre, "tconv", idx, "b"), {cout});
@@ -221,7 +210,7 @@ struct Builder {
             int kidx = c * 16 + kk * 4 + (lane >> 4);
             int n = nt * 16 + (lane & 15);
             int tb = kidx / cin, ci = kidx % cin;
-            int i = taps - 1 - tb;
+            int i = tb;   // K block tb multiplies input row b - tb, i.e. taps jj + s * tb
             int jj = n / cout, co = n % cout;
             frag[(((size_t)nt * KC + c) * 64 + lane) * 4 + kk] = w[((size_t)co * k + (jj + s * i)) * cin + ci];
           }
@@ -268,6 +257,7 @@ struct Builder {
       bf[n] = (int32_t)(b[n] - (long long)zin * sum);
       QM m = quantize_multiplier((double)q[0] * (double)ws[n] / (double)q[2]);
       M[n] = m.m; sh[n] = m.shift;
+      if (mode == 2) { M[n] = xnn_scale_bits(q[0], ws[n], q[2]); sh[n] = 0; }
     }
     put(&out->w, frag);
     put(&out->b, bf);
@@ -289,6 +279,7 @@ struct Builder {
     for (int c = 0; c < (int)C; ++c) {
       QM m = quantize_multiplier((double)q[0] * (double)ws[c] / (double)q[2]);
       M[c] = m.m; sh[c] = m.shift;
+      if (mode == 2) { M[c] = xnn_scale_bits(q[0], ws[c], q[2]); sh[c] = 0; }
       long long sum = 0;
       for (int j = 0; j < (int)k; ++j) sum += w[(size_t)j * C + c];
       bf[c] = (int32_t)(b[c] - (long long)zin * sum);  // the kernel accumulates raw codes
@@ -337,6 +328,7 @@ struct Builder {
     put(&out->zfold, zf);
     put(&out->bias, std::vector<int32_t>(b, b + cout));
     out->M = m.m; out->sh = m.shift; out->zout = (int)q[3];
+    if (mode == 2) { out->M = xnn_scale_bits(q[0], ws[0], q[2]); out->sh = 0; }
     dq->s = q[2]; dq->z = (int)q[3];
     put(sub, std::vector<float>(sc, sc + cout));
   }
@@ -348,6 +340,12 @@ struct Builder {
     QM n = quantize_multiplier((double)q[0] * (double)LYRA_LRELU_ALPHA / (double)q[2]);
     out->zin = (int)q[1]; out->zout = (int)q[3];
     out->mpos = p.m; out->spos = p.shift; out->mneg = n.m; out->sneg = n.shift;
+    if (mode == 2) {   // XNNPACK qs8 leaky relu: Q8 multipliers from fp32 scale ratios (spos / sneg unused)
+      volatile float pos = q[0] / q[2];
+      volatile float neg = pos * LYRA_LRELU_ALPHA;
+      out->mpos = (int32_t)std::lrintf(256.0f * pos); out->mneg = (int32_t)std::lrintf(256.0f * neg);
+      out->spos = out->sneg = 0;
+    }
   }
   void add_q(const char* pre, int idx, AddQ* out) {
     const float* q = pk.f32(key(pre, "add8", idx, "q"), {6});
@@ -358,6 +356,17 @@ struct Builder {
     QM mo = quantize_multiplier(twice / ((double)(1 << 20) * so));
     out->z1 = (int)q[1]; out->z2 = (int)q[3]; out->zo = (int)q[5];
     out->m1 = m1.m; out->s1 = m1.shift; out->m2 = m2.m; out->s2 = m2.shift; out->mo = mo.m; out->so = mo.shift;
+    if (mode == 2) {   // XNNPACK qs8 add (lyra_dev.h xnn_add): m1 = ma, m2 = mb, mo = bias, so = shift
+      volatile float ao = q[0] / q[4], bo = q[2] / q[4];
+      const float mx = ao > bo ? ao : bo;
+      uint32_t bits;
+      memcpy(&bits, &mx, 4);
+      const int shift = 20 - ((int)(bits >> 23) - 127);
+      const int32_t ma = (int32_t)std::lrintf(std::ldexp((float)ao, shift)), mb = (int32_t)std::lrintf(std::ldexp((float)bo, shift));
+      out->m1 = ma; out->m2 = mb; out->s1 = out->s2 = 0;
+      out->mo = (int32_t)(1 << (shift - 1)) - ma * out->z1 - mb * out->z2;
+      out->so = shift;
+    }
   }
   // int8 LeakyReLU tabulated over its 256 possible inputs: lut[i][c + 128] = lrelu_q(c)
   void lrelu_luts(const LreluQ* L, int n, const int8_t** out) {
@@ -365,6 +374,11 @@ struct Builder {
     for (int i = 0; i < n; ++i)
       for (int c = -128; c < 128; ++c) {
         int32_t v = c - L[i].zin;
+        if (mode == 2) {   // (v * m + (z_out << 8) + 0x80) >> 8, arithmetic shift
+          const int32_t acc = (L[i].zout << 8) + 0x80 + v * (v >= 0 ? L[i].mpos : L[i].mneg);
+          lut[(size_t)i * 256 + c + 128] = (int8_t)h_clamp8(acc >> 8);
+          continue;
+        }
         int32_t r = v >= 0 ? h_mbqm(v, L[i].mpos, L[i].spos) : h_mbqm(v, L[i].mneg, L[i].sneg);
         lut[(size_t)i * 256 + c + 128] = (int8_t)h_clamp8(r + L[i].zout);
       }
@@ -373,6 +387,7 @@ struct Builder {
   // int8 ADD: the two operand rescalings, lut[i][0][a + 128] and lut[i][1][b + 128] (int32)
   void add_luts(const AddQ* A, int n, const int32_t** out) {
     std::vector<int32_t> lut((size_t)n * 512);
+    if (mode != 2)   // mode 2 computes the ADD (no tables); the zero-filled block keeps the kernels' LDS layout
     for (int i = 0; i < n; ++i)
       for (int c = -128; c < 128; ++c) {
         lut[(size_t)i * 512 + c + 128] = h_mbqm((c - A[i].z1) * (1 << 20), A[i].m1, A[i].s1);
@@ -397,7 +412,7 @@ double hz_to_mel(double f) { return 1127.0 * std::log1p(f / 700.0); }
 bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   const int32_t* ver = pk.i32("meta.version", {1});
   if (!ver || ver[0] != 3) { *err = "weight container version identifier is not 3 (lyra_config.h:145-166)"; return false; }
-  Builder B{pk};
+  Builder B{pk, requant_mode};
   // Each kernel's weights are packed contiguously so that the kernel can warm its XCD's L2 / TLBs with one
   // pass over [warm.base, warm.base + warm.bytes) (l2_warm in lyra_dev.h).
   // ---- encoder (op numbering: tools/pack_weights.py) ----------------------------------
@@ -484,13 +499,8 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
     B.dw_f("dec", 6 + r, &M->dec2.dw[r], 64);
-#ifdef LYRA_WAVE_PRIVATE
-    B.conv_f_sw("dec", 13 + 2 * r, &M->dec2.pw[r]);
-    B.conv_f_sw("dec", 14 + 2 * r, &M->dec2.cv[r]);
-#else
     B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r], 64, 1, 64);
     B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r], 64, 1, 64);
-#endif
   }
   B.tconv_f("dec", 7, &M->dec2.up, 1, 64, 64, 16);
   {

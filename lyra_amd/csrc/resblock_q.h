@@ -5,7 +5,8 @@
 // These stages are bound by VALU issue (fixed-point emulation) and by exposed global-load latency, not by
 // MFMA or HBM, so:
 //   * int8 LeakyReLU is a function of one int8 code -> a 256-byte table in LDS (built on the host with the
-//     same gemmlowp arithmetic, model.hip lrelu_luts); the int8 ADD's two operand rescalings are int32 tables.
+//     mode's arithmetic -- gemmlowp or XNNPACK's Q8 multipliers --, model.hip lrelu_luts); the TFLite-builtin int8
+//     ADD's two operand rescalings are int32 tables (XNNPACK's ADD is cheap enough to compute).
 //   * thread (s, w4) owns channels 4*w4..4*w4+3 of stream s for BOTH rows of the frame, so LeakyReLU ->
 //     depthwise conv -> history write are thread-local (no LDS round trip, no barrier);
 //   * every global load a block needs (ring history words, per-channel requantisation parameters) is issued
@@ -81,10 +82,11 @@ __device__ __forceinline__ RbqPre resblock_q_prefetch(const TileCtx& cx, int d, 
 }
 
 // la / lm: LDS tables of the block's two LeakyReLUs; addlut: LDS table pair of its ADD.
-template <int S>
+// MODE: arithmetic flavour (0 exact / 1 gemmlowp double rounding / 2 xnnpack), compile-time.
+template <int S, int MODE>
 __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP, const TileCtx& cx, int d, int off,
                                               const int8_t* la, const int8_t* lm, const DwQ& dq, const ConvQ& pw,
-                                              const ConvQ& cv, const AddQ& add, const int32_t* addlut, int mode,
+                                              const ConvQ& cv, const AddQ& add, const int32_t* addlut,
                                               const RbqPre& pre, int tb) {
   static_assert(S == 8, "see resblock_q_prefetch");
   constexpr int QS = 288;
@@ -108,7 +110,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
         int acc = pre.b[e];
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc += sx8(x[j], e) * sx8(pre.ww[j], e);
-        o[e] = clamp8(requant(acc, pre.M[e], pre.sh[e], mode) + dq.zout);
+        o[e] = conv_code<MODE>(acc, pre.M[e], pre.sh[e], dq.zout);
       }
       *reinterpret_cast<int*>(&QD[(t * S + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
     }
@@ -129,7 +131,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        r8[j][e] = (int8_t)lut8(lm, clamp8(requant(acc[0][j][e] + pre.pb[j], pre.pM[j], pre.psh[j], mode) + pw.zout));
+        r8[j][e] = (int8_t)lut8(lm, conv_code<MODE>(acc[0][j][e] + pre.pb[j], pre.pM[j], pre.psh[j], pw.zout));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
@@ -159,16 +161,22 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int c8 = clamp8(requant(acc[0][j][e] + pre.cb[j], pre.cM[j], pre.csh[j], mode) + cv.zout);
-        ta[j][e] = addlut[c8 + 128];
-        tb2[j][e] = addlut[256 + xo[j][e] + 128];
+        int c8 = conv_code<MODE>(acc[0][j][e] + pre.cb[j], pre.cM[j], pre.csh[j], cv.zout);
+        if constexpr (MODE == 2) {
+          ta[j][e] = xnn_add(c8, xo[j][e], add);       // XNNPACK's qs8 add is two multiply-adds and a shift: no table
+        } else {
+          ta[j][e] = addlut[c8 + 128];
+          tb2[j][e] = addlut[256 + xo[j][e] + 128];
+        }
       }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        QX[(q * 4 + e) * QS + n] = (int8_t)clamp8(mbqm_double(ta[j][e] + tb2[j][e], add.mo, add.so) + add.zo);
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (MODE == 2) QX[(q * 4 + e) * QS + n] = (int8_t)ta[j][e];
+        else QX[(q * 4 + e) * QS + n] = (int8_t)clamp8(mbqm_double(ta[j][e] + tb2[j][e], add.mo, add.so) + add.zo);
+      }
     }
   }
   __syncthreads();

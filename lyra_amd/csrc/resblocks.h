@@ -110,11 +110,12 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     f32x4 dreg[5];
     {
       const f32x4 w0 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + p4 * 4);
+      const f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dws[r].b) + p4 * 4);
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const int t0 = tq + k * TSTEP - 2 * d;
         const f32x4 v0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(&A[(t0 * S + sq) * CS + p4 * 4]) : h0[k];
-        dreg[k] = fma4(v0, w0, (f32x4){0.f, 0.f, 0.f, 0.f});
+        dreg[k] = fma4(v0, w0, bb);   // the chain starts from the bias (XNNPACK's DWCONV order)
       }
       const f32x4 w1 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 64 + p4 * 4);
 #pragma unroll
@@ -124,11 +125,10 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
         dreg[k] = fma4(v1, w1, dreg[k]);
       }
       const f32x4 w2 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 128 + p4 * 4);
-      const f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dws[r].b) + p4 * 4);
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const f32x4 v2 = *reinterpret_cast<const f32x4*>(&A[(rq + k * RSTEP) * CS + p4 * 4]);
-        dreg[k] = fma4(v2, w2, dreg[k]) + bb;
+        dreg[k] = fma4(v2, w2, dreg[k]);
       }
     }
     LYRA_TSTAMP(10 + r * 8 + 2);
@@ -147,25 +147,25 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     auto aoff = [&](int i, int c) { return ((wm * 5 + i) * 16 + m) * CS + c * 16 + q * 4; };
     {  // 4. pointwise 64 -> 64, LeakyReLU -> A
       f32x4 acc[5][1];
-      float bias = as_global(pws[r].b)[ncol];
-      gemm_f32<5, 1, 4>(A, aoff, pws[r].w + wn * 4 * 64, acc);
+      acc_bias(acc, pws[r].b, wn * 16);
+      gemm_f32<5, 1, 4, 4, false>(A, aoff, pws[r].w + wn * 4 * 64, acc);
       LYRA_TSTAMP(10 + r * 8 + 5);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][0][e] + bias);
+        for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][0][e]);
       __syncthreads();
       LYRA_TSTAMP(10 + r * 8 + 6);
     }
     {  // 5. 1x1 conv 64 -> 64 + residual (registers)
       f32x4 acc[5][1];
-      float bias = as_global(cvs[r].b)[ncol];
-      gemm_f32<5, 1, 4>(A, aoff, cvs[r].w + wn * 4 * 64, acc);
+      acc_bias(acc, cvs[r].b, wn * 16);
+      gemm_f32<5, 1, 4, 4, false>(A, aoff, cvs[r].w + wn * 4 * 64, acc);
 #pragma unroll
       for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xr[i][0][e] = (acc[i][0][e] + bias) + xr[i][0][e];
+        for (int e = 0; e < 4; ++e) xr[i][0][e] = acc[i][0][e] + xr[i][0][e];
     }
     LYRA_TSTAMP(10 + r * 8 + 7);
     __syncthreads();  // all waves are done reading A before the next block overwrites it
@@ -248,10 +248,10 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
         f32x4 v0 = H.h[k][0], v1 = H.h[k][1];
         if (t0 >= 0) v0 = lrelu4(*reinterpret_cast<const f32x4*>(xq + t0 * S * CS));
         if (t1 >= 0) v1 = lrelu4(*reinterpret_cast<const f32x4*>(xq + t1 * S * CS));
-        f32x4 acc = fma4(v0, w0, (f32x4){0.f, 0.f, 0.f, 0.f});
+        f32x4 acc = fma4(v0, w0, bb);   // the chain starts from the bias
         acc = fma4(v1, w1, acc);
         acc = fma4(a, w2, acc);
-        *reinterpret_cast<f32x4*>(&D[(t * S + s) * CS + p4 * 4]) = acc + bb;
+        *reinterpret_cast<f32x4*>(&D[(t * S + s) * CS + p4 * 4]) = acc;
         if (valid) {
           if (ring) {
             int row = base + t;
@@ -268,10 +268,8 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
     {  // pointwise 128 -> 128, LeakyReLU
       f32x4 acc[MT][NTW];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + c * 16 + q * 4; };
-      float biasv[NTW];
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) biasv[j] = as_global(pws[r].b)[(wave * NTW + j) * 16 + (lane & 15)];
-      gemm_f32<MT, NTW, 8>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, acc);
+      acc_bias(acc, pws[r].b, wave * NTW * 16);
+      gemm_f32<MT, NTW, 8, 8, false>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, acc);
       LYRA_TSTAMP(40 + r * 8 + 3);
       // The next block's history rows.  vmcnt retires in order, so these loads would stall the first weight
       // fetch of a GEMM issued right after them; here they have the two barriers and the LDS-only P write
@@ -280,12 +278,11 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int ncol = (wave * NTW + j) * 16 + (lane & 15);
-        const float bias = biasv[j];
         const int pcol = at16(ncol);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) P[(i * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][j][e] + bias);
+          for (int e = 0; e < 4; ++e) P[(i * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][j][e]);
       }
       __syncthreads();
       LYRA_TSTAMP(40 + r * 8 + 4);
@@ -294,22 +291,19 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
       f32x4 acc[MT][NTW];
       const int g = (wave * NTW) >> 2;
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + g * 64 + c * 16 + q * 4; };
-      float biasv[NTW];
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) biasv[j] = as_global(cvs[r].b)[(wave * NTW + j) * 16 + (lane & 15)];
-      gemm_f32<MT, NTW, 4>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, acc);
+      acc_bias(acc, cvs[r].b, wave * NTW * 16);
+      gemm_f32<MT, NTW, 4, 4, false>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, acc);
       LYRA_TSTAMP(40 + r * 8 + 5);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int ncol = (wave * NTW + j) * 16 + (lane & 15);
-        const float bias = biasv[j];
         const int pcol = at16(ncol);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float* x = &X[(i * 16 + q * 4 + e) * CS + pcol];
-            *x = (acc[i][j][e] + bias) + *x;
+            *x = acc[i][j][e] + *x;
           }
       }
     }

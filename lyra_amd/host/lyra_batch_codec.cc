@@ -32,7 +32,7 @@ bool ParamsSupported(int sample_rate_hz, int num_channels, int num_streams) {
 
 lyra_hip_ctx* NewContext(const ghc::filesystem::path& model_path, int device, int num_streams) {
   lyra_hip_ctx* ctx = nullptr;
-  if (lyra_hip_create(model_path.string().c_str(), device, num_streams, LYRA_HIP_REQUANT_EXACT, &ctx) != 0) {
+  if (lyra_hip_create(model_path.string().c_str(), device, num_streams, LYRA_HIP_REQUANT_DEFAULT, &ctx) != 0) {
     LOG(ERROR) << "lyra_hip_create failed: " << lyra_hip_last_error(nullptr);
     return nullptr;
   }

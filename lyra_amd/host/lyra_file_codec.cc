@@ -102,7 +102,7 @@ bool EncodeWavs(const std::vector<std::vector<int16_t>>& wav_data, int num_chann
   encoded_features->assign(n, {});
   if (n == 0) return true;
   Ctx ctx;
-  if (lyra_hip_create(model_path.string().c_str(), device, n, LYRA_HIP_REQUANT_EXACT, &ctx.c) != 0) {
+  if (lyra_hip_create(model_path.string().c_str(), device, n, LYRA_HIP_REQUANT_DEFAULT, &ctx.c) != 0) {
     LOG(ERROR) << "Could not create lyra encoder: " << lyra_hip_last_error(nullptr);
     return false;
   }
@@ -176,7 +176,7 @@ bool DecodeFeaturesBatch(const std::vector<std::vector<uint8_t>>& packet_streams
     max_packets = std::max(max_packets, p.size() / packet_size);
   }
   Ctx ctx;
-  if (lyra_hip_create(model_path.string().c_str(), device, n, LYRA_HIP_REQUANT_EXACT, &ctx.c) != 0) {
+  if (lyra_hip_create(model_path.string().c_str(), device, n, LYRA_HIP_REQUANT_DEFAULT, &ctx.c) != 0) {
     LOG(ERROR) << "Could not create lyra decoder: " << lyra_hip_last_error(nullptr);
     return false;
   }

@@ -72,7 +72,7 @@ class SharedContext {
   lyra_hip_ctx* Acquire(const std::string& model_dir, int* stream_id) {
     std::lock_guard<std::mutex> l(mu_);
     if (!ctx_) {
-      if (lyra_hip_create(model_dir.c_str(), device, max_streams, LYRA_HIP_REQUANT_EXACT, &ctx_) != 0) {
+      if (lyra_hip_create(model_dir.c_str(), device, max_streams, LYRA_HIP_REQUANT_DEFAULT, &ctx_) != 0) {
         LOG(ERROR) << "lyra_hip_create failed: " << lyra_hip_last_error(nullptr);
         ctx_ = nullptr;
         return nullptr;

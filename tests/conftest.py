@@ -38,3 +38,9 @@ def oracle_xnnpack():
     from oracle import lyra_oracle
     lyra_oracle.build()
     return lyra_oracle.Oracle(mode="xnnpack")
+
+
+@pytest.fixture(scope="session")
+def oracle_default(oracle_xnnpack):
+    """The oracle in the product's default arithmetic mode ("xnnpack": what the reference runs, use_xnn=true)."""
+    return oracle_xnnpack

@@ -13,15 +13,15 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def test_reference_model_decoder_state_machine(oracle_exact):
+def test_reference_model_decoder_state_machine(oracle_default):
     """CPU: the restated LyraDecoder control flow against the reference's own expectations (lyra_decoder_test.cc):
     right sample counts for arbitrary requests, comfort noise reached after concealment (4 hops) + fade (2 hops) of
     loss, left again 2 hops after packets resume."""
     from oracle import lyra_codec_model as M
     from oracle import lyra_oracle
     rng = np.random.default_rng(0)
-    enc = M.RefLyraEncoder(oracle_exact, 16000, 64, False)
-    dec = M.RefLyraDecoder(oracle_exact, 16000, cng_seed=1)
+    enc = M.RefLyraEncoder(oracle_default, 16000, 64, False)
+    dec = M.RefLyraDecoder(oracle_default, 16000, cng_seed=1)
     for t in range(5):
         dec.SetEncodedPacket(enc.Encode(rng.integers(-3000, 3000, 320).astype(np.int16)))
         assert dec.DecodeSamples(320).size == 320 and not dec.is_comfort_noise()
@@ -60,7 +60,7 @@ def _run_session(tmp_path, oracle, rate, bitrate, dtx, pcm, script, demo=None):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rate,bitrate,dtx", [(16000, 6000, False), (48000, 3200, False), (8000, 9200, False),
                                               (16000, 9200, True), (32000, 6000, True)])
-def test_batch_codec_session_vs_reference_model(tmp_path, golden_dir, oracle_exact, rate, bitrate, dtx):
+def test_batch_codec_session_vs_reference_model(tmp_path, golden_dir, oracle_default, rate, bitrate, dtx):
     from oracle import lyra_codec_model as M
     from oracle import lyra_oracle
     bits = {3200: 64, 6000: 120, 9200: 184}[bitrate]
@@ -83,10 +83,10 @@ def test_batch_codec_session_vs_reference_model(tmp_path, golden_dir, oracle_exa
         mask = "".join(["0" if 12 <= t < 21 else "1", "1", "0" if t % 7 == 3 else "1", "1"])
         sizes = [hop] if t % 3 == 0 else ([hop // 4 + 3, hop - hop // 4 - 3] if t % 3 == 1 else [1, hop // 2, hop - hop // 2 - 1])
         script.append((mask, sizes))
-    packets, lengths, out = _run_session(tmp_path, oracle_exact, rate, bitrate, dtx, pcm, script)
+    packets, lengths, out = _run_session(tmp_path, oracle_default, rate, bitrate, dtx, pcm, script)
 
-    encs = [M.RefLyraEncoder(oracle_exact, rate, bits, dtx) for _ in range(n)]
-    decs = [M.RefLyraDecoder(oracle_exact, rate, cng_seed=0x4C797261 ^ s) for s in range(n)]
+    encs = [M.RefLyraEncoder(oracle_default, rate, bits, dtx) for _ in range(n)]
+    decs = [M.RefLyraDecoder(oracle_default, rate, cng_seed=0x4C797261 ^ s) for s in range(n)]
     pos = 0
     n_exact = n_total = 0
     worst = 0

@@ -12,7 +12,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits", [64, 120, 184])
-def test_cpp_plugin_surface(oracle_exact, golden_dir, tmp_path, bits):
+def test_cpp_plugin_surface(oracle_default, golden_dir, tmp_path, bits):
     import lyra_amd
     from oracle import lyra_oracle
     demo = os.path.join(ROOT, "lyra_amd", "plugin_demo")
@@ -24,7 +24,7 @@ def test_cpp_plugin_surface(oracle_exact, golden_dir, tmp_path, bits):
     r = subprocess.run([demo, lyra_amd.default_model_dir(), str(pin), str(bits), str(bits_out), str(pout)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
-    ref = lyra_oracle.run_batch(oracle_exact, pcm[:, None, :], bits // 4, do_decode=True)
+    ref = lyra_oracle.run_batch(oracle_default, pcm[:, None, :], bits // 4, do_decode=True)
     lines = open(bits_out).read().split()
     assert len(lines) == 12 and all(len(l) == bits for l in lines)
     for f, l in enumerate(lines):
@@ -35,7 +35,7 @@ def test_cpp_plugin_surface(oracle_exact, golden_dir, tmp_path, bits):
 
 
 @pytest.mark.gpu
-def test_cpp_plugins_many_threads_combined_calls(oracle_exact, golden_dir, tmp_path):
+def test_cpp_plugins_many_threads_combined_calls(oracle_default, golden_dir, tmp_path):
     """48 codec objects (extractor + quantizer + generative model each) on 48 threads, every one used hop by hop as the
     reference uses its plugins; the plugin layer combines calls that wait at the same time into batched device calls
     (lyra_hip_components.cc "Call combining").  Bit strings and PCM of every stream must equal the oracle's, and
@@ -55,7 +55,7 @@ def test_cpp_plugins_many_threads_combined_calls(oracle_exact, golden_dir, tmp_p
     r = subprocess.run([demo, lyra_amd.default_model_dir(), str(pin), str(n), str(bits), str(bits_out), str(pout)],
                        capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
-    ref = lyra_oracle.run_batch(oracle_exact, pcm, bits // 4, do_decode=True, threads=8)
+    ref = lyra_oracle.run_batch(oracle_default, pcm, bits // 4, do_decode=True, threads=8)
     lines = open(bits_out).read().split()
     assert len(lines) == T * n
     for f in range(T):
@@ -72,7 +72,7 @@ def test_cpp_plugins_many_threads_combined_calls(oracle_exact, golden_dir, tmp_p
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bitrate", [3200, 9200])
-def test_cpp_batch_codec_twins(oracle_exact, golden_dir, tmp_path, bitrate):
+def test_cpp_batch_codec_twins(oracle_default, golden_dir, tmp_path, bitrate):
     """BatchLyraEncoder / BatchLyraDecoder: the public-API twins for many streams.  Packets and
     PCM of every stream must equal the oracle's; the demo also checks the reference's argument validation."""
     import lyra_amd
@@ -89,7 +89,7 @@ def test_cpp_batch_codec_twins(oracle_exact, golden_dir, tmp_path, bitrate):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     bits = {3200: 64, 6000: 120, 9200: 184}[bitrate]
-    ref = lyra_oracle.run_batch(oracle_exact, pcm, bits // 4, do_decode=True)
+    ref = lyra_oracle.run_batch(oracle_default, pcm, bits // 4, do_decode=True)
     packets = np.fromfile(pk, np.uint8).reshape(T, n, -1)
     assert np.array_equal(packets, ref["packets"])
     out = np.fromfile(pout, np.int16).reshape(T, n, 320)
@@ -113,7 +113,7 @@ def _read_wav(path):
 
 
 @pytest.mark.gpu
-def test_cpp_file_transcode_ragged_batch(oracle_exact, golden_dir, tmp_path):
+def test_cpp_file_transcode_ragged_batch(oracle_default, golden_dir, tmp_path):
     """EncodeFiles / DecodeFiles: several WAV files of different lengths transcoded together
     (streams leave the batch as they run out of full hops; a trailing partial hop is dropped as
     encoder_main_lib.cc:71-73 does).  .lyra bytes and decoded samples must equal the oracle's per file."""
@@ -146,7 +146,7 @@ def test_cpp_file_transcode_ragged_batch(oracle_exact, golden_dir, tmp_path):
         assert enc.size == hops * 15 and dec.size == hops * 320
         if hops == 0:
             continue
-        ref = lyra_oracle.run_batch(oracle_exact, pcm[:hops * 320].reshape(hops, 1, 320), 120 // 4, do_decode=True)
+        ref = lyra_oracle.run_batch(oracle_default, pcm[:hops * 320].reshape(hops, 1, 320), 120 // 4, do_decode=True)
         assert np.array_equal(enc.reshape(hops, 15), ref["packets"][:, 0]), name
         assert np.array_equal(dec.reshape(hops, 320), ref["pcm"][:, 0]), name
 

@@ -19,18 +19,22 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ctx():
+    """The product's default arithmetic: XNNPACK's (what the reference runs)."""
     import lyra_amd
-    c = lyra_amd.LyraHip(max_streams=8192, requant="exact")
+    c = lyra_amd.LyraHip(max_streams=8192)
+    assert c.requant == "xnnpack"
     yield c
     c.close()
 
 
 @pytest.fixture(scope="module")
-def ctx_double():
+def ctx_builtin():
+    """The two TFLite-builtin-kernel flavours."""
     import lyra_amd
-    c = lyra_amd.LyraHip(max_streams=64, requant="gemmlowp_double")
-    yield c
-    c.close()
+    cs = {m: lyra_amd.LyraHip(max_streams=64, requant=m) for m in ("exact", "gemmlowp_double")}
+    yield cs
+    for c in cs.values():
+        c.close()
 
 
 def _g(golden_dir, name):
@@ -45,45 +49,46 @@ def synth(B, T, seed=0x4C797261):
 # ------------------------------------------------------------------------------------------------
 # golden fixtures
 # ------------------------------------------------------------------------------------------------
-def test_speech_golden_exact(ctx, golden_dir):
-    g = _g(golden_dir, "speech_sample1.npz")
-    ctx.reset()
+def _speech_golden(c, g, suf):
+    """Fixtures = graph execution of the reference's flatbuffers (tools/make_golden.py) with the fp32 layers as the
+    bias-first fmaf chains real XNNPACK computes: features, indices, lossy features and PCM are all bit-equal."""
+    c.reset()
     sid = np.array([5], np.int32)
     for f, hop in enumerate(g["pcm_in"]):
-        feat = ctx.extract(hop[None], sid)
-        assert np.array_equal(feat[0], g["feats_exact"][f]), f"features differ at hop {f}"
-        idx = ctx.rvq_encode(feat, 184)
-        assert np.array_equal(idx[0], g["idx_exact"][f]), f"indices differ at hop {f}"
-        lossy = ctx.rvq_decode(idx)
-        assert np.array_equal(lossy[0], g["lossy_exact"][f])
-        pcm = ctx.generate(lossy, sid)
-        assert np.abs(pcm[0].astype(int) - g["pcm_exact"][f].astype(int)).max() <= 1
-
-
-def test_speech_golden_double_rounding(ctx_double, golden_dir):
-    g = _g(golden_dir, "speech_sample1.npz")
-    c = ctx_double
-    c.reset()
-    for f, hop in enumerate(g["pcm_in"]):
-        feat = c.extract(hop[None])
-        assert np.array_equal(feat[0], g["feats_double"][f])
+        feat = c.extract(hop[None], sid)
+        assert np.array_equal(feat[0], g["feats_" + suf][f]), f"features differ at hop {f}"
         idx = c.rvq_encode(feat, 184)
-        assert np.array_equal(idx[0], g["idx_double"][f])
-        pcm = c.generate(c.rvq_decode(idx))
-        assert np.abs(pcm[0].astype(int) - g["pcm_double"][f].astype(int)).max() <= 1
+        assert np.array_equal(idx[0], g["idx_" + suf][f]), f"indices differ at hop {f}"
+        lossy = c.rvq_decode(idx)
+        if "lossy_" + suf in g.files:
+            assert np.array_equal(lossy[0], g["lossy_" + suf][f])
+        pcm = c.generate(lossy, sid)
+        assert np.array_equal(pcm[0], g["pcm_" + suf][f]), f"PCM differs at hop {f}"
 
 
-def test_known_answer_packets_fused(ctx, golden_dir):
-    """BASELINE.md section 4 known answers through the fused encode path; embedded bit-stream."""
+def test_speech_golden_xnnpack(ctx, golden_dir):
+    _speech_golden(ctx, _g(golden_dir, "speech_sample1.npz"), "xnnpack")
+
+
+@pytest.mark.parametrize("mode,suf", [("exact", "exact"), ("gemmlowp_double", "double")])
+def test_speech_golden_builtin_modes(ctx_builtin, golden_dir, mode, suf):
+    _speech_golden(ctx_builtin[mode], _g(golden_dir, "speech_sample1.npz"), suf)
+
+
+def test_known_answer_packets_fused(ctx, ctx_builtin, golden_dir):
+    """Known answers through the fused encode path; embedded bit-stream.  "exact": BASELINE.md section 4 / SURVEY.md A.6;
+    "xnnpack": graph execution in round 4 (tests/test_oracle_golden.py holds the same strings for the oracle)."""
     g = _g(golden_dir, "speech_sample1.npz")
-    want = ["a00809827516b2df", "a6890bde76bcb6e1", "a0f9692544bc120d"]
-    for bits, nbytes in ((64, 8), (120, 15), (184, 23)):
-        ctx.reset()
-        pk = [ctx.encode(g["pcm_in"][f][None], bits)[0] for f in range(3)]
-        assert all(p.size == nbytes for p in pk)
-        assert [bytes(p[:8]).hex() for p in pk] == want
-        if bits == 184:
-            assert bytes(pk[0]).hex() == "a00809827516b2df55c14f95327f2cc981d6a9f0d2dbc7"
+    for c, want, full in ((ctx, ["a008090c75b6ce39", "a6890bdc76bc46e8", "a0f9698548b79206"], None),
+                          (ctx_builtin["exact"], ["a00809827516b2df", "a6890bde76bcb6e1", "a0f9692544bc120d"],
+                           "a00809827516b2df55c14f95327f2cc981d6a9f0d2dbc7")):
+        for bits, nbytes in ((64, 8), (120, 15), (184, 23)):
+            c.reset()
+            pk = [c.encode(g["pcm_in"][f][None], bits)[0] for f in range(3)]
+            assert all(p.size == nbytes for p in pk)
+            assert [bytes(p[:8]).hex() for p in pk] == want
+            if bits == 184 and full:
+                assert bytes(pk[0]).hex() == full
 
 
 def test_noise_golden_batched(ctx, golden_dir):
@@ -93,9 +98,9 @@ def test_noise_golden_batched(ctx, golden_dir):
     for t in range(6):
         pk = ctx.encode(g["pcm_in"][t], 184, ids)
         idx = np.stack([np.array([[p >> 4, p & 15] for p in row]).reshape(-1) for row in pk])
-        assert np.array_equal(idx, g["idx"][t])
+        assert np.array_equal(idx, g["idx_xnnpack"][t])
         pcm = ctx.decode(pk, 184, ids)
-        assert np.abs(pcm.astype(int) - g["pcm"][t].astype(int)).max() <= 1
+        assert np.array_equal(pcm, g["pcm_xnnpack"][t])
 
 
 def test_rvq_fixture_and_random(ctx, golden_dir):
@@ -118,12 +123,12 @@ def test_rvq_fixture_and_random(ctx, golden_dir):
 # oracle on the same seeded inputs, many streams, ragged batch sizes, scattered stream ids
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,bits", [(1, 64), (13, 120), (37, 184)])
-def test_vs_oracle_bit_exact(ctx, oracle_exact, B, bits):
+def test_vs_oracle_bit_exact(ctx, oracle_default, B, bits):
     from oracle import lyra_oracle
     T = 8
     pcm = synth(B, T, seed=1234 + B)
     pcm[2:4] //= 64  # some quiet frames too
-    r = lyra_oracle.run_batch(oracle_exact, pcm, bits // 4, do_decode=True, threads=4, want_feats=True)
+    r = lyra_oracle.run_batch(oracle_default, pcm, bits // 4, do_decode=True, threads=4, want_feats=True)
     ctx.reset()
     rng = np.random.default_rng(B)
     ids = rng.permutation(4000)[:B].astype(np.int32)
@@ -131,10 +136,28 @@ def test_vs_oracle_bit_exact(ctx, oracle_exact, B, bits):
         feat = ctx.extract(pcm[t], ids)
         assert np.array_equal(feat, r["feats"][t])
         idx = ctx.rvq_encode(feat, bits)
-        pk = oracle_exact.pack(idx, bits // 4)
+        pk = oracle_default.pack(idx, bits // 4)
         assert np.array_equal(pk, r["packets"][t])
         out = ctx.decode(pk, bits, ids)
         assert np.array_equal(out, r["pcm"][t]), f"PCM not bit-exact at step {t}"
+
+
+@pytest.mark.parametrize("mode", ["exact", "gemmlowp_double"])
+def test_builtin_modes_vs_oracle_bit_exact(ctx_builtin, oracle_exact, oracle_double, mode):
+    """The two TFLite-builtin flavours stay available on CPU and GPU (what the graphs compute without the delegate)."""
+    from oracle import lyra_oracle
+    o = oracle_exact if mode == "exact" else oracle_double
+    c = ctx_builtin[mode]
+    B, T, bits = 21, 6, 184
+    pcm = synth(B, T, seed=777)
+    pcm[3] //= 50
+    r = lyra_oracle.run_batch(o, pcm, bits // 4, do_decode=True, threads=4, want_feats=True)
+    c.reset()
+    ids = np.arange(B, dtype=np.int32)[::-1].copy()
+    for t in range(T):
+        pk = c.encode(pcm[t], bits, ids)
+        assert np.array_equal(pk, r["packets"][t])
+        assert np.array_equal(c.decode(pk, bits, ids), r["pcm"][t]), f"PCM not bit-exact at step {t}"
 
 
 def test_fused_equals_plugin_path(ctx):
@@ -196,7 +219,7 @@ def test_argument_validation(ctx):
     assert q.DecodeToLossyFeatures(bits).shape == (64,)
 
 
-def test_plugin_objects_reference_semantics(ctx, oracle_exact, golden_dir):
+def test_plugin_objects_reference_semantics(ctx, oracle_default, golden_dir):
     """soundstream_encoder_test.cc:51-57, lyra_gan_model_test.cc:60-76 behaviours."""
     import lyra_amd
     from oracle import lyra_oracle
@@ -205,7 +228,7 @@ def test_plugin_objects_reference_semantics(ctx, oracle_exact, golden_dir):
     feats = enc.Extract(np.zeros(320, np.int16))
     assert feats.shape == (64,)
     assert enc.Extract(np.zeros(321, np.int16)) is None
-    st = lyra_oracle.Stream(oracle_exact)
+    st = lyra_oracle.Stream(oracle_default)
     assert np.array_equal(feats, st.encode(np.zeros(320, np.int16)))
     gan = lyra_amd.LyraGanModel(ctx, 3)
     assert gan.GenerateSamples(1) is None          # no features yet
@@ -220,12 +243,12 @@ def test_plugin_objects_reference_semantics(ctx, oracle_exact, golden_dir):
     assert np.array_equal(np.concatenate([a, b]), want)
 
 
-def test_logmel(ctx, oracle_exact, golden_dir):
+def test_logmel(ctx, oracle_default, golden_dir):
     from oracle import lyra_oracle
     g = _g(golden_dir, "speech_sample1.npz")
     ctx.reset()
     B = 3
-    streams = [lyra_oracle.Stream(oracle_exact) for _ in range(B)]
+    streams = [lyra_oracle.Stream(oracle_default) for _ in range(B)]
     ids = np.array([9, 1, 77], np.int32)
     for t in range(12):
         pcm = np.stack([g["pcm_in"][(t + 5 * b) % 50] for b in range(B)])
@@ -241,14 +264,14 @@ def test_logmel(ctx, oracle_exact, golden_dir):
 # BASELINE.json sizes: size-independent properties
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,bits", [(1024, 64), (4096, 184), (8192, 120)])
-def test_full_size_properties(ctx, oracle_exact, B, bits):
+def test_full_size_properties(ctx, oracle_default, B, bits):
     from oracle import lyra_oracle
     T = 3
     base = synth(64, T, seed=B)
     # every stream b replays base stream b % 64: all replicas must agree bit for bit (stream independence,
     # no cross-stream leakage at full batch), and replica 0..63 must match the oracle.
     pcm = base[:, np.arange(B) % 64]
-    r = lyra_oracle.run_batch(oracle_exact, base, bits // 4, do_decode=True, threads=8)
+    r = lyra_oracle.run_batch(oracle_default, base, bits // 4, do_decode=True, threads=8)
     ctx.reset()
     for t in range(T):
         pk = ctx.encode(pcm[t], bits)
@@ -261,7 +284,7 @@ def test_full_size_properties(ctx, oracle_exact, B, bits):
         # embedded bit-stream: fewer bits = prefix (re-encode a copy of the first 64 streams on spare ids)
     # decode-only path (config #4): generate() from features == decode() from packets
     ctx.reset()
-    feats = ctx.rvq_decode(oracle_exact.unpack(r["packets"][0], bits // 4))
+    feats = ctx.rvq_decode(oracle_default.unpack(r["packets"][0], bits // 4))
     a = ctx.generate(feats, np.arange(64, dtype=np.int32))
     ctx.reset()
     b = ctx.decode(r["packets"][0], bits, np.arange(64, dtype=np.int32))
@@ -273,13 +296,13 @@ def test_full_size_properties(ctx, oracle_exact, B, bits):
 # encode and decode, encode of step i+1 overlapping decode of step i on the library's streams)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,bits", [(37, 184), (1000, 64), (4096, 184)])
-def test_device_pipeline_as_benchmarked(ctx, oracle_exact, B, bits):
+def test_device_pipeline_as_benchmarked(ctx, oracle_default, B, bits):
     import torch
     import lyra_amd
     from oracle import lyra_oracle
     T, R = 6, min(B, 48)
     base = synth(R, T, seed=4242 + B)
-    r = lyra_oracle.run_batch(oracle_exact, base, bits // 4, do_decode=True, threads=8)
+    r = lyra_oracle.run_batch(oracle_default, base, bits // 4, do_decode=True, threads=8)
     dev = torch.device("cuda", 0)
     pcm = torch.from_numpy(base[:, np.arange(B) % R].copy()).to(dev)
     ids = torch.arange(B, device=dev, dtype=torch.int32)

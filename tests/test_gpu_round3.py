@@ -22,7 +22,7 @@ def synth(B, T, seed):
     return rng.integers(-32768, 32768, size=(T, B, 320)).astype(np.int16)
 
 
-def test_config5_32768_streams_one_gpu(oracle_exact):
+def test_config5_32768_streams_one_gpu(oracle_default):
     """bench.py --config 5 at N = 1: one context of 32,768 streams (2.65 GB of state; every (size_t)id * stride),
     120 bits, 20 hops through encode_dev / decode_dev with steps overlapping: packets and PCM of the 64 base streams
     equal to the oracle, and every replica equal to its base stream, at every hop."""
@@ -32,9 +32,9 @@ def test_config5_32768_streams_one_gpu(oracle_exact):
     B, R, T, bits = 32768, 64, 20, 120
     base = synth(R, T, seed=55555)
     base[7:9] //= 50
-    ref = lyra_oracle.run_batch(oracle_exact, base, bits // 4, do_decode=True, threads=8)
+    ref = lyra_oracle.run_batch(oracle_default, base, bits // 4, do_decode=True, threads=8)
     dev = torch.device("cuda", 0)
-    ctx = lyra_amd.LyraHip(max_streams=B, requant="exact")
+    ctx = lyra_amd.LyraHip(max_streams=B, requant="xnnpack")
     try:
         ctx.torch_order = False
         # replicas scattered over the id space: stream id = a permutation, so base stream r lives at ids r, r+64, ...
@@ -63,7 +63,7 @@ def test_config5_32768_streams_one_gpu(oracle_exact):
 
 
 @pytest.mark.parametrize("entry", ["generate_dev", "decode_dev"])
-def test_config4_decode_only_8192_two_subbatches(oracle_exact, entry):
+def test_config4_decode_only_8192_two_subbatches(oracle_default, entry):
     """bench.py --config 4 as benchmarked: decode only, 8,192 streams, LYRA_HIP_SUBBATCHES = 2, 20 hops, no caller
     synchronisation inside pairs of steps.  Oracle: features -> Stream.decode (lyra_gan_model.cc:53-64) / packets ->
     decode."""
@@ -72,10 +72,10 @@ def test_config4_decode_only_8192_two_subbatches(oracle_exact, entry):
     from oracle import lyra_oracle
     B, R, T, bits = 8192, 64, 20, 120
     base = synth(R, T, seed=4444)
-    ref = lyra_oracle.run_batch(oracle_exact, base, bits // 4, do_decode=True, threads=8)
-    feats = np.stack([oracle_exact.rvq_decode(oracle_exact.unpack(ref["packets"][t], bits // 4)) for t in range(T)])
+    ref = lyra_oracle.run_batch(oracle_default, base, bits // 4, do_decode=True, threads=8)
+    feats = np.stack([oracle_default.rvq_decode(oracle_default.unpack(ref["packets"][t], bits // 4)) for t in range(T)])
     dev = torch.device("cuda", 0)
-    ctx = lyra_amd.LyraHip(max_streams=B, requant="exact", sub_batches=2)
+    ctx = lyra_amd.LyraHip(max_streams=B, requant="xnnpack", sub_batches=2)
     try:
         ctx.torch_order = False
         rep = np.arange(B) % R
@@ -200,7 +200,7 @@ def test_run_steps_equals_individual_calls(golden_dir, mode):
         Bc.close()
 
 
-def test_decode_sees_quantizer_behind_other_encode_side_call(oracle_exact):
+def test_decode_sees_quantizer_behind_other_encode_side_call(oracle_default):
     """include/lyra_hip.h "Streams" (1): a decode-side call is ordered after EVERY earlier encode-side call.
     encode_dev -> extract_dev (other streams; records a newer encode-side event while the quantizer of encode_dev is
     still running on its own stream) -> decode_dev on the packets.  No caller-side ordering at all."""
@@ -209,7 +209,7 @@ def test_decode_sees_quantizer_behind_other_encode_side_call(oracle_exact):
     from oracle import lyra_oracle
     B, R, T, bits = 4096, 32, 8, 184
     base = synth(R, T, seed=777)
-    ref = lyra_oracle.run_batch(oracle_exact, base, bits // 4, do_decode=True, threads=8)
+    ref = lyra_oracle.run_batch(oracle_default, base, bits // 4, do_decode=True, threads=8)
     dev = torch.device("cuda", 0)
     ctx = lyra_amd.LyraHip(max_streams=B + 64)
     try:

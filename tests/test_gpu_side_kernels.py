@@ -30,7 +30,7 @@ def _ctx(fused, requant):
             os.environ["LYRA_HIP_FUSED"] = old
 
 
-@pytest.mark.parametrize("requant", ["exact", "gemmlowp_double"])
+@pytest.mark.parametrize("requant", ["xnnpack", "exact", "gemmlowp_double"])
 @pytest.mark.parametrize("B,bits", [(37, 184), (1, 64), (4096, 120)])
 def test_side_kernels_equal_stage_kernels(requant, B, bits):
     T = 12 if B < 100 else 3

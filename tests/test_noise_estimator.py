@@ -20,9 +20,9 @@ def base_noise():
     return (rise * np.arange(160, dtype=np.float32) + SILENCE).astype(np.float32)
 
 
-def test_oracle_noise_identification(oracle_exact):
+def test_oracle_noise_identification(oracle_default):
     """noise_estimator_test.cc:175-199 with the peer's parameters (10 hops per update, half-lives 20 / 50 hops)."""
-    ne = lyra_oracle.NoiseEstimator(oracle_exact, 10, float(np.float32(0.5) ** np.float32(1 / 20)),
+    ne = lyra_oracle.NoiseEstimator(oracle_default, 10, float(np.float32(0.5) ** np.float32(1 / 20)),
                                     float(np.float32(0.5) ** np.float32(1 / 50)))
     rng = np.random.default_rng(0)
     base = base_noise()
@@ -34,8 +34,8 @@ def test_oracle_noise_identification(oracle_exact):
     assert not ne.ComputeIsNoise(periodic)
 
 
-def test_oracle_first_hop_and_silence(oracle_exact):
-    ne = lyra_oracle.NoiseEstimator(oracle_exact)
+def test_oracle_first_hop_and_silence(oracle_default):
+    ne = lyra_oracle.NoiseEstimator(oracle_default)
     assert np.all(ne.noise_estimate() == 0) and np.all(ne.noise_bound() == 0)
     is_noise, mel = ne.ReceiveSamples(np.zeros(320, np.int16))
     assert np.allclose(mel, SILENCE) and not is_noise           # |silence - 0| > bound 0: the estimate must update
@@ -56,7 +56,7 @@ def _speech_and_noise(golden_dir, hops=172):
 
 
 @pytest.mark.gpu
-def test_gpu_noise_estimator_matches_oracle(golden_dir, oracle_exact):
+def test_gpu_noise_estimator_matches_oracle(golden_dir, oracle_default):
     """Streams: speech, stationary noise, quiet speech, silence, speech after 60 hops of noise.  Decisions identical,
     noise estimate / bound within 1e-5 of the oracle at every hop, for the encoder-side and the decoder-side slot."""
     import lyra_amd
@@ -68,7 +68,7 @@ def test_gpu_noise_estimator_matches_oracle(golden_dir, oracle_exact):
     ids = np.array([3, 0, 41, 7, 12], np.int32)
     for side in ("encoder", "decoder"):
         ctx.reset()
-        refs = [lyra_oracle.NoiseEstimator(oracle_exact) for _ in range(5)]
+        refs = [lyra_oracle.NoiseEstimator(oracle_default) for _ in range(5)]
         for t in range(streams.shape[0]):
             got = ctx.noise_receive(streams[t], ids, side=side)
             want = [r.ReceiveSamples(streams[t, b])[0] for b, r in enumerate(refs)]
@@ -81,7 +81,7 @@ def test_gpu_noise_estimator_matches_oracle(golden_dir, oracle_exact):
 
 
 @pytest.mark.gpu
-def test_gpu_dtx_encode(golden_dir, oracle_exact):
+def test_gpu_dtx_encode(golden_dir, oracle_default):
     """LyraEncoder::Encode with enable_dtx (lyra_encoder.cc:131-156): noise hops give an EMPTY packet and do not run
     the feature extractor (its state stays put); other hops give exactly the packet a DTX-less encoder that only ever
     saw the non-noise hops would give."""
@@ -92,8 +92,8 @@ def test_gpu_dtx_encode(golden_dir, oracle_exact):
     B, bits = 3, 120
     ctx = lyra_amd.LyraHip(max_streams=64)
     ids = np.array([9, 2, 30], np.int32)
-    nes = [lyra_oracle.NoiseEstimator(oracle_exact) for _ in range(B)]
-    encs = [lyra_oracle.Stream(oracle_exact) for _ in range(B)]
+    nes = [lyra_oracle.NoiseEstimator(oracle_default) for _ in range(B)]
+    encs = [lyra_oracle.Stream(oracle_default) for _ in range(B)]
     n_empty = 0
     for t in range(streams.shape[0]):
         pk, nbytes = ctx.encode_dtx(streams[t], bits, ids)
@@ -104,7 +104,7 @@ def test_gpu_dtx_encode(golden_dir, oracle_exact):
                 n_empty += 1
             else:
                 feat = encs[b].encode(streams[t, b])
-                want = oracle_exact.pack(oracle_exact.rvq_encode(feat, bits // 4), bits // 4)[0]
+                want = oracle_default.pack(oracle_default.rvq_encode(feat, bits // 4), bits // 4)[0]
                 assert nbytes[b] == bits // 8 and np.array_equal(pk[b], want), (t, b)
     assert n_empty > 20      # the silence stream does go quiet; otherwise this test checks nothing
     ctx.close()

@@ -12,7 +12,7 @@ STAGES = {64: 16, 120: 30, 184: 46}
 
 @pytest.fixture(scope="module")
 def o():
-    return lyra_oracle.Oracle(mode="exact")
+    return lyra_oracle.Oracle(mode="xnnpack")
 
 
 @settings(max_examples=60, deadline=None)

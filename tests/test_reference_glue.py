@@ -18,12 +18,12 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 @pytest.fixture(scope="module")
-def ref(oracle_exact):
+def ref(oracle_default):
     from oracle import lyra_ref
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     if not lyra_ref.available():
         pytest.skip("oracle/_ref/liblyra_ref.so not built (needs /root/reference at build time)")
-    lyra_ref.load(oracle_exact)
+    lyra_ref.load(oracle_default)
     return lyra_ref
 
 
@@ -36,7 +36,7 @@ def _signals(golden_dir, T, hop_rate=16000):
 
 
 # ---- CPU: restatements vs the reference's classes -------------------------------------------------------------------
-def test_packet_layout_is_the_references(ref, oracle_exact):
+def test_packet_layout_is_the_references(ref, oracle_default):
     """oracle pack / unpack (what the GPU's nibble packing is checked against) == Packet<>::PackQuantized /
     UnpackPacket (packet.h:91-146) on the bit strings ResidualVectorQuantizer::Quantize produces."""
     rng = np.random.default_rng(0)
@@ -45,27 +45,27 @@ def test_packet_layout_is_the_references(ref, oracle_exact):
         idx = rng.integers(0, 16, size=(64, 46)).astype(np.int32)
         idx[0, :] = 15
         idx[1, :] = 0
-        pk = oracle_exact.pack(idx, ns)
+        pk = oracle_default.pack(idx, ns)
         for r in range(idx.shape[0]):
             s = ref.bits_string(idx[r], ns)
-            p = ref.pack(oracle_exact, s)
+            p = ref.pack(oracle_default, s)
             assert p.size == (bits + 7) // 8 and np.array_equal(p, pk[r]), (bits, r)
-            assert ref.unpack(oracle_exact, p) == s
-        assert np.array_equal(oracle_exact.unpack(pk, ns)[:, :ns], idx[:, :ns])
-    assert ref.unpack(oracle_exact, np.zeros(9, np.uint8)) is None       # not a packet size the codec knows
+            assert ref.unpack(oracle_default, p) == s
+        assert np.array_equal(oracle_default.unpack(pk, ns)[:, :ns], idx[:, :ns])
+    assert ref.unpack(oracle_default, np.zeros(9, np.uint8)) is None       # not a packet size the codec knows
 
 
-def test_sample_conversions_are_the_references(ref, oracle_exact):
+def test_sample_conversions_are_the_references(ref, oracle_default):
     """Row a7: the oracle's int16 <-> unit-float conversions (fused into enc_s0's prologue and dec_s2's epilogue on the
     GPU, where PCM equality with the oracle covers them) against dsp_utils.h compiled from the reference: every int16
     value; 2^22 floats across (-1.5, 1.5) incl. every clipping edge, +-inf and values far out of range; the
     log-spectral distance the integration test thresholds (dsp_utils.cc:27-41)."""
     import ctypes as C
-    L = oracle_exact.L
+    L = oracle_default.L
     allv = np.arange(-32768, 32768, dtype=np.int32).astype(np.int16)
     mine = np.empty(allv.size, np.float32)
     L.lo_int16_to_unit(allv.ctypes.data_as(C.c_void_p), allv.size, mine.ctypes.data_as(C.c_void_p))
-    assert np.array_equal(mine, ref.int16_to_unit(oracle_exact, allv))
+    assert np.array_equal(mine, ref.int16_to_unit(oracle_default, allv))
     rng = np.random.default_rng(7)
     x = np.concatenate([rng.uniform(-1.5, 1.5, 1 << 22).astype(np.float32),
                         (np.arange(-40000, 40000, dtype=np.float32) + np.float32(0.5)) / np.float32(32768.0),
@@ -73,13 +73,13 @@ def test_sample_conversions_are_the_references(ref, oracle_exact):
                         np.array([np.inf, -np.inf, 1e30, -1e30, 0.0, -0.0, 32767.0 / 32768.0, 0.99999994, -1.0, 1.0], np.float32)])
     got = np.empty(x.size, np.int16)
     L.lo_unit_to_int16(x.ctypes.data_as(C.c_void_p), x.size, got.ctypes.data_as(C.c_void_p))
-    assert np.array_equal(got, ref.unit_to_int16(oracle_exact, x))
+    assert np.array_equal(got, ref.unit_to_int16(oracle_default, x))
     a, b = rng.normal(0, 1, 160).astype(np.float32), rng.normal(0, 1, 160).astype(np.float32)
     want = np.float32(10) * np.sqrt(np.float32(((a - b) ** 2).astype(np.float32).sum(dtype=np.float32)) / np.float32(160))
-    assert abs(ref.log_spectral_distance(oracle_exact, a, b) - float(want)) < 1e-4
+    assert abs(ref.log_spectral_distance(oracle_default, a, b) - float(want)) < 1e-4
 
 
-def test_noise_estimator_restatement_vs_reference_class(ref, oracle_exact, golden_dir):
+def test_noise_estimator_restatement_vs_reference_class(ref, oracle_default, golden_dir):
     """oracle NoiseEstimator (lyra_oracle.c, what noise_update_kernel is checked against) vs
     chromemedia::codec::NoiseEstimator compiled from noise_estimator.cc: is_noise identical at every hop.  Estimate and
     bound agree to 2e-3: the class calls std::exp(float) (glibc expf here, not correctly rounded in ~0.2 % of calls and
@@ -91,7 +91,7 @@ def test_noise_estimator_restatement_vs_reference_class(ref, oracle_exact, golde
     mixed = np.concatenate([noise[:60], speech[:112]])
     worst = 0.0
     for name, sig in (("speech", speech), ("noise", noise), ("quiet", quiet), ("silence", silence), ("mixed", mixed)):
-        a, b = ref.NoiseEstimator(oracle_exact), lyra_oracle.NoiseEstimator(oracle_exact)
+        a, b = ref.NoiseEstimator(oracle_default), lyra_oracle.NoiseEstimator(oracle_default)
         flips = 0
         for t in range(sig.shape[0]):
             ra = a.ReceiveSamples(sig[t])
@@ -129,7 +129,7 @@ def _session(golden_dir, rate, bitrate, T=40, n=4):
 
 
 @pytest.mark.parametrize("rate,bitrate,dtx", SESSIONS)
-def test_codec_model_vs_reference_classes(ref, oracle_exact, golden_dir, rate, bitrate, dtx):
+def test_codec_model_vs_reference_classes(ref, oracle_default, golden_dir, rate, bitrate, dtx):
     """oracle/lyra_codec_model.py (Python restatement) vs the reference's LyraEncoder / LyraDecoder over the same
     oracle components: packets and is_comfort_noise() EXACTLY equal, every DecodeSamples(n) result equal through loss
     bursts, concealment, comfort noise, both fades, DTX and all sample rates -- exactly in four of the five sessions, and
@@ -142,10 +142,10 @@ def test_codec_model_vs_reference_classes(ref, oracle_exact, golden_dir, rate, b
     bits = BITS[bitrate]
     pcm, script = _session(golden_dir, rate, bitrate)
     n = pcm.shape[1]
-    renc = [ref.LyraEncoder(oracle_exact, rate, bits, dtx) for _ in range(n)]
-    rdec = [ref.LyraDecoder(oracle_exact, rate, 0x4C797261 ^ s) for s in range(n)]
-    menc = [M.RefLyraEncoder(oracle_exact, rate, bits, dtx) for _ in range(n)]
-    mdec = [M.RefLyraDecoder(oracle_exact, rate, cng_seed=0x4C797261 ^ s) for s in range(n)]
+    renc = [ref.LyraEncoder(oracle_default, rate, bits, dtx) for _ in range(n)]
+    rdec = [ref.LyraDecoder(oracle_default, rate, 0x4C797261 ^ s) for s in range(n)]
+    menc = [M.RefLyraEncoder(oracle_default, rate, bits, dtx) for _ in range(n)]
+    mdec = [M.RefLyraDecoder(oracle_default, rate, cng_seed=0x4C797261 ^ s) for s in range(n)]
     saw_cng = saw_empty = False
     n_diff = n_total = 0
     for t, (mask, sizes) in enumerate(script):
@@ -169,9 +169,9 @@ def test_codec_model_vs_reference_classes(ref, oracle_exact, golden_dir, rate, b
     assert n_diff <= 1e-3 * n_total, (n_diff, n_total)
 
 
-def test_reference_decoder_accepts_any_request_size(ref, oracle_exact):
+def test_reference_decoder_accepts_any_request_size(ref, oracle_default):
     """lyra_decoder_test.cc behaviours on the compiled class: DecodeSamples(0), requests beyond a hop, nothing received."""
-    d = ref.LyraDecoder(oracle_exact, 48000, 7)
+    d = ref.LyraDecoder(oracle_default, 48000, 7)
     assert d.DecodeSamples(0).size == 0
     assert d.DecodeSamples(5000).size == 5000           # pure concealment, many hops in one request
     assert not d.SetEncodedPacket(np.zeros(9, np.uint8))  # unsupported packet size
@@ -190,7 +190,7 @@ def _read_wav(path):
         return np.frombuffer(w.readframes(w.getnframes()), np.int16), w.getframerate()
 
 
-def test_reference_file_codec_vs_model(ref, oracle_exact, golden_dir, tmp_path):
+def test_reference_file_codec_vs_model(ref, oracle_default, golden_dir, tmp_path):
     """The reference's EncodeFile / DecodeFile (cli_example/*_main_lib.cc, compiled from the reference tree; LyraEncoder /
     LyraDecoder created through their public Create) against the per-stream model: .lyra bytes, decoded samples, the
     trailing partial hop dropped, a fixed packet-loss pattern (FixedPacketLossModel), random request sizes."""
@@ -199,15 +199,15 @@ def test_reference_file_codec_vs_model(ref, oracle_exact, golden_dir, tmp_path):
     speech = np.load(os.path.join(golden_dir, "sample_wavs.npz"))["sample1_16kHz"]
     pcm = speech[:320 * 60 + 123]
     _write_wav(tmp_path / "in.wav", pcm)
-    assert ref.encode_file(oracle_exact, tmp_path / "in.wav", tmp_path / "a.lyra", 6000, model_dir)
+    assert ref.encode_file(oracle_default, tmp_path / "in.wav", tmp_path / "a.lyra", 6000, model_dir)
     got = np.fromfile(tmp_path / "a.lyra", np.uint8)
-    enc = M.RefLyraEncoder(oracle_exact, 16000, 120, False)
+    enc = M.RefLyraEncoder(oracle_default, 16000, 120, False)
     want = np.concatenate([enc.Encode(pcm[h * 320:(h + 1) * 320]) for h in range(60)])
     assert np.array_equal(got, want)
     # no loss, whole hops
-    assert ref.decode_file(oracle_exact, tmp_path / "a.lyra", tmp_path / "a.wav", 16000, 6000, model_dir, cng_seed=5)
+    assert ref.decode_file(oracle_default, tmp_path / "a.lyra", tmp_path / "a.wav", 16000, 6000, model_dir, cng_seed=5)
     out, rate = _read_wav(tmp_path / "a.wav")
-    dec = M.RefLyraDecoder(oracle_exact, 16000, cng_seed=5)
+    dec = M.RefLyraDecoder(oracle_default, 16000, cng_seed=5)
     ref_out = []
     for h in range(60):
         dec.SetEncodedPacket(want[h * 15:(h + 1) * 15])
@@ -215,10 +215,10 @@ def test_reference_file_codec_vs_model(ref, oracle_exact, golden_dir, tmp_path):
     assert rate == 16000 and np.array_equal(out, np.concatenate(ref_out))
     # packets lost from 0.25 s for 0.25 s = hops [13, 25) (fixed_packet_loss_model.cc:33-40 rounds both ends up):
     # concealment, fade, comfort noise, fade back; 48 kHz output
-    assert ref.decode_file(oracle_exact, tmp_path / "a.lyra", tmp_path / "b.wav", 48000, 6000, model_dir, cng_seed=5,
+    assert ref.decode_file(oracle_default, tmp_path / "a.lyra", tmp_path / "b.wav", 48000, 6000, model_dir, cng_seed=5,
                            loss_starts=[0.25], loss_durations=[0.25])
     out, rate = _read_wav(tmp_path / "b.wav")
-    dec = M.RefLyraDecoder(oracle_exact, 48000, cng_seed=5)
+    dec = M.RefLyraDecoder(oracle_default, 48000, cng_seed=5)
     ref_out, lost = [], 0
     for h in range(60):
         if 13 <= h < 25:
@@ -232,14 +232,14 @@ def test_reference_file_codec_vs_model(ref, oracle_exact, golden_dir, tmp_path):
     assert d.max() <= 1 and (d > 0).mean() < 1e-3      # 1 LSB where comfort noise is mixed in (expf, see above)
     # a file without a single full hop: nothing to encode, and DecodeFile refuses an empty stream (decoder_main_lib.cc:186)
     _write_wav(tmp_path / "tiny.wav", pcm[:100])
-    assert ref.encode_file(oracle_exact, tmp_path / "tiny.wav", tmp_path / "tiny.lyra", 6000, model_dir)
+    assert ref.encode_file(oracle_default, tmp_path / "tiny.wav", tmp_path / "tiny.lyra", 6000, model_dir)
     assert os.path.getsize(tmp_path / "tiny.lyra") == 0
-    assert not ref.decode_file(oracle_exact, tmp_path / "tiny.lyra", tmp_path / "tiny_out.wav", 16000, 6000, model_dir)
+    assert not ref.decode_file(oracle_default, tmp_path / "tiny.lyra", tmp_path / "tiny_out.wav", 16000, 6000, model_dir)
 
 
 # ---- GPU: the product vs the reference's classes -------------------------------------------------------------------
 @pytest.mark.gpu
-def test_gpu_packets_vs_reference_encoder(ref, oracle_exact, golden_dir):
+def test_gpu_packets_vs_reference_encoder(ref, oracle_default, golden_dir):
     """lyra_hip_encode (extractor + quantizer + nibble packing on the device) vs the reference's LyraEncoder::Encode:
     every packet byte-identical, 3 bit rates, 16 streams x 40 hops of speech / noise / quiet speech / silence."""
     import lyra_amd
@@ -251,7 +251,7 @@ def test_gpu_packets_vs_reference_encoder(ref, oracle_exact, golden_dir):
     try:
         for bits in (64, 120, 184):
             ctx.reset()
-            encs = [ref.LyraEncoder(oracle_exact, 16000, bits, False) for _ in range(B)]
+            encs = [ref.LyraEncoder(oracle_default, 16000, bits, False) for _ in range(B)]
             for t in range(pcm.shape[0]):
                 got = ctx.encode(pcm[t], bits)
                 for b in range(B):
@@ -261,7 +261,7 @@ def test_gpu_packets_vs_reference_encoder(ref, oracle_exact, golden_dir):
 
 
 @pytest.mark.gpu
-def test_gpu_noise_estimator_vs_reference_class(ref, oracle_exact, golden_dir):
+def test_gpu_noise_estimator_vs_reference_class(ref, oracle_default, golden_dir):
     """noise_update_kernel (behind the device log-mel) vs chromemedia::codec::NoiseEstimator: is_noise identical at every
     hop on speech / noise / quiet speech / silence / noise-then-speech, encoder-side and decoder-side slot; estimates
     within 2e-3 (std::exp(float) of the host libm vs exp evaluated in double, see the CPU test above)."""
@@ -274,7 +274,7 @@ def test_gpu_noise_estimator_vs_reference_class(ref, oracle_exact, golden_dir):
     try:
         for side in ("encoder", "decoder"):
             ctx.reset()
-            refs = [ref.NoiseEstimator(oracle_exact) for _ in range(5)]
+            refs = [ref.NoiseEstimator(oracle_default) for _ in range(5)]
             for t in range(streams.shape[0]):
                 got = ctx.noise_receive(streams[t], ids, side=side)
                 want = [r.ReceiveSamples(streams[t, b]) for b, r in enumerate(refs)]
@@ -289,7 +289,7 @@ def test_gpu_noise_estimator_vs_reference_class(ref, oracle_exact, golden_dir):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rate,bitrate,dtx", SESSIONS)
-def test_gpu_batch_twins_vs_reference_classes(ref, oracle_exact, golden_dir, tmp_path, rate, bitrate, dtx):
+def test_gpu_batch_twins_vs_reference_classes(ref, oracle_default, golden_dir, tmp_path, rate, bitrate, dtx):
     """BatchLyraEncoder / BatchLyraDecoder (lyra_amd/host/lyra_batch_codec.cc over the device) vs the reference's
     LyraEncoder / LyraDecoder, one pair per stream: packets exact; PCM exact wherever only the generative model speaks,
     within 2 LSB where device comfort noise (fp64 sin / cos / exp) is mixed in."""
@@ -297,9 +297,9 @@ def test_gpu_batch_twins_vs_reference_classes(ref, oracle_exact, golden_dir, tmp
     bits = BITS[bitrate]
     pcm, script = _session(golden_dir, rate, bitrate)
     n = pcm.shape[1]
-    packets, lengths, out = _run_session(tmp_path, oracle_exact, rate, bitrate, dtx, pcm, script)
-    encs = [ref.LyraEncoder(oracle_exact, rate, bits, dtx) for _ in range(n)]
-    decs = [ref.LyraDecoder(oracle_exact, rate, 0x4C797261 ^ s) for s in range(n)]
+    packets, lengths, out = _run_session(tmp_path, oracle_default, rate, bitrate, dtx, pcm, script)
+    encs = [ref.LyraEncoder(oracle_default, rate, bits, dtx) for _ in range(n)]
+    decs = [ref.LyraDecoder(oracle_default, rate, 0x4C797261 ^ s) for s in range(n)]
     pos = n_exact = n_total = worst = 0
     saw_cng = False
     for t, (mask, sizes) in enumerate(script):
@@ -323,7 +323,7 @@ def test_gpu_batch_twins_vs_reference_classes(ref, oracle_exact, golden_dir, tmp
 
 
 @pytest.mark.gpu
-def test_gpu_file_transcode_vs_reference_file_codec(ref, oracle_exact, golden_dir, tmp_path):
+def test_gpu_file_transcode_vs_reference_file_codec(ref, oracle_default, golden_dir, tmp_path):
     """EncodeFiles / DecodeFiles (lyra_amd/host/lyra_file_codec.cc: several WAV files of different lengths transcoded
     together on the device) against the reference's EncodeFile / DecodeFile run file by file: identical .lyra bytes,
     identical decoded samples."""
@@ -344,10 +344,10 @@ def test_gpu_file_transcode_vs_reference_file_codec(ref, oracle_exact, golden_di
                        timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     for name in files:
-        assert ref.encode_file(oracle_exact, tmp_path / f"{name}.wav", tmp_path / f"{name}.ref.lyra", 9200, model_dir)
+        assert ref.encode_file(oracle_default, tmp_path / f"{name}.wav", tmp_path / f"{name}.ref.lyra", 9200, model_dir)
         assert np.array_equal(np.fromfile(out_dir / f"{name}.lyra", np.uint8),
                               np.fromfile(tmp_path / f"{name}.ref.lyra", np.uint8)), name
-        assert ref.decode_file(oracle_exact, out_dir / f"{name}.lyra", tmp_path / f"{name}.ref.wav", 16000, 9200, model_dir)
+        assert ref.decode_file(oracle_default, out_dir / f"{name}.lyra", tmp_path / f"{name}.ref.wav", 16000, 9200, model_dir)
         got, _ = _read_wav(out_dir / f"{name}_decoded.wav")
         want, _ = _read_wav(tmp_path / f"{name}.ref.wav")
         assert np.array_equal(got, want), name
@@ -355,7 +355,7 @@ def test_gpu_file_transcode_vs_reference_file_codec(ref, oracle_exact, golden_di
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rate", [48000, 8000, 16000])
-def test_gpu_batch_decoder_large_requests_vs_reference_class(ref, oracle_exact, golden_dir, tmp_path, rate):
+def test_gpu_batch_decoder_large_requests_vs_reference_class(ref, oracle_default, golden_dir, tmp_path, rate):
     """DecodeSamples with requests far beyond one hop (the reference's BufferedResampler / LyraDecoder accept any
     num_samples): several hops per request -- so most of what is played is concealment and comfort noise -- including
     requests of more than 960 internal samples, which the device resampler serves in chunks (lyra_hip_twin_fetch)."""
@@ -367,9 +367,9 @@ def test_gpu_batch_decoder_large_requests_vs_reference_class(ref, oracle_exact, 
     if rate == 8000:
         big = [2 * k for k in big]                                          # keep the 16 -> 8 kHz decimation whole
     script = [("1111", [big[t % len(big)]]) for t in range(pcm.shape[0])]
-    packets, lengths, out = _run_session(tmp_path, oracle_exact, rate, bitrate, False, pcm, script)
-    encs = [ref.LyraEncoder(oracle_exact, rate, bits, False) for _ in range(n)]
-    decs = [ref.LyraDecoder(oracle_exact, rate, 0x4C797261 ^ s) for s in range(n)]
+    packets, lengths, out = _run_session(tmp_path, oracle_default, rate, bitrate, False, pcm, script)
+    encs = [ref.LyraEncoder(oracle_default, rate, bits, False) for _ in range(n)]
+    decs = [ref.LyraDecoder(oracle_default, rate, 0x4C797261 ^ s) for s in range(n)]
     pos = worst = n_diff = n_total = 0
     for t, (mask, sizes) in enumerate(script):
         for s in range(n):
@@ -389,7 +389,7 @@ def test_gpu_batch_decoder_large_requests_vs_reference_class(ref, oracle_exact, 
 
 
 @pytest.mark.gpu
-def test_gpu_batch_twins_many_streams_random_loss_vs_reference_classes(ref, oracle_exact, golden_dir, tmp_path):
+def test_gpu_batch_twins_many_streams_random_loss_vs_reference_classes(ref, oracle_default, golden_dir, tmp_path):
     """192 streams, 24 ticks, every stream losing its packets independently (18 %, in bursts), odd request sizes: the
     rounds of BatchLyraDecoder's loop now hold large mixed groups (received / concealing / comfort noise / fading, hops
     starting and ending in different rounds) -- against 192 pairs of the reference's LyraEncoder / LyraDecoder."""
@@ -414,9 +414,9 @@ def test_gpu_batch_twins_many_streams_random_loss_vs_reference_classes(ref, orac
         mask = "".join("0" if lost[t, s] else "1" for s in range(n))
         sizes = [hop] if t % 3 == 0 else ([97, hop - 97] if t % 3 == 1 else [1, 160, 159])
         script.append((mask, sizes))
-    packets, lengths, out = _run_session(tmp_path, oracle_exact, rate, bitrate, False, pcm, script)
-    encs = [ref.LyraEncoder(oracle_exact, rate, bits, False) for _ in range(n)]
-    decs = [ref.LyraDecoder(oracle_exact, rate, 0x4C797261 ^ s) for s in range(n)]
+    packets, lengths, out = _run_session(tmp_path, oracle_default, rate, bitrate, False, pcm, script)
+    encs = [ref.LyraEncoder(oracle_default, rate, bits, False) for _ in range(n)]
+    decs = [ref.LyraDecoder(oracle_default, rate, 0x4C797261 ^ s) for s in range(n)]
     pos = worst = n_diff = n_total = 0
     saw_cng = 0
     for t, (mask, sizes) in enumerate(script):
