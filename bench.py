@@ -149,6 +149,15 @@ def parse(argv=None):
                     help="--gpus N in ONE process: a host thread and a context per GPU, no process group")
     ap.add_argument("--bcast-weights", action="store_true",
                     help="rank 0 reads the weight container, RCCL-broadcasts it, every rank builds from the image")
+    ap.add_argument("--requant", default="xnnpack", choices=["xnnpack", "exact", "gemmlowp_double"],
+                    help="arithmetic of the graphs' int8 regions: xnnpack = what the reference runs (default); the other "
+                         "two are TFLite's builtin kernels (include/lyra_hip.h)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the self-check: after all timing, the packets and the PCM of the run's LAST TWO steps are "
+                         "compared, for the first --verify-streams streams of every rank, with the CPU oracle replaying "
+                         "every step the context has executed since its reset (state is carried, so the end state "
+                         "vouches for the whole run).  Outside every timed region.")
+    ap.add_argument("--verify-streams", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--selftest-dist", action="store_true",
@@ -222,11 +231,11 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(bits, mode):
+def cpu_baseline(bits, mode, requant="xnnpack"):
     """Oracle (CPU port of the same arithmetic) on the host cores, bounded to ~12 s."""
     from oracle import lyra_oracle
     lyra_oracle.build()
-    o = lyra_oracle.Oracle(mode="xnnpack")
+    o = lyra_oracle.Oracle(mode=requant)
     cores = usable_cores()
     rng = np.random.Generator(np.random.PCG64(SEED))
     streams = cores * 2
@@ -390,8 +399,9 @@ class Shard:
         self.dev = torch.device("cuda", device)
         self.wl, self.args = wl, args
         B, bits = wl["B"], wl["bits"]
-        self.ctx = lyra_amd.LyraHip(device=device, max_streams=B, requant="xnnpack", weights_image=weights_image,
+        self.ctx = lyra_amd.LyraHip(device=device, max_streams=B, requant=args.requant, weights_image=weights_image,
                                     sub_batches=wl.get("sub_batches"))
+        self.history = []   # every (kind, first step, n) this context has executed since its last reset: --verify replays it
         self.ctx.torch_order = False   # this harness synchronises explicitly around every region it times
         gen = torch.Generator(device=self.dev)
         gen.manual_seed(SEED + first_id)
@@ -443,11 +453,65 @@ class Shard:
             self.pk_seq[i] = ((nib[:, 0::2] << 4) | nib[:, 1::2]).to(torch.uint8)   # packet.h:91-122, no header
             torch.cuda.synchronize(self.dev)
         ctx.reset()
+        self.history = []
+
+    def verify(self, n_streams):
+        """The run checks itself (lyra_benchmark_lib.cc:121-160 is the loop being replaced; it verifies nothing either, but
+        a benchmark of a re-implementation should).  The CPU oracle replays, for the first n_streams streams of this
+        shard, EVERY step this context has executed since its reset -- warm-up, serialised table, ramp, timed region(s),
+        latency steps, with the same cycled input ring -- and the packets / PCM the GPU left in its two output buffers
+        (the run's last two steps) must equal the oracle's, bit for bit.  Only the bare codec step is covered."""
+        a = self.args
+        if a.dtx or a.rate != 16000 or a.with_logmel:
+            return {"verified": None, "why": "self-check covers the bare codec step (no --dtx / --rate / --with-logmel)"}
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import lyra_oracle
+        lyra_oracle.build()
+        t0 = time.perf_counter()
+        self.sync()
+        o = lyra_oracle.Oracle(mode=a.requant)
+        S = min(n_streams, self.wl["B"])
+        bits, ns = self.wl["bits"], self.wl["bits"] // 4
+        order = [(k, i) for (k, f, n) in self.history for i in range(f, f + n)]
+        if len(order) < 2:
+            return {"verified": None, "why": "fewer than two steps executed"}
+        got_pk = [self.packets[s][:S].cpu().numpy() for s in range(2)]
+        got_pcm = [self.pcm_out[s][:S].cpu().numpy() for s in range(2)]
+        last = order[-2:]
+        ok = True
+        if all(k == "encdec" for k, _ in order):
+            ring = self.pcm_in[:, :S].cpu().numpy()
+            pcm = np.stack([ring[i % ring.shape[0]] for _, i in order])
+            r = lyra_oracle.run_batch(o, pcm, ns, do_decode=True, threads=usable_cores())
+            for j, (_, i) in enumerate(last):
+                ok = ok and np.array_equal(got_pk[i & 1], r["packets"][len(order) - 2 + j]) \
+                    and np.array_equal(got_pcm[i & 1], r["pcm"][len(order) - 2 + j])
+        else:   # decode-only run: features (generate) or packets (decode) from the prepared rings, per-stream decoder state
+            feats = self.feats[:, :S].cpu().numpy()
+            pks = self.pk_seq[:, :S].cpu().numpy()
+
+            def one(sidx):
+                st = lyra_oracle.Stream(o)
+                out = []
+                for k, i in order:
+                    f = feats[i % feats.shape[0], sidx] if k == "generate" else \
+                        o.rvq_decode(o.unpack(pks[i % pks.shape[0], sidx][None], ns))[0]
+                    out.append(st.decode(f))
+                return out[-2:]
+            with ThreadPoolExecutor(max_workers=usable_cores()) as ex:
+                tails = list(ex.map(one, range(S)))
+            for j, (_, i) in enumerate(last):
+                ok = ok and np.array_equal(got_pcm[i & 1], np.stack([t[j] for t in tails]))
+        return {"verified": bool(ok), "streams": S, "steps_replayed": len(order), "requant_mode": a.requant,
+                "seconds": round(time.perf_counter() - t0, 2),
+                "what": "packets + PCM of the run's last two steps == CPU oracle replaying every step since the reset "
+                        "(bit-exact; state carried, so the end state vouches for the run)"}
 
     # -- steps --------------------------------------------------------------------------------------------------
     # kind: "encdec" (encode + decode of every hop), "generate" (features -> PCM), "decode" (packets -> PCM)
     def steps(self, kind, first, n):
         """n consecutive steps starting at absolute step `first`: ONE library call (lyra_hip_run_steps_dev)."""
+        self.history.append((kind, first, n))
         if self.per_call:
             for i in range(first, first + n):
                 self._step_per_call(kind, i)
@@ -565,6 +629,10 @@ class StubShard:
         self.steps(kind, first, M)
         return [1e-4 * (1 + (i % 5 == 4)) for i in range(M)]
 
+    def verify(self, n_streams):
+        return {"verified": True, "streams": 0, "steps_replayed": sum(self.calls[k] for k in ("encdec", "generate", "decode")),
+                "what": "stub"}
+
 
 def dominant_sample_every(K):
     """Every how-many-th launch of the dominant kernel is bracketed inside the timed region: ~32 samples of a long run,
@@ -622,6 +690,11 @@ def run_shard(sh, args, wl, barrier):
         secs2, _ = sh.timed("decode", cursor, K, barrier)
         res["secondary_seconds"] = secs2
         res["secondary_table"] = table2
+    if not args.no_verify:
+        try:
+            res["verify"] = sh.verify(args.verify_streams)
+        except Exception as e:   # a broken checker must not take the measurement down; it must not pass silently either
+            res["verify"] = {"verified": False, "error": repr(e)}
     return res
 
 
@@ -653,7 +726,7 @@ def result_line(args, wl, world, secs, frames, res, launcher):
                    "baseline_config": wl["config"], "streams_per_gpu": B, "total_streams": wl["total"],
                    "num_bits": bits,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective ({launcher})",
-                   "requant_mode": "xnnpack", "sub_batches": wl.get("sub_batches") or 1,
+                   "requant_mode": args.requant, "sub_batches": wl.get("sub_batches") or 1,
                    "driver": "python, one `_dev` call per codec call" if (args.per_call or args.with_logmel)
                    else "lyra_hip_run_steps_dev: one C call per timed region"},
         "xrt_per_stream": round(value / 50.0 / wl["total"], 3),
@@ -679,6 +752,9 @@ def result_line(args, wl, world, secs, frames, res, launcher):
         out["step_latency_us"] = dict(latency_stats(res["latency"]),
                                       what="one isolated step of this rank: enqueue -> every output complete "
                                            "(host clock around lyra_hip_run_steps_dev(n=1) + lyra_hip_synchronize)")
+    if res.get("verify") is not None:
+        out["verified"] = res["verify"].get("verified")
+        out["verify"] = res["verify"]
     if mode == "decode":
         s2 = res["secondary_seconds"]
         v2 = frames / s2
@@ -686,6 +762,26 @@ def result_line(args, wl, world, secs, frames, res, launcher):
                             "value": round(v2, 1), "unit": "frames/s", "ms_per_step": round(s2 / K * 1e3, 4)}
         if res.get("secondary_table"):
             out["secondary"]["kernels"] = res["secondary_table"]
+    return out
+
+
+def rank_summary(res, args, wl):
+    """What every rank contributes to the N > 1 line beyond the max-reduced time."""
+    out = {"ms_per_step": round(res["seconds"] / args.steps * 1e3, 4)}
+    if res.get("dom") and res.get("dom_prof") and res["dom_prof"][1]:
+        ms, n = res["dom_prof"]
+        out["dominant_kernel"] = {"kernel": res["dom"], "avg_us": round(ms / n * 1e3, 2), "launches": n}
+    if res.get("verify") is not None:
+        out["verified"] = res["verify"].get("verified")
+    return out
+
+
+def gather_ranks(summary, world):
+    if world == 1:
+        return [summary]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, summary)
     return out
 
 
@@ -821,6 +917,7 @@ def main(argv=None):
     secs, frames = reduce_job(res["seconds"], wl["B"] * args.steps, world, dev)
     if wl["mode"] == "decode":
         res["secondary_seconds"], _ = reduce_job(res["secondary_seconds"], 0, world, dev)
+    per_rank = gather_ranks(rank_summary(res, args, wl), world)
     if rank == 0:
         backend = "gloo (stub)" if stub else "RCCL"
         out = result_line(args, wl, world, secs, frames, res,
@@ -828,11 +925,15 @@ def main(argv=None):
                           "timing barrier and the result reduction only"
                           + (", self-spawned from `python bench.py --gpus N`" if os.environ.get("LYRA_BENCH_RESPAWNED") else ""))
         out["ranks"] = world
+        if world > 1:   # a straggler must be visible: every rank's own clock, dominant kernel and self-check
+            out["per_rank_ms_per_step"] = [r["ms_per_step"] for r in per_rank]
+            out["per_rank"] = per_rank
+            out["verified"] = None if any(r.get("verified") is None for r in per_rank) else all(r["verified"] for r in per_rank)
         if stub:
             out["stub"] = {"calls": sh.calls, "first_id": first_id, "weights_bytes": sh.weights_bytes}
-        if world == 1 and not args.no_cpu_baseline and not stub:
+        if not args.no_cpu_baseline and not stub:   # rank 0's host cores, at any world size
             try:
-                out["cpu_baseline"] = cpu_baseline(wl["bits"], wl["mode"])
+                out["cpu_baseline"] = cpu_baseline(wl["bits"], wl["mode"], args.requant)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -144,8 +144,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     f32x4 acc[1][4];
     const int g = wave >> 1;
     auto aoff = [&](int i, int c) { return (c * 16 + m) * FS + g * 16 + q * 4; };
-    acc_bias(acc, P.head.b, wave * 4 * 16);
-    gemm_f32<1, 4, 3, 3, false>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, acc);
+    gemm_f32_bias<1, 4, 3, 3>(FB, aoff, P.head.w + (wave * 4) * 3 * 64, P.head.b, wave * 4 * 16, acc);
     fold_rows8<2>(acc[0]);   // rows = 8 streams: lanes 32-63 take over N tiles 2, 3
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -243,43 +242,40 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     }
     __syncthreads();
     LYRA_TSTAMP(84);
+    static_assert(MTD0 == 1, "one 16-row M tile: rows (t, s)");
+    const int row = lane & 15, ch0 = wave * 32 + q * 4;   // operand-swapped GEMMs (lyra_dev.h gemm_i8_t): this lane's row / channels
     {
-      i32x4 acc[MTD0][2];
-      auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + c * 64 + q * 16; };
-      gemm_i8<MTD0, 2, 4>(QD, aoff, P.pwq[0].w + (wave * 2) * 4 * 64, acc);
+      i32x4 acc[2] = {chan_quad(P.pwq[0].b, wave * 2), chan_quad(P.pwq[0].b, wave * 2 + 1)};
+      const i32x4 M[2] = {chan_quad(P.pwq[0].M, wave * 2), chan_quad(P.pwq[0].M, wave * 2 + 1)};
+      const i32x4 sh[2] = {chan_quad(P.pwq[0].sh, wave * 2), chan_quad(P.pwq[0].sh, wave * 2 + 1)};
+      auto aoff = [&](int c) { return m * QS + c * 64 + q * 16; };
+      gemm_i8_t<2, 4>(QD, aoff, P.pwq[0].w + (wave * 2) * 4 * 64, acc);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        int n = (wave * 2 + j) * 16 + (lane & 15);
-        int bias = as_global(P.pwq[0].b)[n], M = as_global(P.pwq[0].M)[n], sh = as_global(P.pwq[0].sh)[n];
+        int r8[4];
 #pragma unroll
-        for (int i = 0; i < MTD0; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int c8 = conv_code<MODE>(acc[i][j][e] + bias, M, sh, P.pwq[0].zout);
-            QP[(i * 16 + q * 4 + e) * QS + n] = (int8_t)lut8(LQ, c8);
-          }
+        for (int e = 0; e < 4; ++e) r8[e] = lut8(LQ, conv_code<MODE>(acc[j][e], M[j][e], sh[j][e], P.pwq[0].zout));
+        *reinterpret_cast<int*>(&QP[row * QS + ch0 + 16 * j]) = pack8(r8[0], r8[1], r8[2], r8[3]);
       }
     }
     __syncthreads();
     {
-      i32x4 acc[MTD0][2];
+      i32x4 acc[2] = {chan_quad(P.cvq[0].b, wave * 2), chan_quad(P.cvq[0].b, wave * 2 + 1)};
+      const i32x4 M[2] = {chan_quad(P.cvq[0].M, wave * 2), chan_quad(P.cvq[0].M, wave * 2 + 1)};
+      const i32x4 sh[2] = {chan_quad(P.cvq[0].sh, wave * 2), chan_quad(P.cvq[0].sh, wave * 2 + 1)};
       const int g = wave >> 1;
-      auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 64 + q * 16; };
-      gemm_i8<MTD0, 2, 1>(QP, aoff, P.cvq[0].w + (wave * 2) * 64, acc);
+      auto aoff = [&](int c) { return m * QS + g * 64 + q * 16; };
+      gemm_i8_t<2, 1>(QP, aoff, P.cvq[0].w + (wave * 2) * 64, acc);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        int n = (wave * 2 + j) * 16 + (lane & 15);
-        int bias = as_global(P.cvq[0].b)[n], M = as_global(P.cvq[0].M)[n], sh = as_global(P.cvq[0].sh)[n];
-        int pc = at16(n);
+        int o[4];
 #pragma unroll
-        for (int i = 0; i < MTD0; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int row = i * 16 + q * 4 + e;
-            int c8 = conv_code<MODE>(acc[i][j][e] + bias, M, sh, P.cvq[0].zout);
-            float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + pc];
-            QX[row * QS + n] = (int8_t)quantize_code<MODE>(v, P.q3);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int c8 = conv_code<MODE>(acc[j][e], M[j][e], sh[j][e], P.cvq[0].zout);
+          const float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + at16(ch0 + 16 * j + e)];
+          o[e] = quantize_code<MODE>(v, P.q3);
+        }
+        *reinterpret_cast<int*>(&QX[row * QS + ch0 + 16 * j]) = pack8(o[0], o[1], o[2], o[3]);
       }
     }
     __syncthreads();
@@ -388,28 +384,31 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
     return (t * SD1 + s) * CS1 + c * 16 + q * 4;
   };
   const f32x4* wfrag = P.up.w + tile0 * 16 * 64;   // per N tile 16 K chunks: 0-7 taps 0..4, 8-15 taps 5..9
-  float biasv[NTW];
+  {
+    f32x4 bias4[NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    biasv[j] = as_global(P.up.b)[((tile0 + j) * 16 + (lane & 15)) & 63];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) acc[i][j] = (f32x4){biasv[j], biasv[j], biasv[j], biasv[j]};
+    for (int j = 0; j < NTW; ++j) {
+      const float v = as_global(P.up.b)[((tile0 + j) * 16 + (lane & 15)) & 63];
+      bias4[j] = (f32x4){v, v, v, v};
+    }
+    gemm_f32_init<2, NTW, 8, 16>(XB, aoff, wfrag, bias4, acc);
   }
-  gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag, acc);
   LYRA_TSTAMP(54);
   LYRA_WSTAMP(114);
   f32x4 head[NTW];
   const bool lo = lane < 32;
 #pragma unroll
-  for (int j = 0; j < NTW; ++j)
+  for (int j = 0; j < NTW; ++j) {
+    const float biasb = as_global(P.up.b)[((tile0 + j) * 16 + (lane & 15)) & 63];   // L1 hit: read before pass 1 too
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float a = acc[0][j][e], bb = acc[1][j][e];   // a = [Y(b0) | Y(b1)], bb = [Y(b2) | Y(b3)]  (lanes 0-31 | 32-63)
       head[j][e] = a;                              // lanes 0-31: block 0, complete
       rot32_pair(a, bb);                           // a = [Y(b1) | Y(b0)], bb = [Y(b3) | Y(b2)]
       acc[0][j][e] = lo ? a : bb;                  // blocks 1 | 2
-      acc[1][j][e] = lo ? bb : biasv[j];           // blocks 3 | 4 (block 4 starts from the bare bias)
+      acc[1][j][e] = lo ? bb : biasb;              // blocks 3 | 4 (block 4 starts from the bare bias)
     }
+  }
   gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
   LYRA_TSTAMP(55);
   LYRA_WSTAMP(115);
@@ -419,17 +418,18 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
     const int jj = n >> 6, co = n & 63;
     const float sub = as_global(P.up_sub)[co];
     const int pc = at16(co);
+    // C rows (SD1 = 8): tile 0 = blocks 1 | 2, tile 1 = blocks 3 | 4 (lanes 0-31 | 32-63); block 4 is the carried tail
+    const int blk = lo ? 0 : 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int R = i * 16 + q * 4 + e, b = 1 + R / SD1, s = R & (SD1 - 1);
-        float y = acc[i][j][e];
-        y = y + 0.f;
-        if (!cx.valid(s)) continue;
-        if (b < 4) out1[((size_t)(b0 + s) * 20 + 5 * b + jj) * 64 + pc] = y;
-        else reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y - sub;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int s = (q & 1) * 4 + e;
+      const float y0 = acc[0][j][e] + 0.f, y1 = acc[1][j][e] + 0.f;
+      if (!cx.valid(s)) continue;
+      float* o = &out1[((size_t)(b0 + s) * 20 + 5 * (1 + blk) + jj) * 64 + pc];
+      o[0] = y0;                                   // block 1 | 2
+      if (lo) o[10 * 64] = y1;                     // block 3
+      else reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y1 - sub;
+    }
     if (lo) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -580,9 +580,8 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
       return ((b + 3 - (c >> 2)) * SD2 + s) * CS0 + (c & 3) * 16 + q * 4;
     };
     const float bias = as_global(P.up.b)[0];
-    acc[0][0] = (f32x4){bias, bias, bias, bias};
-    acc[1][0] = acc[0][0];
-    gemm_f32<2, 1, 16, 16, false>(XB, aoff, P.up.w, acc);
+    const f32x4 bias4[1] = {(f32x4){bias, bias, bias, bias}};
+    gemm_f32_init<2, 1, 16, 16>(XB, aoff, P.up.w, bias4, acc);
     const int j = lane & 15;
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -85,7 +85,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   // ---- resblock 0, fp32 half: depthwise (dil 1, history 2 rows, replaced) + pointwise 256->256 ----
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
-    f32x4 acc = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(&as_global(P.dw0.b)[p4 * 4]);   // chain starts from the bias
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};   // the chain starts from the bias, which is +0.0 for every depthwise layer (model.hip checks)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int tau = t - (2 - j);
@@ -107,8 +107,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   {  // pointwise fp32 -> QUANTIZE -> int8 LeakyReLU -> QP
     f32x4 acc[MT2][2];
     auto aoff = [&](int i, int c) { return (i * 16 + m) * CS2 + c * 16 + q * 4; };
-    acc_bias(acc, P.pw0.b, wave * 2 * 16);
-    gemm_f32<MT2, 2, 16, 16, false>(DF, aoff, P.pw0.w + (wave * 2) * 16 * 64, acc);
+    gemm_f32_bias<MT2, 2, 16, 16>(DF, aoff, P.pw0.w + (wave * 2) * 16 * 64, P.pw0.b, wave * 2 * 16, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = (wave * 2 + j) * 16 + (lane & 15);
@@ -123,25 +122,25 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   }
   __syncthreads();
   LYRA_TSTAMP(3);
-  {  // grouped 1x1 int8 (4 groups 64->64) -> DEQUANTIZE + float skip -> QUANTIZE = X1
-    i32x4 acc[MT2][2];
+  {  // grouped 1x1 int8 (4 groups 64->64) -> DEQUANTIZE + float skip -> QUANTIZE = X1; operand-swapped (gemm_i8_t)
+    static_assert(MT2 == 1, "one 16-row M tile: rows (t, s)");
+    const int row = lane & 15, ch0 = wave * 32 + q * 4;
+    i32x4 acc[2] = {chan_quad(P.r0b.b, wave * 2), chan_quad(P.r0b.b, wave * 2 + 1)};
+    const i32x4 M[2] = {chan_quad(P.r0b.M, wave * 2), chan_quad(P.r0b.M, wave * 2 + 1)};
+    const i32x4 sh[2] = {chan_quad(P.r0b.sh, wave * 2), chan_quad(P.r0b.sh, wave * 2 + 1)};
     const int g = wave >> 1;
-    auto aoff = [&](int i, int c) { return (i * 16 + m) * QS + g * 64 + q * 16; };
-    gemm_i8<MT2, 2, 1>(QP, aoff, P.r0b.w + (wave * 2) * 64, acc);
+    auto aoff = [&](int c) { return m * QS + g * 64 + q * 16; };
+    gemm_i8_t<2, 1>(QP, aoff, P.r0b.w + (wave * 2) * 64, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int n = (wave * 2 + j) * 16 + (lane & 15);
-      int bias = as_global(P.r0b.b)[n], M = as_global(P.r0b.M)[n], sh = as_global(P.r0b.sh)[n];
-      int pc = at16(n);
+      int o[4];
 #pragma unroll
-      for (int i = 0; i < MT2; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int row = i * 16 + q * 4 + e;
-          int c8 = conv_code<MODE>(acc[i][j][e] + bias, M, sh, P.r0b.zout);
-          float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + pc];
-          QX[row * QS + n] = (int8_t)quantize_code<MODE>(v, P.q_x1);
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int c8 = conv_code<MODE>(acc[j][e], M[j][e], sh[j][e], P.r0b.zout);
+        const float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + at16(ch0 + 16 * j + e)];
+        o[e] = quantize_code<MODE>(v, P.q_x1);
+      }
+      *reinterpret_cast<int*>(&QX[row * QS + ch0 + 16 * j]) = pack8(o[0], o[1], o[2], o[3]);
     }
   }
   __syncthreads();

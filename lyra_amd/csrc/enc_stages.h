@@ -109,8 +109,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
       int R = (wm * 5 + i) * 16 + m;
       return (R & (S0 - 1)) * PBS + (R / S0 + c) * 16 + q * 4;
     };
-    acc_bias(xr, P.first.b, wn * 16);
-    gemm_f32<5, 1, 4, 4, false>(PB, aoff, P.first.w + wn * 4 * 64, xr);
+    gemm_f32_bias<5, 1, 4, 4>(PB, aoff, P.first.w + wn * 4 * 64, P.first.b, wn * 16, xr);
   }
   __syncthreads();  // PCM staging area is free again
 #pragma unroll
@@ -150,8 +149,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
       int R = i * 16 + m;
       return ((5 * (R / S0) + tap) * S0 + (R & (S0 - 1))) * CS0 + c16 * 16 + q * 4;
     };
-    acc_bias(acc, P.down.b, wave * NTW * 16);
-    gemm_f32<MTW, NTW, 40, 40, false>(XB, aoff, P.down.w + (wave * NTW) * 40 * 64, acc);
+    gemm_f32_bias<MTW, NTW, 40, 40>(XB, aoff, P.down.w + (wave * NTW) * 40 * 64, P.down.b, wave * NTW * 16, acc);
     LYRA_TSTAMP(5);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
@@ -243,8 +241,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
       int R = i * 16 + m;
       return ((2 * (R / S1) + tap) * S1 + (R & (S1 - 1))) * CS1 + g * 64 + c16 * 16 + q * 4;
     };
-    acc_bias(acc, P.down.b, nt0 * 16);
-    gemm_f32<MTW, NTW, 16, 16, false>(XB, aoff, P.down.w + nt0 * 16 * 64, acc);
+    gemm_f32_bias<MTW, NTW, 16, 16>(XB, aoff, P.down.w + nt0 * 16 * 64, P.down.b, nt0 * 16, acc);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       int n = (nt0 + j) * 16 + (lane & 15);

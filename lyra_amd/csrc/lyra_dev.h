@@ -9,7 +9,7 @@
 //    the lane's A operands for four consecutive MFMAs (k = q, 4+q, 8+q, 12+q ... i.e. kk*4+q), so the
 //    K loop runs in strictly ascending k -- bitwise the fmaf chain the oracle defines
 //    (oracle/lyra_oracle.c header) -- at one LDS read per four MFMAs.  The chains START FROM THE BIAS
-//    (acc_bias below): that is the order XNNPACK's f32 micro-kernels compute (tests/test_xnnpack_witness.py),
+//    (gemm_f32_bias below): that is the order XNNPACK's f32 micro-kernels compute (tests/test_xnnpack_witness.py),
 //    and it removes the epilogues' "+ bias" vector add.
 //  * fp32 rows are padded by 8 floats (stride C+8): conflict-free for that ds_read_b128 pattern.
 //  * int8 activations keep natural channel order, row stride C+32 bytes.
@@ -247,17 +247,18 @@ __device__ __forceinline__ void wg_schedule_hint() {
 #else
 #define LYRA_WCHUNK(c) (c)
 #endif
-template <int MTW, int NTW, int KC, int KS = KC, bool ZERO = true,
-          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
-__device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* bfrag_generic,
-                                         f32x4 (&acc)[MTW][NTW]) {
+// INIT: 0 = the chains start from 0, 1 = acc carries values in (a chain continued from an earlier GEMM), 2 = the chains
+// start from init[j] (the bias splat of N tile j): the first MFMA of every chain takes it as its C operand directly,
+// so no accumulator is written (or even allocated) before the first products arrive.
+template <int MTW, int NTW, int KC, int KS, int INIT, int PF, class AOff>
+__device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, const f32x4* bfrag_generic,
+                                              f32x4 (&acc)[MTW][NTW], const f32x4 (&init)[NTW]) {
   const int lane = threadIdx.x & 63;
   const f32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic) + lane;
-  if (ZERO) {
+  if (INIT == 2) {   // the splat lives in the LAST M tile's accumulator: the first MFMA of tile i reads it from there and
+                     // tile MTW - 1 (issued last) overwrites it in place -- no register beyond the accumulators themselves
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[MTW - 1][j] = init[j];
   }
   f32x4 bq[PF + 1][NTW], aq[PF + 1][MTW];
 #pragma unroll
@@ -287,23 +288,45 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
 #pragma unroll
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NTW; ++j) {
+          const bool first = c == 0 && kk == 0;
+          const f32x4 cin = (first && INIT == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : (first && INIT == 2) ? acc[MTW - 1][j] : acc[i][j];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], cin, 0, 0, 0);
+        }
     LYRA_MFMA_END();
   }
 }
 
-// Start the chains from the bias: C layout col = lane & 15, so one value per N tile fills a lane's four rows.
-//   bias: logical channel order; n0 = first output channel of the wave's first N tile
-template <int MTW, int NTW>
-__device__ __forceinline__ void acc_bias(f32x4 (&acc)[MTW][NTW], const float* bias, int n0) {
+template <int MTW, int NTW, int KC, int KS = KC, bool ZERO = true,
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+__device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32x4* bfrag_generic,
+                                         f32x4 (&acc)[MTW][NTW]) {
+  f32x4 none[NTW];
+  gemm_f32_core<MTW, NTW, KC, KS, ZERO ? 0 : 1, PF>(lds, a_off, bfrag_generic, acc, none);
+}
+
+// The chains start from the bias (logical channel order; n0 = first output channel of the wave's first N tile):
+// C layout col = lane & 15, so one value per N tile fills a lane's four rows.
+template <int MTW, int NTW, int KC, int KS = KC,
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+__device__ __forceinline__ void gemm_f32_bias(const float* lds, AOff a_off, const f32x4* bfrag_generic,
+                                              const float* bias, int n0, f32x4 (&acc)[MTW][NTW]) {
   const float LYRA_GLOBAL* b = as_global(bias) + n0 + (threadIdx.x & 15);
+  f32x4 init[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const float v = b[j * 16];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) acc[i][j] = (f32x4){v, v, v, v};
+    init[j] = (f32x4){v, v, v, v};
   }
+  gemm_f32_core<MTW, NTW, KC, KS, 2, PF>(lds, a_off, bfrag_generic, acc, init);
+}
+
+// ... from splats the caller already holds
+template <int MTW, int NTW, int KC, int KS = KC,
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+__device__ __forceinline__ void gemm_f32_init(const float* lds, AOff a_off, const f32x4* bfrag_generic,
+                                              const f32x4 (&init)[NTW], f32x4 (&acc)[MTW][NTW]) {
+  gemm_f32_core<MTW, NTW, KC, KS, 2, PF>(lds, a_off, bfrag_generic, acc, init);
 }
 
 template <int MTW, int NTW, int KC, class AOff>
@@ -328,6 +351,31 @@ __device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32
       for (int j = 0; j < NTW; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
   }
+}
+
+// Operand-swapped int8 GEMM: the weight fragment is the A operand and the activation fragment the B operand (both have
+// the same per-lane shape -- 16 consecutive k of one row / column --, so nothing is repacked), which transposes the C
+// tile: lane l holds OUT CHANNELS 4 * (l >> 4) + e (e = 0..3) of the wave's N tile j for activation row l & 15.  An
+// epilogue then packs its four codes into ONE dword store (the un-swapped layout scatters them over four rows: four
+// ds_write_b8 at stride QS, the bank-conflict hot spot of rounds 2-3), reads a residual row's four bytes with one dword
+// load, and takes its per-channel parameters as 16-byte quads.  acc comes in initialised (bias - zin * sum(w)).
+template <int NTW, int KC, class AOff>
+__device__ __forceinline__ void gemm_i8_t(const int8_t* lds, AOff a_off, const i32x4* bfrag_generic, i32x4 (&acc)[NTW]) {
+  const int lane = threadIdx.x & 63;
+  const i32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic);
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    i32x4 w[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) w[j] = bfrag[(j * KC + c) * 64 + lane];
+    const i32x4 a = *reinterpret_cast<const i32x4*>(lds + a_off(c));
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[j], a, acc[j], 0, 0, 0);
+  }
+}
+// this lane's four consecutive per-channel parameters of N tile nt (swapped layout)
+__device__ __forceinline__ i32x4 chan_quad(const int32_t* p, int nt) {
+  return *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(as_global(p) + nt * 16 + (((threadIdx.x & 63) >> 4) << 2));
 }
 
 // A 16-row tile whose rows 8..15 are padding (GEMM rows = 8 streams) leaves lanes 32-63 idle in the epilogue.

@@ -156,6 +156,7 @@ struct Builder {
   int mode;                                      // 0 exact / 1 gemmlowp_double / 2 xnnpack
   Arena arena;
   std::vector<std::pair<void*, size_t>> fixups;  // (address of a device-pointer field, arena offset)
+  std::string nonzero_dw_bias;                   // first fp32 depthwise layer with a non-zero bias (unsupported)
   std::string stride_mismatch;                   // first transposed conv whose stride is not the kernels'
 
   template <class P, class T>
@@ -224,6 +225,10 @@ struct Builder {
     const float* w = pk.f32(key(pre, "dw", idx, "w"), {k, C});
     const float* b = pk.f32(key(pre, "dw", idx, "b"), {C});
     if (!w || !b) return;
+    // The kernels are specialised to what the graphs contain: bias-free depthwise layers (the converter materialises an
+    // all-zero bias tensor).  Their fmaf chains start from +0.0, which IS "from the bias" then.
+    for (int c = 0; c < (int)C; ++c)
+      if (b[c] != 0.0f) { nonzero_dw_bias = key(pre, "dw", idx, "b"); return; }
     std::vector<float> wp((size_t)k * C), bp(C);
     for (int j = 0; j < (int)k; ++j)
       for (int c = 0; c < (int)C; ++c) wp[(size_t)j * C + at16(c)] = w[(size_t)j * C + c];
@@ -603,6 +608,10 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   }
   if (!pk.ok()) { *err = "weight container: " + pk.missing(); return false; }
   if (!B.stride_mismatch.empty()) { *err = "weight container: unexpected stride in " + B.stride_mismatch; return false; }
+  if (!B.nonzero_dw_bias.empty()) {
+    *err = "weight container: " + B.nonzero_dw_bias + " is not all zero (the kernels are specialised to bias-free fp32 depthwise layers)";
+    return false;
+  }
 
   const std::vector<uint8_t>& bytes = B.arena.bytes();
   if (hipMalloc((void**)&M->d_arena, bytes.size()) != hipSuccess) { *err = "hipMalloc(weights) failed"; return false; }

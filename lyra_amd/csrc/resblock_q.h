@@ -46,8 +46,6 @@ struct RbqPre {
   int h[2][2];        // ring history words: [t][0] = row t - 2d, [t][1] = row t - d
   int ww[3];          // depthwise taps, 4 channels each
   i32x4 b, M, sh;     // depthwise requantisation, 4 channels
-  int pb[2], pM[2], psh[2];   // pointwise epilogue (2 N tiles)
-  int cb[2], cM[2], csh[2];   // grouped-conv epilogue
 };
 
 template <int S>
@@ -72,12 +70,10 @@ __device__ __forceinline__ RbqPre resblock_q_prefetch(const TileCtx& cx, int d, 
   p.b = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.b)[w4 * 4]);
   p.M = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.M)[w4 * 4]);
   p.sh = *reinterpret_cast<const i32x4 LYRA_GLOBAL*>(&as_global(dq.sh)[w4 * 4]);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int n = (wave * 2 + j) * 16 + (lane & 15);
-    p.pb[j] = as_global(pw.b)[n]; p.pM[j] = as_global(pw.M)[n]; p.psh[j] = as_global(pw.sh)[n];
-    p.cb[j] = as_global(cv.b)[n]; p.cM[j] = as_global(cv.M)[n]; p.csh[j] = as_global(cv.sh)[n];
-  }
+  // The two GEMMs' per-channel parameters are NOT prefetched here: in the operand-swapped layout they are 16-byte quads
+  // (24 registers for both epilogues); each GEMM phase requests its own together with its first weight fragments --
+  // the bias is the accumulators' initial value and arrives in the same L2 round trip as the weights.
+  (void)lane; (void)wave; (void)pw; (void)cv;
   return p;
 }
 
@@ -117,66 +113,50 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
   }
   __syncthreads();
   LYRA_TSTAMP(tb + 1);
-  {
-    i32x4 acc[1][2];
-    auto aoff = [&](int i, int c) { return m * QS + c * 64 + q * 16; };
-    gemm_i8<1, 2, 4>(QD, aoff, pw.w + (wave * 2) * 4 * 64, acc);
+  const int row = lane & 15;               // activation row (t, s) this lane's C column belongs to
+  const int ch0 = wave * 32 + q * 4;       // its four output channels of N tile j: ch0 + 16 * j + e
+  {  // pointwise 256 -> 256, int8 LeakyReLU -> QP
+    i32x4 acc[2] = {chan_quad(pw.b, wave * 2), chan_quad(pw.b, wave * 2 + 1)};
+    const i32x4 pM[2] = {chan_quad(pw.M, wave * 2), chan_quad(pw.M, wave * 2 + 1)};
+    const i32x4 psh[2] = {chan_quad(pw.sh, wave * 2), chan_quad(pw.sh, wave * 2 + 1)};
+    auto aoff = [&](int c) { return m * QS + c * 64 + q * 16; };
+    gemm_i8_t<2, 4>(QD, aoff, pw.w + (wave * 2) * 4 * 64, acc);
 #ifdef LYRA_TIMING
-    if (tb == 94) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][3])); LYRA_TSTAMP(122); }   // GEMM done (results awaited)
+    if (tb == 94) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3])); LYRA_TSTAMP(122); }   // GEMM done (results awaited)
 #endif
-    // all eight table reads before the first store: an int8 store between two LDS reads of unknown aliasing makes the
-    // compiler drain the LDS queue each time (eight serial round trips instead of one pipelined batch)
-    int8_t r8[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        r8[j][e] = (int8_t)lut8(lm, conv_code<MODE>(acc[0][j][e] + pre.pb[j], pre.pM[j], pre.psh[j], pw.zout));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int n = (wave * 2 + j) * 16 + (lane & 15);
+      int r8[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) QP[(q * 4 + e) * QS + n] = r8[j][e];
+      for (int e = 0; e < 4; ++e) r8[e] = lut8(lm, conv_code<MODE>(acc[j][e], pM[j][e], psh[j][e], pw.zout));
+      *reinterpret_cast<int*>(&QP[row * QS + ch0 + 16 * j]) = pack8(r8[0], r8[1], r8[2], r8[3]);
     }
   }
   __syncthreads();
   LYRA_TSTAMP(tb + 2);
-  {
-    i32x4 acc[1][2];
+  {  // grouped 1x1 (4 groups of 64 -> 64), int8 ADD with the residual stream
+    i32x4 acc[2] = {chan_quad(cv.b, wave * 2), chan_quad(cv.b, wave * 2 + 1)};
+    const i32x4 cM[2] = {chan_quad(cv.M, wave * 2), chan_quad(cv.M, wave * 2 + 1)};
+    const i32x4 csh[2] = {chan_quad(cv.sh, wave * 2), chan_quad(cv.sh, wave * 2 + 1)};
     const int g = wave >> 1;
-    auto aoff = [&](int i, int c) { return m * QS + g * 64 + q * 16; };
-    gemm_i8<1, 2, 1>(QP, aoff, cv.w + (wave * 2) * 64, acc);
+    auto aoff = [&](int c) { return m * QS + g * 64 + q * 16; };
+    gemm_i8_t<2, 1>(QP, aoff, cv.w + (wave * 2) * 64, acc);
 #ifdef LYRA_TIMING
-    if (tb == 94) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][1][3])); LYRA_TSTAMP(123); }
+    if (tb == 94) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][3])); LYRA_TSTAMP(123); }
 #endif
-    // reads batched ahead of the stores for the same reason: residual bytes, then both ADD operand tables, then stores
-    int xo[2][4], ta[2][4], tb2[2][4];
+    int xw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xw[j] = *reinterpret_cast<const int*>(&QX[row * QS + ch0 + 16 * j]);   // residual, 4 channels
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int n = (wave * 2 + j) * 16 + (lane & 15);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xo[j][e] = (int)QX[(q * 4 + e) * QS + n];
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
+      int o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int c8 = conv_code<MODE>(acc[0][j][e] + pre.cb[j], pre.cM[j], pre.csh[j], cv.zout);
-        if constexpr (MODE == 2) {
-          ta[j][e] = xnn_add(c8, xo[j][e], add);       // XNNPACK's qs8 add is two multiply-adds and a shift: no table
-        } else {
-          ta[j][e] = addlut[c8 + 128];
-          tb2[j][e] = addlut[256 + xo[j][e] + 128];
-        }
+        const int c8 = conv_code<MODE>(acc[j][e], cM[j][e], csh[j][e], cv.zout);
+        if constexpr (MODE == 2) o[e] = xnn_add(c8, sx8(xw[j], e), add);   // two multiply-adds and a shift: no table
+        else o[e] = add_q_lut(addlut, c8, sx8(xw[j], e), add);
       }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int n = (wave * 2 + j) * 16 + (lane & 15);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if constexpr (MODE == 2) QX[(q * 4 + e) * QS + n] = (int8_t)ta[j][e];
-        else QX[(q * 4 + e) * QS + n] = (int8_t)clamp8(mbqm_double(ta[j][e] + tb2[j][e], add.mo, add.so) + add.zo);
-      }
+      *reinterpret_cast<int*>(&QX[row * QS + ch0 + 16 * j]) = pack8(o[0], o[1], o[2], o[3]);
     }
   }
   __syncthreads();

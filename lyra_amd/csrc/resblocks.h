@@ -110,12 +110,13 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     f32x4 dreg[5];
     {
       const f32x4 w0 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + p4 * 4);
-      const f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dws[r].b) + p4 * 4);
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const int t0 = tq + k * TSTEP - 2 * d;
         const f32x4 v0 = t0 >= 0 ? *reinterpret_cast<const f32x4*>(&A[(t0 * S + sq) * CS + p4 * 4]) : h0[k];
-        dreg[k] = fma4(v0, w0, bb);   // the chain starts from the bias (XNNPACK's DWCONV order)
+        // the chain starts from the bias (XNNPACK's DWCONV order), and every depthwise bias of these graphs is +0.0
+        // (bias-free layers; model.hip refuses a container where that is not so)
+        dreg[k] = fma4(v0, w0, (f32x4){0.f, 0.f, 0.f, 0.f});
       }
       const f32x4 w1 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 64 + p4 * 4);
 #pragma unroll
@@ -147,8 +148,7 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     auto aoff = [&](int i, int c) { return ((wm * 5 + i) * 16 + m) * CS + c * 16 + q * 4; };
     {  // 4. pointwise 64 -> 64, LeakyReLU -> A
       f32x4 acc[5][1];
-      acc_bias(acc, pws[r].b, wn * 16);
-      gemm_f32<5, 1, 4, 4, false>(A, aoff, pws[r].w + wn * 4 * 64, acc);
+      gemm_f32_bias<5, 1, 4, 4>(A, aoff, pws[r].w + wn * 4 * 64, pws[r].b, wn * 16, acc);
       LYRA_TSTAMP(10 + r * 8 + 5);
       __syncthreads();
 #pragma unroll
@@ -160,8 +160,7 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     }
     {  // 5. 1x1 conv 64 -> 64 + residual (registers)
       f32x4 acc[5][1];
-      acc_bias(acc, cvs[r].b, wn * 16);
-      gemm_f32<5, 1, 4, 4, false>(A, aoff, cvs[r].w + wn * 4 * 64, acc);
+      gemm_f32_bias<5, 1, 4, 4>(A, aoff, cvs[r].w + wn * 4 * 64, cvs[r].b, wn * 16, acc);
 #pragma unroll
       for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -235,7 +234,6 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
       const f32x4 w0 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww);
       const f32x4 w1 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 128);
       const f32x4 w2 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 256);
-      const f32x4 bb = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(dws[r].b) + p4 * 4);
       float* hp = reinterpret_cast<float*>(cx.sbase(s) + off) + p4 * 4;
       const int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
       const bool valid = cx.valid(s);
@@ -248,7 +246,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
         f32x4 v0 = H.h[k][0], v1 = H.h[k][1];
         if (t0 >= 0) v0 = lrelu4(*reinterpret_cast<const f32x4*>(xq + t0 * S * CS));
         if (t1 >= 0) v1 = lrelu4(*reinterpret_cast<const f32x4*>(xq + t1 * S * CS));
-        f32x4 acc = fma4(v0, w0, bb);   // the chain starts from the bias
+        f32x4 acc = fma4(v0, w0, (f32x4){0.f, 0.f, 0.f, 0.f});   // the chain starts from the bias, which is +0.0 (see resblocks64r)
         acc = fma4(v1, w1, acc);
         acc = fma4(a, w2, acc);
         *reinterpret_cast<f32x4*>(&D[(t * S + s) * CS + p4 * 4]) = acc;
@@ -268,8 +266,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
     {  // pointwise 128 -> 128, LeakyReLU
       f32x4 acc[MT][NTW];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + c * 16 + q * 4; };
-      acc_bias(acc, pws[r].b, wave * NTW * 16);
-      gemm_f32<MT, NTW, 8, 8, false>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, acc);
+      gemm_f32_bias<MT, NTW, 8, 8>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, pws[r].b, wave * NTW * 16, acc);
       LYRA_TSTAMP(40 + r * 8 + 3);
       // The next block's history rows.  vmcnt retires in order, so these loads would stall the first weight
       // fetch of a GEMM issued right after them; here they have the two barriers and the LDS-only P write
@@ -291,8 +288,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
       f32x4 acc[MT][NTW];
       const int g = (wave * NTW) >> 2;
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + g * 64 + c * 16 + q * 4; };
-      acc_bias(acc, cvs[r].b, wave * NTW * 16);
-      gemm_f32<MT, NTW, 4, 4, false>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, acc);
+      gemm_f32_bias<MT, NTW, 4, 4>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, cvs[r].b, wave * NTW * 16, acc);
       LYRA_TSTAMP(40 + r * 8 + 5);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {

@@ -1,0 +1,42 @@
+"""bench.py checks the run it times: the exact call pattern of the driver's invocation (`--steps 20 --warmup 5`: warm-up,
+serialised kernel table, 64 ramp steps, the timed lyra_hip_run_steps_dev region, latency steps, one context, input ring
+cycled) is replayed by the CPU oracle and the GPU's final packets / PCM must be bit-equal -- for every BASELINE config the
+bench offers (lyra_benchmark_lib.cc:121-160 is the loop being replaced).  A negative control shows the check has teeth."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(argv):
+    import bench
+    args = bench.parse(argv + ["--no-cpu-baseline", "--verify-streams", "64"])
+    wl = bench.resolve_workload(args, 1)
+    sh = bench.Shard(0, 0, wl, args)
+    res = bench.run_shard(sh, args, wl, lambda: None)
+    return bench, sh, args, wl, res
+
+
+@pytest.mark.parametrize("cfg", [3, 2, 5, 4])
+def test_bench_driver_form_is_verified_against_the_oracle(cfg):
+    bench, sh, args, wl, res = _run(["--config", str(cfg), "--steps", "20", "--warmup", "5", "--latency-steps", "7"])
+    v = res["verify"]
+    assert v["verified"] is True, v
+    assert v["streams"] == 64
+    n_regions = 2 if cfg == 4 else 1          # config #4 times lyra_hip_generate_dev and lyra_hip_decode_dev
+    assert v["steps_replayed"] >= n_regions * (20 + 64) + 5
+    line = bench.result_line(args, wl, 1, res["seconds"], wl["B"] * args.steps, res, "test")
+    assert line["verified"] is True and json.dumps(line)
+    sh.ctx.close()
+
+
+def test_bench_verify_has_teeth():
+    """The same run checked against the WRONG arithmetic flavour must fail (the three modes are three different codecs)."""
+    bench, sh, args, wl, res = _run(["--config", "2", "--steps", "6", "--warmup", "2", "--latency-steps", "0", "--ramp-steps", "4",
+                                     "--no-kernel-table"])
+    assert res["verify"]["verified"] is True
+    sh.args.requant = "exact"
+    assert sh.verify(64)["verified"] is False
+    sh.ctx.close()
