@@ -403,6 +403,8 @@ class Shard:
                                     sub_batches=wl.get("sub_batches"))
         self.history = []   # every (kind, first step, n) this context has executed since its last reset: --verify replays it
         self.ctx.torch_order = False   # this harness synchronises explicitly around every region it times
+        if args.dtx:   # a DTX LyraEncoder at --rate hands that rate to its NoiseEstimator (lyra_encoder.cc:82-85)
+            self.ctx.set_encoder_sample_rate(args.rate)
         gen = torch.Generator(device=self.dev)
         gen.manual_seed(SEED + first_id)
         n = min(self.RING, args.warmup + args.steps)

@@ -305,13 +305,19 @@ int lyra_hip_twin_noise(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B);
  * out [num_streams][num_internal_samples * out_rate / 16000]; synchronises.  num_internal_samples == 0 just synchronises. */
 int lyra_hip_twin_fetch(lyra_hip_ctx* ctx, int num_streams, int num_internal_samples, int out_rate, int16_t* out);
 
-/* The context's HIP streams (hipStream_t as void*), for event timing / ordering by the caller: encode side, decode
- * side, and the quantizer stream of lyra_hip_encode_dev / lyra_hip_encode_dtx_dev.  The packets of those two calls are
- * written on the QUANTIZER stream: lyra_hip_stream() does not cover them (it covers every other encode-side output).
- * lyra_hip_synchronize() waits for all three; lyra_hip_stream_wait() orders a caller's stream behind all three. */
+/* The context's FOUR HIP streams (hipStream_t as void*), for event timing / ordering by the caller: encode side, decode
+ * side, the quantizer stream of lyra_hip_encode_dev / lyra_hip_encode_dtx_dev, and the noise stream.
+ *  - The packets of the two encode calls are written on the QUANTIZER stream: lyra_hip_stream() does not cover them (it
+ *    covers every other encode-side output).
+ *  - The decoder-side lyra_hip_noise_receive_dev (d_is_noise and the estimator's state) and, inside
+ *    lyra_hip_run_steps_dev at an external rate, the output resampler (d_ext_out) complete on the NOISE stream: an event
+ *    recorded on lyra_hip_stream_decode() after those calls does NOT cover them -- use lyra_hip_stream_noise(),
+ *    lyra_hip_stream_wait() or lyra_hip_synchronize().
+ * lyra_hip_synchronize() waits for all four; lyra_hip_stream_wait() orders a caller's stream behind all four. */
 void* lyra_hip_stream(lyra_hip_ctx* ctx);
 void* lyra_hip_stream_decode(lyra_hip_ctx* ctx);
 void* lyra_hip_stream_quantizer(lyra_hip_ctx* ctx);
+void* lyra_hip_stream_noise(lyra_hip_ctx* ctx);
 int lyra_hip_synchronize(lyra_hip_ctx* ctx);
 /* Ordering against a caller-owned HIP stream (hipStream_t as void*, NULL = the null stream); see "Streams". */
 int lyra_hip_wait_for_stream(lyra_hip_ctx* ctx, void* caller_stream);

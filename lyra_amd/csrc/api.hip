@@ -616,10 +616,14 @@ int launch_logmel(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d
 int launch_noise(lyra_hip_ctx* c, int side, hipStream_t st_, const int32_t* d_ids, int B, const int16_t* d_pcm,
                  int32_t* d_is_noise, int32_t* d_masked_ids) {
   uint8_t* region = c->sm.base[side == 0 ? st::R_NOISE_E : st::R_NOISE_D];
+  // the estimator's extractor is created with the rate NoiseEstimator::Create is given (noise_estimator.cc:104-106): its
+  // mel filterbank follows the DTX encoder's external rate, like the time constants
+  const int rate = side == 0 ? c->enc_noise_rate : 16000;
+  const MelP* melp = c->model.d_mel_rate[rate == 8000 ? 0 : rate == 32000 ? 2 : rate == 48000 ? 3 : 1];
   { ProfScope ps(c, K_NOISE, st_);
-    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), st_, c->model.d_mel, d_pcm, d_ids,
+    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), st_, melp, d_pcm, d_ids,
                        B, region, (int)st::NOISE_BYTES, (int)st::N_PREV, (float*)nullptr, 1,
-                       noise_params(side == 0 ? c->enc_noise_rate : 16000), d_is_noise, d_masked_ids); }
+                       noise_params(rate), d_is_noise, d_masked_ids); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -839,6 +843,7 @@ const char* lyra_hip_last_error(const lyra_hip_ctx* c) {
 void* lyra_hip_stream(lyra_hip_ctx* c) { return c ? (void*)c->se[0] : nullptr; }
 void* lyra_hip_stream_decode(lyra_hip_ctx* c) { return c ? (void*)c->sd[0] : nullptr; }
 void* lyra_hip_stream_quantizer(lyra_hip_ctx* c) { return c ? (void*)c->sq[0] : nullptr; }
+void* lyra_hip_stream_noise(lyra_hip_ctx* c) { return c ? (void*)c->sn : nullptr; }
 int lyra_hip_synchronize(lyra_hip_ctx* c) {
   if (!c) return LYRA_HIP_EINVAL;
   return sync_all(c);
@@ -1484,6 +1489,11 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
     return fail(c, LYRA_HIP_EINVAL, "run_steps: DECODER_NOISE needs DECODE and d_is_noise");
   const int ext = S->external_rate ? S->external_rate : 16000;
   const bool rs = ext != 16000;
+  // A DTX LyraEncoder created at `ext` hands that rate to its NoiseEstimator (lyra_encoder.cc:82-85): a step that claims to
+  // run what LyraEncoder::Encode runs must not combine an external rate with another estimator
+  if ((F & LYRA_HIP_STEP_DTX) && enc && c->enc_noise_rate != ext)
+    return fail(c, LYRA_HIP_EINVAL, "run_steps: DTX at external_rate %d but the encoder-side noise estimator is set up for %d Hz "
+                "(call lyra_hip_set_encoder_sample_rate(%d) first)", ext, c->enc_noise_rate, ext);
   const int n_ext = 320 * (ext / 1000) / 16;   // samples per 20 ms hop at the external rate
   if (rs) {
     if (ext != 8000 && ext != 32000 && ext != 48000) return fail(c, LYRA_HIP_EINVAL, "run_steps: external_rate %d", ext);

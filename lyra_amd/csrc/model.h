@@ -44,12 +44,14 @@ struct Model {
   DecS0P dec0; DecS1P dec1; DecS2P dec2;
   const float* cb = nullptr;   // [46][16][64]
   const float* cbt = nullptr;  // [46][64][16]
-  MelP mel;
+  MelP mel;            // = mel_rate[1]
+  MelP mel_rate[4];    // log-mel tables of an extractor created for 8 / 16 / 32 / 48 kHz (model.hip)
   ResetP reset;
   // device-resident copies of the parameter blocks above (what the kernels actually read)
   EncS0P* d_enc0 = nullptr; EncS1P* d_enc1 = nullptr; EncS2P* d_enc2 = nullptr;
   DecS0P* d_dec0 = nullptr; DecS1P* d_dec1 = nullptr; DecS2P* d_dec2 = nullptr;
   MelP* d_mel = nullptr; ResetP* d_reset = nullptr;
+  MelP* d_mel_rate[4] = {nullptr, nullptr, nullptr, nullptr};
   uint8_t* d_params = nullptr;
   uint8_t* d_arena = nullptr;
   size_t arena_bytes = 0;

@@ -538,49 +538,61 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
         twi[len / 2 - 1 + k] = std::sin(ang * k);
       }
     }
-    const int NB = 160, BINS = 513;
-    double lo = 0.0, hi = 0.495 * 16000.0;
-    double mel_lo = hz_to_mel(lo), mel_hi = hz_to_mel(hi);
-    double spacing = (mel_hi - mel_lo) / (NB + 1);
-    std::vector<double> center(NB + 1);
-    for (int i = 0; i <= NB; ++i) center[i] = mel_lo + spacing * (i + 1);
-    double hz_per_bin = 0.5 * 16000.0 / (BINS - 1);
-    int start = (int)(1.5 + lo / hz_per_bin), end = (int)(hi / hz_per_bin);
-    std::vector<int> band(BINS, -2);
-    int channel = 0;
-    for (int i = start; i <= end; ++i) {
-      double melf = hz_to_mel(i * hz_per_bin);
-      while (channel < NB && center[channel] < melf) ++channel;
-      band[i] = channel - 1;
-      int ch = channel - 1;
-      w[i] = ch >= 0 ? (center[ch + 1] - melf) / (center[ch + 1] - center[ch])
-                     : (center[0] - melf) / (center[0] - mel_lo);
+    // The mel filterbank depends on the sample rate the extractor is CREATED with (MelFilterbank::Initialize(kFftBins,
+    // sample_rate_hz, ..., 0.495 * sample_rate_hz), log_mel_spectrogram_extractor_impl.cc:81-87): 16 kHz everywhere on this
+    // path except the DTX encoder's NoiseEstimator, which is handed the encoder's EXTERNAL rate (lyra_encoder.cc:82-85).
+    // The mel scale is not linear, so band edges and weights at 8 / 32 / 48 kHz are other tables: one MelP per rate.
+    static const int kRates[4] = {8000, 16000, 32000, 48000};
+    for (int ri = 0; ri < 4; ++ri) {
+      const int NB = 160, BINS = 513;
+      const double rate = kRates[ri];
+      std::vector<double> w(BINS, 0.0);
+      double lo = 0.0, hi = 0.495 * rate;
+      double mel_lo = hz_to_mel(lo), mel_hi = hz_to_mel(hi);
+      double spacing = (mel_hi - mel_lo) / (NB + 1);
+      std::vector<double> center(NB + 1);
+      for (int i = 0; i <= NB; ++i) center[i] = mel_lo + spacing * (i + 1);
+      double hz_per_bin = 0.5 * rate / (BINS - 1);
+      int start = (int)(1.5 + lo / hz_per_bin), end = (int)(hi / hz_per_bin);
+      std::vector<int> band(BINS, -2);
+      int channel = 0;
+      for (int i = start; i <= end; ++i) {
+        double melf = hz_to_mel(i * hz_per_bin);
+        while (channel < NB && center[channel] < melf) ++channel;
+        band[i] = channel - 1;
+        int ch = channel - 1;
+        w[i] = ch >= 0 ? (center[ch + 1] - melf) / (center[ch + 1] - center[ch])
+                       : (center[0] - melf) / (center[0] - mel_lo);
+      }
+      // first[v + 1] = first bin whose lower band is >= v, v = -1 .. 160 (bands are non-decreasing over [start,end])
+      std::vector<int> first(NB + 2);
+      for (int v = -1; v <= NB; ++v) {
+        int i = start;
+        while (i <= end && band[i] < v) ++i;
+        first[v + 1] = i;
+      }
+      MelP& T = M->mel_rate[ri];
+      B.put(&T.hann, hann);
+      B.put(&T.tw_re, twr);
+      B.put(&T.tw_im, twi);
+      B.put(&T.band, first);
+      B.put(&T.w, w);
+      std::vector<double> wsum(NB, 0.0);   // total forward weight per band (MelFilterbank two-tap scatter)
+      for (int i = start; i <= end; ++i) {
+        int ch = band[i];
+        if (ch >= 0) wsum[ch] += w[i];
+        if (ch + 1 < NB) wsum[ch + 1] += 1.0 - w[i];
+      }
+      B.put(&T.wsum, wsum);
+      T.start = start;
+      T.end = end;
     }
-    // first[v + 1] = first bin whose lower band is >= v, v = -1 .. 160 (bands are non-decreasing over [start,end])
-    std::vector<int> first(NB + 2);
-    for (int v = -1; v <= NB; ++v) {
-      int i = start;
-      while (i <= end && band[i] < v) ++i;
-      first[v + 1] = i;
-    }
-    B.put(&M->mel.hann, hann);
-    B.put(&M->mel.tw_re, twr);
-    B.put(&M->mel.tw_im, twi);
-    B.put(&M->mel.band, first);
-    B.put(&M->mel.w, w);
-    std::vector<double> wsum(NB, 0.0);   // total forward weight per band (MelFilterbank two-tap scatter)
-    for (int i = start; i <= end; ++i) {
-      int ch = band[i];
-      if (ch >= 0) wsum[ch] += w[i];
-      if (ch + 1 < NB) wsum[ch + 1] += 1.0 - w[i];
-    }
-    B.put(&M->mel.wsum, wsum);
     std::vector<double> t4r(768), t4i(768);   // W_1024^j = exp(-2 pi i j / 1024), j < 3 * 256
     for (int j = 0; j < 768; ++j) { t4r[j] = std::cos(-2.0 * PI * j / 1024); t4i[j] = std::sin(-2.0 * PI * j / 1024); }
-    B.put(&M->mel.tw4_re, t4r);
-    B.put(&M->mel.tw4_im, t4i);
-    M->mel.start = start;
-    M->mel.end = end;
+    for (int ri = 0; ri < 4; ++ri) {
+      B.put(&M->mel_rate[ri].tw4_re, t4r);
+      B.put(&M->mel_rate[ri].tw4_im, t4i);
+    }
   }
   // ---- zero points of the int8 histories -----------------------------------------------------------------------
   M->reset.e_r2_1 = (int8_t)E2.dwq[0].zin;
@@ -637,13 +649,16 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   {  // log-mel / reset parameter blocks (not on the encode/decode path)
     std::vector<uint8_t> pb;
     auto add = [&](const void* p, size_t n) { size_t off = (pb.size() + 255) / 256 * 256; pb.resize(off + n); memcpy(pb.data() + off, p, n); return off; };
-    size_t o6 = add(&M->mel, sizeof M->mel), o7 = add(&M->reset, sizeof M->reset);
+    M->mel = M->mel_rate[1];   // 16 kHz: every extractor but the DTX encoder's estimator at another external rate
+    size_t o6 = add(&M->mel_rate[0], sizeof M->mel_rate), o7 = add(&M->reset, sizeof M->reset);
     if (hipMalloc((void**)&M->d_params, pb.size()) != hipSuccess ||
         hipMemcpy(M->d_params, pb.data(), pb.size(), hipMemcpyHostToDevice) != hipSuccess) {
       *err = "uploading parameter blocks failed";
       return false;
     }
-    M->d_mel = (MelP*)(M->d_params + o6); M->d_reset = (ResetP*)(M->d_params + o7);
+    for (int ri = 0; ri < 4; ++ri) M->d_mel_rate[ri] = (MelP*)(M->d_params + o6) + ri;
+    M->d_mel = M->d_mel_rate[1];
+    M->d_reset = (ResetP*)(M->d_params + o7);
   }
   return true;
 }

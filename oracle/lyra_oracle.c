@@ -586,9 +586,12 @@ typedef struct {
   const float* cb; /* [46][16][64] */
   /* log-mel tables (window 640, fft 1024, 160 bands) */
   double hann[640];
-  int mel_start, mel_end;
+  int mel_start, mel_end;      /* the 16 kHz table (every extractor on the path but the DTX encoder's estimator) */
   int mel_band[513];
   double mel_w[513];
+  /* MelFilterbank::Initialize(kFftBins, sample_rate_hz, ..., 0.495 * sample_rate_hz)
+   * (log_mel_spectrogram_extractor_impl.cc:81-87): one table per rate an extractor can be created with */
+  struct mel_table { int start, end; int band[513]; double w[513]; } mel_rate[4];   /* 8 / 16 / 32 / 48 kHz */
 } lo_model;
 
 typedef struct {
@@ -964,27 +967,38 @@ void lo_int16_to_unit(const int16_t* in, long n, float* out) { for (long i = 0; 
 
 static double hz_to_mel(double f) { return 1127.0 * log1p(f / 700.0); }
 
-static void init_logmel(lo_model* m) {
-  const double PI = 3.14159265358979323846;
-  for (int i = 0; i < MEL_WIN; ++i) m->hann[i] = 0.5 - 0.5 * cos(2.0 * PI * i / MEL_WIN);
-  double lo = 0.0, hi = 0.495 * 16000.0;
+static int rate_index(int sample_rate_hz) {
+  return sample_rate_hz == 8000 ? 0 : sample_rate_hz == 32000 ? 2 : sample_rate_hz == 48000 ? 3 : 1;
+}
+static void init_mel_table(struct mel_table* T, double sample_rate) {
+  double lo = 0.0, hi = 0.495 * sample_rate;
   double mel_lo = hz_to_mel(lo), mel_hi = hz_to_mel(hi);
   double spacing = (mel_hi - mel_lo) / (MEL_BANDS + 1);
   double center[MEL_BANDS + 1];
   for (int i = 0; i <= MEL_BANDS; ++i) center[i] = mel_lo + spacing * (i + 1);
-  double hz_per_bin = 0.5 * 16000.0 / (MEL_BINS - 1);
-  m->mel_start = (int)(1.5 + lo / hz_per_bin);
-  m->mel_end = (int)(hi / hz_per_bin);
+  double hz_per_bin = 0.5 * sample_rate / (MEL_BINS - 1);
+  T->start = (int)(1.5 + lo / hz_per_bin);
+  T->end = (int)(hi / hz_per_bin);
   int channel = 0;
   for (int i = 0; i < MEL_BINS; ++i) {
     double melf = hz_to_mel(i * hz_per_bin);
-    if (i < m->mel_start || i > m->mel_end) { m->mel_band[i] = -2; m->mel_w[i] = 0.0; continue; }
+    if (i < T->start || i > T->end) { T->band[i] = -2; T->w[i] = 0.0; continue; }
     while (channel < MEL_BANDS && center[channel] < melf) ++channel;
-    m->mel_band[i] = channel - 1;
+    T->band[i] = channel - 1;
     int ch = channel - 1;
-    if (ch >= 0) m->mel_w[i] = (center[ch + 1] - melf) / (center[ch + 1] - center[ch]);
-    else m->mel_w[i] = (center[0] - melf) / (center[0] - mel_lo);
+    if (ch >= 0) T->w[i] = (center[ch + 1] - melf) / (center[ch + 1] - center[ch]);
+    else T->w[i] = (center[0] - melf) / (center[0] - mel_lo);
   }
+}
+static void init_logmel(lo_model* m) {
+  const double PI = 3.14159265358979323846;
+  static const double kRates[4] = {8000.0, 16000.0, 32000.0, 48000.0};
+  for (int i = 0; i < MEL_WIN; ++i) m->hann[i] = 0.5 - 0.5 * cos(2.0 * PI * i / MEL_WIN);
+  for (int r = 0; r < 4; ++r) init_mel_table(&m->mel_rate[r], kRates[r]);
+  m->mel_start = m->mel_rate[1].start;
+  m->mel_end = m->mel_rate[1].end;
+  memcpy(m->mel_band, m->mel_rate[1].band, sizeof m->mel_band);
+  memcpy(m->mel_w, m->mel_rate[1].w, sizeof m->mel_w);
 }
 
 static void fft1024(double* re, double* im) {
@@ -1019,7 +1033,7 @@ static void fft1024(double* re, double* im) {
 static float log_f(float x) { return (float)log((double)x); }
 static float exp_f(float x) { return (float)exp((double)x); }
 
-static void logmel_core(const lo_model* m, double* prev, const int16_t* pcm, float* mel) {
+static void logmel_core(const lo_model* m, const struct mel_table* T, double* prev, const int16_t* pcm, float* mel) {
   double re[MEL_FFT], im[MEL_FFT];
   memset(re, 0, sizeof re);
   memset(im, 0, sizeof im);
@@ -1028,10 +1042,10 @@ static void logmel_core(const lo_model* m, double* prev, const int16_t* pcm, flo
   fft1024(re, im);
   double out[MEL_BANDS];
   memset(out, 0, sizeof out);
-  for (int i = m->mel_start; i <= m->mel_end; ++i) {
+  for (int i = T->start; i <= T->end; ++i) {
     double v = sqrt(re[i] * re[i] + im[i] * im[i]);
-    double w = v * m->mel_w[i];
-    int ch = m->mel_band[i];
+    double w = v * T->w[i];
+    int ch = T->band[i];
     if (ch >= 0) out[ch] += w;
     ++ch;
     if (ch < MEL_BANDS) out[ch] += v - w;
@@ -1043,7 +1057,12 @@ static void logmel_core(const lo_model* m, double* prev, const int16_t* pcm, flo
   }
 }
 
-void lo_logmel(const lo_model* m, lo_stream* s, const int16_t* pcm, float* mel) { logmel_core(m, s->mel_prev, pcm, mel); }
+void lo_logmel(const lo_model* m, lo_stream* s, const int16_t* pcm, float* mel) { logmel_core(m, &m->mel_rate[1], s->mel_prev, pcm, mel); }
+/* the extractor LogMelSpectrogramExtractorImpl::Create(sample_rate_hz, 320, 640, 160) builds: same spectrogram, the mel
+ * filterbank of that rate */
+void lo_logmel_rate(const lo_model* m, lo_stream* s, const int16_t* pcm, float* mel, int sample_rate_hz) {
+  logmel_core(m, &m->mel_rate[rate_index(sample_rate_hz)], s->mel_prev, pcm, mel);
+}
 
 /* ------------------------------------------------------------------------ */
 /* NoiseEstimator (lyra/noise_estimator.cc:36-245): minimum statistics over the  */
@@ -1059,6 +1078,7 @@ typedef struct {
   int initialised;           /* smoothed_power_ non-empty */
   int num_hops_received;
   int is_noise;
+  int rate_idx;              /* mel table of the rate the estimator's extractor was created with (noise_estimator.cc:104-106) */
   double mel_prev[320];      /* the estimator owns its log-mel extractor, hence its own previous hop */
   float smoothed[MEL_BANDS], squared[MEL_BANDS], tmp_min[MEL_BANDS], estimate[MEL_BANDS], bound[MEL_BANDS];
 } lo_noise;
@@ -1070,6 +1090,7 @@ lo_noise* lo_noise_new(int num_hops_per_update, float max_smoothing, float bound
   n->max_smoothing = max_smoothing > 0.f ? max_smoothing : powf(0.5f, secs_per_hop / 0.7f);
   n->bound_decay = bound_decay > 0.f ? bound_decay : powf(0.5f, secs_per_hop / 1.f);
   n->is_noise = 1;                            /* noise_estimator.cc:139 */
+  n->rate_idx = 1;
   return n;
 }
 /* NoiseEstimator::Create(sample_rate_hz, 320, ...) (noise_estimator.cc:96-124): the hop duration -- hence the update
@@ -1078,7 +1099,9 @@ lo_noise* lo_noise_new(int num_hops_per_update, float max_smoothing, float bound
  * (lyra_encoder.cc:82-85), so an 8 / 32 / 48 kHz encoder updates every 25 / 100 / 150 hops, not every 50. */
 lo_noise* lo_noise_new_rate(int sample_rate_hz) {
   const float secs_per_hop = 320.f / sample_rate_hz;
-  return lo_noise_new((int)roundf(1.f / secs_per_hop), powf(0.5f, secs_per_hop / 0.7f), powf(0.5f, secs_per_hop / 1.f));
+  lo_noise* n = lo_noise_new((int)roundf(1.f / secs_per_hop), powf(0.5f, secs_per_hop / 0.7f), powf(0.5f, secs_per_hop / 1.f));
+  n->rate_idx = rate_index(sample_rate_hz);   /* ... and so is its extractor's mel filterbank */
+  return n;
 }
 void lo_noise_free(lo_noise* n) { free(n); }
 
@@ -1133,7 +1156,7 @@ void lo_noise_update(lo_noise* n, const float* cur) {                  /* Update
 /* ReceiveSamples for one full hop (:144-173): log-mel, decision, then decay or update.  Returns is_noise. */
 int lo_noise_receive(const lo_model* m, lo_noise* n, const int16_t* pcm, float* mel_out) {
   float mel[MEL_BANDS];
-  logmel_core(m, n->mel_prev, pcm, mel);
+  logmel_core(m, &m->mel_rate[n->rate_idx], n->mel_prev, pcm, mel);
   if (mel_out) memcpy(mel_out, mel, sizeof mel);
   n->is_noise = lo_noise_compute_is_noise(n, mel);
   if (n->is_noise) {

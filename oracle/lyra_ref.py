@@ -122,9 +122,11 @@ class NoiseEstimator:
     """chromemedia::codec::NoiseEstimator (lyra/noise_estimator.cc:96-245) as NoiseEstimator::Create builds it for the
     codec; its log-mel front end is the oracle's."""
 
-    def __init__(self, oracle):
+    def __init__(self, oracle, sample_rate_hz=16000):
         self.L = load(oracle)
-        self.h = self.L.ref_noise_new()
+        self.L.ref_noise_new_rate.restype = C.c_void_p
+        self.L.ref_noise_new_rate.argtypes = [C.c_int]
+        self.h = self.L.ref_noise_new_rate(int(sample_rate_hz))
         assert self.h
 
     def __del__(self):

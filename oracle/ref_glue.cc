@@ -216,6 +216,10 @@ int ref_encoder_set_bitrate(void* e, int bitrate) { return ((LyraEncoder*)e)->se
 void* ref_noise_new(void) {
   return NoiseEstimator::Create(16000, 320, 640, 160).release();
 }
+// what a DTX LyraEncoder created at `sample_rate_hz` builds (lyra_encoder.cc:82-85): external rate, internal hop / window
+void* ref_noise_new_rate(int sample_rate_hz) {
+  return NoiseEstimator::Create(sample_rate_hz, 320, 640, 160).release();
+}
 void ref_noise_free(void* n) { delete (NoiseEstimator*)n; }
 int ref_noise_receive(void* n, const int16_t* pcm, int count) {   // -> is_noise after the call, -1 on failure
   NoiseEstimator* ne = (NoiseEstimator*)n;

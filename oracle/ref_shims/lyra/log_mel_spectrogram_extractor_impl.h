@@ -20,24 +20,27 @@ class LogMelSpectrogramExtractorImpl : public FeatureExtractorInterface {
  public:
   static std::unique_ptr<LogMelSpectrogramExtractorImpl> Create(int sample_rate_hz, int hop_length_samples,
                                                                 int window_length_samples, int num_mel_bins) {
-    // the oracle's log-mel is the 16 kHz / 320 / 640 / 160 instance every caller on this path asks for
+    // the oracle's log-mel is the 320 / 640 / 160 instance every caller on this path asks for; the sample rate selects the
+    // mel filterbank (log_mel_spectrogram_extractor_impl.cc:81-87) -- the DTX encoder's NoiseEstimator passes its
+    // EXTERNAL rate here (lyra_encoder.cc:82-85, noise_estimator.cc:104-106)
     if (hop_length_samples != 320 || window_length_samples != 640 || num_mel_bins != 160) return nullptr;
-    (void)sample_rate_hz;
-    return std::unique_ptr<LogMelSpectrogramExtractorImpl>(new LogMelSpectrogramExtractorImpl());
+    if (sample_rate_hz != 8000 && sample_rate_hz != 16000 && sample_rate_hz != 32000 && sample_rate_hz != 48000) return nullptr;
+    return std::unique_ptr<LogMelSpectrogramExtractorImpl>(new LogMelSpectrogramExtractorImpl(sample_rate_hz));
   }
   ~LogMelSpectrogramExtractorImpl() override { lo_stream_free(state_); }
   std::optional<std::vector<float>> Extract(const absl::Span<const int16_t> audio) override {
     if (audio.size() != 320) return std::nullopt;
     std::vector<float> mel(160);
-    lo_logmel(ref_model(), state_, audio.data(), mel.data());
+    lo_logmel_rate(ref_model(), state_, audio.data(), mel.data(), sample_rate_hz_);
     return mel;
   }
   static float GetNormalizationFactor() { return 10.f; }
   static float GetSilenceValue() { return std::log(500.f) / 10.f; }
 
  private:
-  LogMelSpectrogramExtractorImpl() : state_(lo_stream_new()) {}
+  explicit LogMelSpectrogramExtractorImpl(int sample_rate_hz) : state_(lo_stream_new()), sample_rate_hz_(sample_rate_hz) {}
   lo_stream* state_;
+  int sample_rate_hz_;
 };
 
 }  // namespace codec

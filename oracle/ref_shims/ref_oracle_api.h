@@ -11,6 +11,7 @@ void lo_decode_frame(const lo_model*, lo_stream*, const float* feat, int16_t* pc
 void lo_rvq_encode(const lo_model*, const float* feat, int num_stages, int32_t* idx);
 void lo_rvq_decode(const lo_model*, const int32_t* idx, float* feat);
 void lo_logmel(const lo_model*, lo_stream*, const int16_t* pcm, float* mel);
+void lo_logmel_rate(const lo_model*, lo_stream*, const int16_t* pcm, float* mel, int sample_rate_hz);
 lo_resampler* lo_resampler_new(int in_rate, int out_rate);
 void lo_resampler_free(lo_resampler*);
 void lo_resampler_reset(lo_resampler*);

@@ -103,7 +103,33 @@ def test_noise_estimator_restatement_vs_reference_class(ref, oracle_default, gol
     assert worst < 2e-3, worst
 
 
-SESSIONS = [(16000, 6000, False), (48000, 3200, False), (8000, 9200, False), (16000, 9200, True), (32000, 6000, True)]
+@pytest.mark.parametrize("rate", [8000, 32000, 48000])
+def test_noise_estimator_of_a_dtx_encoder_at_other_rates(ref, oracle_default, golden_dir, rate):
+    """A DTX LyraEncoder hands NoiseEstimator::Create its EXTERNAL sample rate (lyra_encoder.cc:82-85), and the estimator
+    passes it on to its log-mel extractor (noise_estimator.cc:104-106 -> MelFilterbank::Initialize(513, rate, 160, 0,
+    0.495 * rate), log_mel_spectrogram_extractor_impl.cc:81-87): time constants AND mel filterbank follow the rate.
+    Round 3 moved only the time constants; the shadow extractor of oracle/_ref now honours the rate, so the
+    compiled reference class sees the same filterbank the oracle / GPU use."""
+    from oracle import lyra_oracle
+    speech, noise, quiet, silence = _signals(golden_dir, 172)
+    mixed = np.concatenate([noise[:60], speech[:112]])
+    for name, sig in (("speech", speech), ("noise", noise), ("mixed", mixed)):
+        a = ref.NoiseEstimator(oracle_default, rate)
+        b = lyra_oracle.NoiseEstimator(oracle_default, sample_rate_hz=rate)
+        c16 = lyra_oracle.NoiseEstimator(oracle_default, sample_rate_hz=16000)
+        differs_from_16k = 0.0
+        for t in range(sig.shape[0]):
+            ra = a.ReceiveSamples(sig[t])
+            rb = b.ReceiveSamples(sig[t])[0]
+            c16.ReceiveSamples(sig[t])
+            assert ra == bool(rb), (name, rate, t)
+            differs_from_16k = max(differs_from_16k, float(np.abs(b.noise_estimate() - c16.noise_estimate()).max()))
+        assert np.abs(a.noise_estimate() - b.noise_estimate()).max() < 2e-3
+        assert differs_from_16k > 1e-2, "the estimate must depend on the rate's filterbank (the check has teeth)"
+
+
+SESSIONS = [(16000, 6000, False), (48000, 3200, False), (8000, 9200, False), (16000, 9200, True), (32000, 6000, True),
+            (48000, 9200, True)]
 BITS = {3200: 64, 6000: 120, 9200: 184}
 
 
@@ -272,9 +298,10 @@ def test_gpu_noise_estimator_vs_reference_class(ref, oracle_default, golden_dir)
     ids = np.array([3, 0, 41, 7, 12], np.int32)
     ctx = lyra_amd.LyraHip(max_streams=64)
     try:
-        for side in ("encoder", "decoder"):
+        for side, rate in (("encoder", 16000), ("decoder", 16000), ("encoder", 48000), ("encoder", 8000)):
             ctx.reset()
-            refs = [ref.NoiseEstimator(oracle_default) for _ in range(5)]
+            ctx.set_encoder_sample_rate(rate)      # what a DTX LyraEncoder created at `rate` gives its estimator
+            refs = [ref.NoiseEstimator(oracle_default, rate) for _ in range(5)]
             for t in range(streams.shape[0]):
                 got = ctx.noise_receive(streams[t], ids, side=side)
                 want = [r.ReceiveSamples(streams[t, b]) for b, r in enumerate(refs)]
