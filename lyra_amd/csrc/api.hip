@@ -113,6 +113,13 @@ struct lyra_hip_ctx {
   float* d_twin_fade = nullptr;    // [TWIN_FADE_N] cross-fade weights
   int32_t* d_twin_iota = nullptr;  // [max_streams] 0, 1, 2, ...
   uint8_t* h_twin_args = nullptr;  // pinned
+  // Small host-buffer calls (the per-object plugin contract: B = 1 per blocking call) skip the copy engine: the kernels read
+  // their input from and write their output to this pinned, device-mapped arena directly -- three copy packets and their
+  // stream bubbles fewer per call (lyra_amd/plugin_demo --bench).  ZC_MAX streams per call; LYRA_HIP_NO_ZEROCOPY=1 turns it off.
+  static constexpr int ZC_MAX = 16;
+  static constexpr size_t ZC_IDS = 0, ZC_IN = 256, ZC_OUT = 256 + ZC_MAX * 640, ZC_BYTES = 256 + 2 * ZC_MAX * 640;
+  uint8_t* h_zc = nullptr;
+  bool zc(int B) const { return h_zc && B <= ZC_MAX; }
   uint8_t* d_twin_args = nullptr;
   size_t twin_args_cap = 0, twin_args_used = 0;
   size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
@@ -792,6 +799,9 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   if (getenv("LYRA_HIP_FUSED") && atoi(getenv("LYRA_HIP_FUSED")))
     return bail(LYRA_HIP_EINVAL, "LYRA_HIP_FUSED: the one-launch-per-side kernels are not in this build (make EXTRA=-DLYRA_PARKED)");
 #endif
+  if (!(getenv("LYRA_HIP_NO_ZEROCOPY") && atoi(getenv("LYRA_HIP_NO_ZEROCOPY"))) &&
+      hipHostMalloc((void**)&c->h_zc, lyra_hip_ctx::ZC_BYTES, hipHostMallocDefault) != hipSuccess)
+    c->h_zc = nullptr;   // optional: the copy-engine path remains
   for (int k = 0; k < c->nsub; ++k)
     if (enc_side_done(c, k) != 0) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
   *out = c;
@@ -806,6 +816,8 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
   twin_free(c);
+  if (c->h_zc) (void)hipHostFree(c->h_zc);
+  c->h_zc = nullptr;
   free_scratch(c);
   for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -1368,6 +1380,18 @@ int lyra_hip_extract(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* 
   PROLOGUE(c, B);
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
+  if (c->zc(B)) {   // zero-copy: see lyra_hip_ctx::h_zc
+    int32_t* z_ids = (int32_t*)(c->h_zc + lyra_hip_ctx::ZC_IDS);
+    int16_t* z_in = (int16_t*)(c->h_zc + lyra_hip_ctx::ZC_IN);
+    float* z_out = (float*)(c->h_zc + lyra_hip_ctx::ZC_OUT);
+    std::memcpy(z_ids, ids, (size_t)B * 4);
+    std::memcpy(z_in, pcm, (size_t)B * 640);
+    if ((rc = launch_extract(c, 0, 0, z_ids, B, z_in, z_out))) return rc;
+    if ((rc = enc_side_done(c, 0))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->se[0]));
+    std::memcpy(features, z_out, (size_t)B * 256);
+    return 0;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->se[0]));
   HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)B * 640, hipMemcpyHostToDevice, c->se[0]));
   if ((rc = launch_extract(c, 0, 0, c->d_ids, B, c->d_pcm_in, c->d_feat))) return rc;
@@ -1384,6 +1408,16 @@ int lyra_hip_rvq_encode(lyra_hip_ctx* c, int B, const float* features, int num_b
   if (B <= 0 || !features || !indices) return fail(c, LYRA_HIP_EINVAL, "bad batch or null pointer");
   HIPCHK(c, hipSetDevice(c->device));
   if ((rc = ensure_scratch(c, B))) return rc;
+  if (c->zc(B)) {
+    float* z_in = (float*)(c->h_zc + lyra_hip_ctx::ZC_IN);
+    int32_t* z_out = (int32_t*)(c->h_zc + lyra_hip_ctx::ZC_OUT);
+    std::memcpy(z_in, features, (size_t)B * 256);
+    if ((rc = launch_rvq_encode(c, 0, B, z_in, num_bits / 4, z_out, nullptr))) return rc;
+    if ((rc = enc_side_done(c, 0))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->se[0]));
+    std::memcpy(indices, z_out, (size_t)B * 46 * 4);
+    return 0;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_feat, features, (size_t)B * 256, hipMemcpyHostToDevice, c->se[0]));
   if ((rc = launch_rvq_encode(c, 0, B, c->d_feat, num_bits / 4, c->d_idx, nullptr))) return rc;
   HIPCHK(c, hipMemcpyAsync(indices, c->d_idx, (size_t)B * 46 * 4, hipMemcpyDeviceToHost, c->se[0]));
@@ -1399,6 +1433,15 @@ int lyra_hip_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* indices, float* f
   int rc;
   if ((rc = ensure_scratch(c, B))) return rc;
   if ((rc = dec_side_begin(c, 0))) return rc;
+  if (c->zc(B)) {
+    int32_t* z_in = (int32_t*)(c->h_zc + lyra_hip_ctx::ZC_IN);
+    float* z_out = (float*)(c->h_zc + lyra_hip_ctx::ZC_OUT);
+    std::memcpy(z_in, indices, (size_t)B * 46 * 4);
+    if ((rc = launch_rvq_decode(c, 0, B, z_in, nullptr, 46, z_out))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->sd[0]));
+    std::memcpy(features, z_out, (size_t)B * 256);
+    return 0;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_idx, indices, (size_t)B * 46 * 4, hipMemcpyHostToDevice, c->sd[0]));
   if ((rc = launch_rvq_decode(c, 0, B, c->d_idx, nullptr, 46, c->d_lossy))) return rc;
   HIPCHK(c, hipMemcpyAsync(features, c->d_lossy, (size_t)B * 256, hipMemcpyDeviceToHost, c->sd[0]));
@@ -1411,6 +1454,17 @@ int lyra_hip_generate(lyra_hip_ctx* c, const int32_t* ids, int B, const float* f
   if (!pcm || !features) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = check_ids_host(c, ids, B))) return rc;
   if ((rc = dec_side_begin(c, 0))) return rc;
+  if (c->zc(B)) {
+    int32_t* z_ids = (int32_t*)(c->h_zc + lyra_hip_ctx::ZC_IDS);
+    float* z_in = (float*)(c->h_zc + lyra_hip_ctx::ZC_IN);
+    int16_t* z_out = (int16_t*)(c->h_zc + lyra_hip_ctx::ZC_OUT);
+    std::memcpy(z_ids, ids, (size_t)B * 4);
+    std::memcpy(z_in, features, (size_t)B * 256);
+    if ((rc = launch_generate(c, 0, 0, z_ids, B, z_in, z_out))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->sd[0]));
+    std::memcpy(pcm, z_out, (size_t)B * 640);
+    return 0;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_ids_dec, ids, (size_t)B * 4, hipMemcpyHostToDevice, c->sd[0]));
   HIPCHK(c, hipMemcpyAsync(c->d_lossy, features, (size_t)B * 256, hipMemcpyHostToDevice, c->sd[0]));
   if ((rc = launch_generate(c, 0, 0, c->d_ids_dec, B, c->d_lossy, c->d_pcm_out))) return rc;
