@@ -131,6 +131,9 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (weak scaling)")
     ap.add_argument("--total-streams", type=int, default=None, help="streams in the whole job (strong scaling)")
     ap.add_argument("--bits", type=int, default=None)
+    ap.add_argument("--sub-batches", type=int, default=None,
+                    help="split every call into this many sub-batches on stream sets of their own (LYRA_HIP_SUBBATCHES); "
+                         "default: the config's (config #2: 4, #4: 2, others 1)")
     ap.add_argument("--with-logmel", action="store_true",
                     help="run the plain log-mel extractor on every decoded hop inside the step (implies --per-call)")
     ap.add_argument("--full-decoder", action="store_true",
@@ -190,7 +193,7 @@ def resolve_workload(args, world):
         per = cfg["streams"]
         total = per * world
     return dict(B=per, total=total, bits=cfg["bits"], mode=cfg["mode"], scaling=cfg["scaling"], config=args.config,
-                sub_batches=cfg.get("sub_batches"))
+                sub_batches=args.sub_batches if args.sub_batches is not None else cfg.get("sub_batches"))
 
 
 def dist_env():

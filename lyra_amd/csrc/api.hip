@@ -124,6 +124,7 @@ struct lyra_hip_ctx {
   size_t twin_args_cap = 0, twin_args_used = 0;
   size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
   int tile_div[6] = {1, 1, 1, 1, 1, 1};   // tiles per workgroup of each stage kernel (LYRA_TILE_LOOP), see tile_div()
+  bool chunk_local = false;                       // see wait_encode_side
   int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
@@ -406,6 +407,9 @@ int encq_done(lyra_hip_ctx* c, int k) {
 // `who`: index of the waiting stream in seen_* (decode stream k, or KMAX for the noise stream).
 int wait_encode_side(lyra_hip_ctx* c, hipStream_t s, int who) {
   for (int j = 0; j < c->nsub; ++j) {
+    // inside lyra_hip_run_steps_dev every call of a step is split the same way over the same stream ids and buffers:
+    // decode chunk k reads what encode chunk k wrote and nothing else, so the sub-batches are independent pipelines
+    if (c->chunk_local && who < lyra_hip_ctx::KMAX && j != who) continue;
     if (c->seen_se[who][j] != c->seq_se[j]) {
       HIPCHK(c, hipStreamWaitEvent(s, c->ev_encs[2][j], 0));
       c->seen_se[who][j] = c->seq_se[j];
@@ -1558,6 +1562,9 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
   // the resamplers leave the codec's chains (resample_in_ahead / resample_deferred) in the default, unsplit configuration;
   // with sub-batches or strict call order they stay where the individual calls put them
   const bool rs_off_chain = rs && !c->serial && c->nsub == 1;
+  struct LocalScope { lyra_hip_ctx* c; ~LocalScope() { c->chunk_local = false; } } local_scope{c};
+  c->chunk_local = c->nsub > 1 && !c->serial && enc && dec && !feats && !rs && !(F & (LYRA_HIP_STEP_DTX | LYRA_HIP_STEP_DECODER_NOISE)) &&
+                   !getenv("LYRA_HIP_NO_CHUNK_LOCAL");
   for (int i = 0; i < S->n_steps; ++i) {
     const long step = S->first_step + i;
     const int set = (int)(step & 1);

@@ -412,17 +412,21 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
   gemm_f32<2, NTW, 8, 16, false>(XB, aoff, wfrag + 8 * 64, acc);
   LYRA_TSTAMP(55);
   LYRA_WSTAMP(115);
+  int lane_e = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_e));
+  const int q_e = lane_e >> 4;
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
-    const int n = (tile0 + j) * 16 + (lane & 15);
+    const int n = (tile0 + j) * 16 + (lane_e & 15);
     const int jj = n >> 6, co = n & 63;
     const float sub = as_global(P.up_sub)[co];
     const int pc = at16(co);
     // C rows (SD1 = 8): tile 0 = blocks 1 | 2, tile 1 = blocks 3 | 4 (lanes 0-31 | 32-63); block 4 is the carried tail
+    const bool lo = lane_e < 32;
     const int blk = lo ? 0 : 1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int s = (q & 1) * 4 + e;
+      const int s = (q_e & 1) * 4 + e;
       const float y0 = acc[0][j][e] + 0.f, y1 = acc[1][j][e] + 0.f;
       if (!cx.valid(s)) continue;
       float* o = &out1[((size_t)(b0 + s) * 20 + 5 * (1 + blk) + jj) * 64 + pc];
@@ -433,7 +437,7 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
     if (lo) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int s = q * 4 + e;
+        const int s = q_e * 4 + e;
         const float y = head[j][e] + SB[(jj * SD1 + s) * 72 + co];
         if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + jj) * 64 + pc] = y;
       }
