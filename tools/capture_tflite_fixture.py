@@ -16,7 +16,7 @@ default delegate (XNNPACK, what lyra_components.cc:42-55 asks for) and once with
     <wav>/<flavour>/pcm_in [T][320] int16, feats [T][64] f32, idx [T][46] i32, lossy [T][64] f32, pcm [T][320] int16
 
 tests/test_tflite_capture.py lights up when the file exists: GPU == TFLite (indices / packets exact, PCM <= 1 LSB),
-and reports which requantisation mode (`exact` / `gemmlowp_double`) matched.
+and reports which arithmetic mode (`xnnpack` / `exact` / `gemmlowp_double`) matched.
 """
 import argparse
 import os
