@@ -172,6 +172,29 @@ def test_bench_default_invocation_spawns_one_rank_per_gpu():
     assert lat["n"] == 10 and lat["min"] == 100.0 and lat["max"] == 200.0 and lat["p50"] == 100.0 and lat["p99"] == 200.0
 
 
+def test_bench_eight_ranks_config5_and_default_respawn():
+    """The shape the driver's 8-GPU run has: `python bench.py --gpus 8 --config 5` typed without a launcher ->
+    eight spawned ranks (gloo here), 4096 streams per rank, one JSON line that carries every rank's own clock and
+    self-check next to the max-reduced time (a straggler must be visible), and rank 0's cpu_baseline leg is attempted at any
+    world size (skipped here only because the stub has no oracle workload to time: --no-cpu-baseline)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stub-context", "--gpus", "8", "--config", "5", "--steps", "4",
+           "--warmup", "1", "--no-cpu-baseline", "--latency-steps", "0", "--no-kernel-table", "--ramp-steps", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["ranks"] == 8 and r["scaling"] == "strong"
+    assert r["config"]["streams_per_gpu"] == 4096 and r["config"]["total_streams"] == 32768 and r["config"]["num_bits"] == 120
+    assert "8 rank(s)" in r["config"]["parallelism"] and "self-spawned" in r["config"]["parallelism"]
+    # stub rank k reports K * 0.1 ms * (1 + k / 2): the slowest rank defines the job, every rank is listed
+    assert r["per_rank_ms_per_step"] == [round(0.1 * (1 + 0.5 * k), 4) for k in range(8)]
+    assert abs(r["ms_per_step"] - 0.1 * 4.5) < 1e-6
+    assert abs(r["value"] - 32768 * 4 / (4 * 1e-4 * 4.5)) < 1.0
+    assert r["verified"] is True and all(p["verified"] for p in r["per_rank"])
+
+
 def test_bench_roofline_bookkeeping():
     """Pure functions of bench.py: per-kernel bounds and the whole-step roofline of every leg."""
     sys.path.insert(0, ROOT)
