@@ -188,8 +188,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       for (int e = 0; e < 4; ++e) {
         const int s = (q & 1) * 4 + e;
         float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP0 + g * 512);
-        int c8 = conv_code<MODE>(acc[0][tap][e] + zf + bias, U.M, U.sh, U.zout);
-        float y = dequantize_f(c8, P.up0_dq[g].s, P.up0_dq[g].z);
+        float y = conv_dequant<MODE>(acc[0][tap][e] + zf + bias, U.M, U.sh, U.zout, P.up0_dq[g].s);   // up0_dq.z == zout (model.hip)
         if (tap < 2) {
           y = y + told[tap < 2 ? tap : 0][e];
           XF[(tap * SD0 + s) * CS2 + pc] = y;
@@ -271,8 +270,8 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
         int o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int c8 = conv_code<MODE>(acc[j][e], M[j][e], sh[j][e], P.cvq[0].zout);
-          const float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + at16(ch0 + 16 * j + e)];
+          const float v = conv_dequant<MODE>(acc[j][e], M[j][e], sh[j][e], P.cvq[0].zout, P.dq_r0.s) +   // dq_r0.z == zout
+                          XF[row * CS2 + at16(ch0 + 16 * j + e)];
           o[e] = quantize_code<MODE>(v, P.q3);
         }
         *reinterpret_cast<int*>(&QX[row * QS + ch0 + 16 * j]) = pack8(o[0], o[1], o[2], o[3]);
@@ -324,8 +323,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       float y[6];
 #pragma unroll
       for (int tau = 0; tau < 6; ++tau) {
-        int c8 = conv_code<MODE>(o[tau] + bias, U.M, U.sh, U.zout);
-        y[tau] = dequantize_f(c8, P.up1_dq[g].s, P.up1_dq[g].z);
+        y[tau] = conv_dequant<MODE>(o[tau] + bias, U.M, U.sh, U.zout, P.up1_dq[g].s);   // up1_dq.z == zout (model.hip)
       }
       y[0] = y[0] + stp[co];
       y[1] = y[1] + stp[64 + co];

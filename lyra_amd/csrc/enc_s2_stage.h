@@ -136,8 +136,8 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
       int o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int c8 = conv_code<MODE>(acc[j][e], M[j][e], sh[j][e], P.r0b.zout);
-        const float v = dequantize_f(c8, P.dq_r0) + XF[row * CS2 + at16(ch0 + 16 * j + e)];
+        const float v = conv_dequant<MODE>(acc[j][e], M[j][e], sh[j][e], P.r0b.zout, P.dq_r0.s) +   // dq_r0.z == zout (model.hip checks)
+                        XF[row * CS2 + at16(ch0 + 16 * j + e)];
         o[e] = quantize_code<MODE>(v, P.q_x1);
       }
       *reinterpret_cast<int*>(&QX[row * QS + ch0 + 16 * j]) = pack8(o[0], o[1], o[2], o[3]);

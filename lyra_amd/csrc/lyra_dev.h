@@ -159,9 +159,17 @@ __device__ __forceinline__ int32_t add_q(int32_t a, int32_t b, const AddQ& L) {
 // conv / depthwise / transpose-conv: q = RNE(clamp(float(acc) * scale)) + z.  `Mbits` carries the fp32 scale
 // (s_in * s_w[c]) / s_out in mode 2 and the Q31 multiplier otherwise (model.hip).  The clamp bounds are integers, so
 // clamp-then-round == round-then-clamp; v_rndne_f32 is round-to-nearest-even like lrintf / cvtps2dq.
+// Rounding by the magic number 1.5 * 2^23: for |v| < 2^22 the float sum v + 12582912.f is RNE(v) + 12582912 exactly (one
+// rounding, ties to even, like v_rndne_f32 / lrintf), and its bit pattern is 0x4B400000 + RNE(v).  v is clamped first (the
+// bounds are integers, so clamp-then-round == round-then-clamp): cvt, mul, med3, add, sub -- and when a table lookup
+// follows, the sub folds into the table's base address.
+__device__ __forceinline__ int32_t rne_clamped_code(float v, int32_t z) {
+  const float lo = (float)(-128 - z), hi = (float)(127 - z);
+  const float c = __builtin_amdgcn_fmed3f(v, lo, hi);   // one v_med3_f32 (v is never NaN: finite operands)
+  return __float_as_int(c + 12582912.f) - (0x4B400000 - z);
+}
 __device__ __forceinline__ int32_t xnn_requant(int32_t acc, int32_t Mbits, int32_t zout) {
-  const float v = (float)acc * __int_as_float(Mbits);
-  return clamp8((int32_t)__builtin_rintf(v) + zout);
+  return rne_clamped_code((float)acc * __int_as_float(Mbits), zout);
 }
 // the layers' requantisation in any mode -> clamped int8 code (as int)
 template <int MODE>
@@ -169,12 +177,23 @@ __device__ __forceinline__ int32_t conv_code(int32_t acc, int32_t M, int sh, int
   if constexpr (MODE == 2) return xnn_requant(acc, M, zout);
   else return clamp8(requant(acc, M, sh, MODE) + zout);
 }
-// f32 -> qs8 convert: RNE(x * (1 / s)) + z, clamped (reciprocal multiply, ties to even)
-__device__ __forceinline__ int32_t xnn_quantize(float x, const QP& Q) {
-  const float v = x * Q.rs;
-  const float lim = __builtin_fminf(__builtin_fmaxf(v, -1024.f), 1024.f);   // keep the int conversion in range
-  return clamp8((int32_t)__builtin_rintf(lim) + Q.z);
+// requantise and dequantise at once (a conv output that a DEQUANTIZE of the SAME tensor follows -- same zero point, model.hip
+// checks --: the graphs' int8 ->
+// fp32 hand-overs): in mode 2 the rounded, clamped value is already a float -- (c + magic) - magic, exact -- so the code
+// never has to exist as an integer: s * float(code - z) == s * RNE(clamp(v)).
+template <int MODE>
+__device__ __forceinline__ float conv_dequant(int32_t acc, int32_t M, int sh, int32_t zout, float s_dq) {
+  if constexpr (MODE == 2) {
+    const float lo = (float)(-128 - zout), hi = (float)(127 - zout);
+    const float c = __builtin_amdgcn_fmed3f((float)acc * __int_as_float(M), lo, hi);
+    const float r = (c + 12582912.f) - 12582912.f;          // RNE(c) = code - zout, still a float
+    return s_dq * r;
+  } else {
+    return dequantize_f(conv_code<MODE>(acc, M, sh, zout), s_dq, zout);
+  }
 }
+// f32 -> qs8 convert: RNE(x * (1 / s)) + z, clamped (reciprocal multiply, ties to even)
+__device__ __forceinline__ int32_t xnn_quantize(float x, const QP& Q) { return rne_clamped_code(x * Q.rs, Q.z); }
 template <int MODE>
 __device__ __forceinline__ int32_t quantize_code(float x, const QP& Q) {
   if constexpr (MODE == 2) return xnn_quantize(x, Q);

@@ -620,6 +620,10 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   }
   if (!pk.ok()) { *err = "weight container: " + pk.missing(); return false; }
   if (!B.stride_mismatch.empty()) { *err = "weight container: unexpected stride in " + B.stride_mismatch; return false; }
+  if (E2.dq_r0.z != E2.r0b.zout || D0.dq_r0.z != D0.cvq[0].zout) {   // a DEQUANTIZE reads the conv's own output tensor
+    *err = "weight container: a DEQUANTIZE's zero point differs from its producer's";
+    return false;
+  }
   if (!B.nonzero_dw_bias.empty()) {
     *err = "weight container: " + B.nonzero_dw_bias + " is not all zero (the kernels are specialised to bias-free fp32 depthwise layers)";
     return false;

@@ -18,8 +18,12 @@
 namespace lyra {
 
 __device__ __forceinline__ int sx8(int w, int i) { return (int)(int8_t)(w >> (8 * i)); }
+// the low bytes of four registers -> one dword: two v_perm_b32 (selector 0-3: bytes of the second operand, 4-7: of the
+// first, 0x0c: zero) and an or
 __device__ __forceinline__ int pack8(int a, int b, int c, int d) {
-  return (a & 255) | ((b & 255) << 8) | ((c & 255) << 16) | ((d & 255) << 24);
+  const unsigned lo = __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x0c0c0400u);
+  const unsigned hi = __builtin_amdgcn_perm((unsigned)d, (unsigned)c, 0x04000c0cu);
+  return (int)(lo | hi);
 }
 
 // ---- lookup tables (LDS) ----------------------------------------------------------------------------
