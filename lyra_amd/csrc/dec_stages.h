@@ -107,7 +107,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     const int b = min(b0 + s, B - 1);
     float f;
     if (feats) {
-      f = feats[(size_t)b * 64 + c];
+      f = *goff<const float>(feats + (size_t)b0 * 64, (uint32_t)(((b - b0) * 64 + c) * 4));
     } else {
       f = 0.f;
       // buffer addressing: resource = the codebook, voffset = this lane's channel, soffset = the row (scalar)
@@ -129,14 +129,14 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     int p4 = idx & 15, s = (idx >> 4) & (SD0 - 1), j = (idx >> 4) / SD0;
     int slot = (sphase[s] + j) & 1;
     *reinterpret_cast<f32x4*>(&FB[(j * 16 + s) * FS + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4);
+        *cx.at<const f32x4>(cx.soff(s) + (uint32_t)(st::D_HEAD + (slot * 64 + p4 * 4) * 4));
   }
   __syncthreads();
   for (int idx = tid; idx < SD0 * 16; idx += NTD0) {
     int p4 = idx & 15, s = idx >> 4;
     int slot = sphase[s] & 1;
     if (cx.valid(s))
-      *reinterpret_cast<f32x4*>(cx.sbase(s) + st::D_HEAD + (slot * 64 + p4 * 4) * 4) =
+      *cx.at<f32x4>(cx.soff(s) + (uint32_t)(st::D_HEAD + (slot * 64 + p4 * 4) * 4)) =
           *reinterpret_cast<const f32x4*>(&FB[(2 * 16 + s) * FS + p4 * 4]);
   }
   LYRA_TSTAMP(81);
@@ -174,10 +174,9 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     float told[2][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float LYRA_GLOBAL* stp =
-          as_global(reinterpret_cast<const float*>(cx.sbase((q & 1) * 4 + e) + st::D_UP0 + g * 512));
-      told[0][e] = stp[co];
-      told[1][e] = stp[64 + co];
+      const uint32_t stp = cx.soff((q & 1) * 4 + e) + (uint32_t)(st::D_UP0 + g * 512 + co * 4);
+      told[0][e] = *cx.at<const float>(stp);
+      told[1][e] = *cx.at<const float>(stp + 256);
     }
     gemm_i8<1, 8, 2>(H8, aoff, U.w + ((wave & 1) * 8) * 2 * 64, acc);
     fold_rows8<4>(acc[0]);   // lanes 32-63 take over this wave's second channel tile (N tiles 4..7)
@@ -187,14 +186,14 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = (q & 1) * 4 + e;
-        float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP0 + g * 512);
+        const uint32_t stp = cx.soff(s) + (uint32_t)(st::D_UP0 + g * 512 + co * 4);
         float y = conv_dequant<MODE>(acc[0][tap][e] + zf + bias, U.M, U.sh, U.zout, P.up0_dq[g].s);   // up0_dq.z == zout (model.hip)
         if (tap < 2) {
           y = y + told[tap < 2 ? tap : 0][e];
           XF[(tap * SD0 + s) * CS2 + pc] = y;
         } else {
           y = y + 0.f;
-          if (cx.valid(s)) stp[(tap - 2) * 64 + co] = y - sub;
+          if (cx.valid(s)) *cx.at<float>(stp + (uint32_t)((tap - 2) * 256)) = y - sub;
         }
       }
     }
@@ -208,8 +207,8 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   {
     const DwQ dq = P.dwq[0];
     const int w4 = tid & 63, s = tid >> 6;
-    uint8_t* hp = cx.sbase(s) + st::D_R0_0 + w4 * 4;
-    const int h0 = *reinterpret_cast<const int*>(hp), h1 = *reinterpret_cast<const int*>(hp + 256);
+    const uint32_t hp = cx.soff(s) + (uint32_t)(st::D_R0_0 + w4 * 4);
+    const int h0 = *cx.at<const int>(hp), h1 = *cx.at<const int>(hp + 256);
     int ww[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) ww[j] = *reinterpret_cast<const int LYRA_GLOBAL*>(&as_global(dq.w)[j * 256 + w4 * 4]);
@@ -237,7 +236,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
         o[e] = conv_code<MODE>(acc, dM[e], dsh[e], dq.zout);
       }
       *reinterpret_cast<int*>(&QD[(t * SD0 + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
-      if (cx.valid(s)) *reinterpret_cast<int*>(hp + t * 256) = a[t];
+      if (cx.valid(s)) *cx.at<int>(hp + (uint32_t)(t * 256)) = a[t];
     }
     __syncthreads();
     LYRA_TSTAMP(84);
@@ -312,7 +311,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
     for (int e = 0; e < 4; ++e) {
       int s = q * 4 + e;
       if (s >= SD0) continue;
-      float* stp = reinterpret_cast<float*>(cx.sbase(s) + st::D_UP1 + g * 512);
+      const uint32_t stp = cx.soff(s) + (uint32_t)(st::D_UP1 + g * 512 + co * 4);
       int o[6];
       o[0] = acc[0][0][e] + zf[0];
       o[1] = acc[0][1][e] + zf[1];
@@ -325,15 +324,15 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       for (int tau = 0; tau < 6; ++tau) {
         y[tau] = conv_dequant<MODE>(o[tau] + bias, U.M, U.sh, U.zout, P.up1_dq[g].s);   // up1_dq.z == zout (model.hip)
       }
-      y[0] = y[0] + stp[co];
-      y[1] = y[1] + stp[64 + co];
+      y[0] = y[0] + *cx.at<const float>(stp);
+      y[1] = y[1] + *cx.at<const float>(stp + 256);
 #pragma unroll
       for (int tau = 2; tau < 6; ++tau) y[tau] = y[tau] + 0.f;
       if (cx.valid(s)) {
 #pragma unroll
-        for (int tau = 0; tau < 4; ++tau) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = y[tau];
-        stp[co] = y[4] - sub;
-        stp[64 + co] = y[5] - sub;
+        for (int tau = 0; tau < 4; ++tau) *goff<float>(out0 + (size_t)b0 * 512, (uint32_t)(((s * 4 + tau) * 128 + pc) * 4)) = y[tau];
+        *cx.at<float>(stp) = y[4] - sub;
+        *cx.at<float>(stp + 256) = y[5] - sub;
       }
     }
   }
@@ -344,7 +343,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
 #endif
   if (tid < SD0 && cx.valid(tid)) {   // this region's ring phase
     int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+    *cx.at<int>(cx.soff(tid) + (uint32_t)(st::PHASE)) = ph >= st::PHASE_MOD ? 0 : ph;
   }
   l2_warm_sink(warm_cb, state, B);
   l2_warm_sink(warm, state, B);
@@ -427,17 +426,17 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
       const int s = (q_e & 1) * 4 + e;
       const float y0 = acc[0][j][e] + 0.f, y1 = acc[1][j][e] + 0.f;
       if (!cx.valid(s)) continue;
-      float* o = &out1[((size_t)(b0 + s) * 20 + 5 * (1 + blk) + jj) * 64 + pc];
+      float LYRA_GLOBAL* o = goff<float>(out1 + (size_t)b0 * 1280, (uint32_t)(((s * 20 + 5 * (1 + blk) + jj) * 64 + pc) * 4));
       o[0] = y0;                                   // block 1 | 2
       if (lo) o[10 * 64] = y1;                     // block 3
-      else reinterpret_cast<float*>(cx.sbase(s) + st::D_UP2)[jj * 64 + co] = y1 - sub;
+      else *cx.at<float>(cx.soff(s) + (uint32_t)(st::D_UP2 + (jj * 64 + co) * 4)) = y1 - sub;
     }
     if (lo) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = q_e * 4 + e;
         const float y = head[j][e] + SB[(jj * SD1 + s) * 72 + co];
-        if (cx.valid(s)) out1[((size_t)(b0 + s) * 20 + jj) * 64 + pc] = y;
+        if (cx.valid(s)) *goff<float>(out1 + (size_t)b0 * 1280, (uint32_t)(((s * 20 + jj) * 64 + pc) * 4)) = y;
       }
     }
   }
@@ -474,14 +473,14 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   const auto H0 = hist128_prefetch<SD1, NTD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
     int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
-    int b = min(b0 + s, B - 1);
+    int sb = min(s, B - 1 - b0);
     *reinterpret_cast<f32x4*>(&XB[(t * SD1 + s) * CS1 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
+        *goff<const f32x4>(in0 + (size_t)b0 * 512, (uint32_t)(((sb * 4 + t) * 128 + p4 * 4) * 4));
   }
   for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {   // carried tail: fetched with the input, used at the end
     int p4 = idx & 15, s = (idx >> 4) & (SD1 - 1), j = (idx >> 4) / SD1;
     *reinterpret_cast<f32x4*>(&SB[(j * SD1 + s) * 72 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::D_UP2 + (j * 64 + p4 * 4) * 4);
+        *cx.at<const f32x4>(cx.soff(s) + (uint32_t)(st::D_UP2 + (j * 64 + p4 * 4) * 4));
   }
   __syncthreads();
   LYRA_TSTAMP(51);
@@ -507,7 +506,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
 #endif
   if (tid < SD1 && cx.valid(tid)) {   // this region's ring phase
     int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+    *cx.at<int>(cx.soff(tid) + (uint32_t)(st::PHASE)) = ph >= st::PHASE_MOD ? 0 : ph;
   }
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);
@@ -551,8 +550,8 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / SD2, s = R & (SD2 - 1);
-      int b = min(b0 + s, B - 1);
-      xr[i][0][e] = in1[((size_t)b * 20 + t) * 64 + pcol];
+      int sb = min(s, B - 1 - b0);
+      xr[i][0][e] = *goff<const float>(in1 + (size_t)b0 * 1280, (uint32_t)(((sb * 20 + t) * 64 + pcol) * 4));
     }
   for (int idx = tid; idx < 7 * SD2 * 16; idx += NTD2) {
     int p4 = idx & 15, s = (idx >> 4) & (SD2 - 1), j = (idx >> 4) / SD2;
@@ -561,7 +560,7 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   }
   for (int idx = tid; idx < SD2 * 48; idx += NTD2) {
     int s = idx / 48, i = idx - s * 48;
-    SB[idx] = reinterpret_cast<const float*>(cx.sbase(s) + st::D_UP3)[i];
+    SB[idx] = *cx.at<const float>(cx.soff(s) + (uint32_t)(st::D_UP3 + i * 4));
   }
   LYRA_TSTAMP(61);
   resblocks64r<SD2, NTD2>(xr, XB + 3 * SD2 * CS0, cx, P.dw, P.pw, P.cv, st::D_R2_0, st::D_R2_1, st::D_R2_2);
@@ -600,9 +599,9 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
           float v = y * 32768.f;
           v = v < -32768.f ? -32768.f : v;
           v = v > 32767.f ? 32767.f : v;
-          pcm[(size_t)(b0 + s) * 320 + tau] = (int16_t)v;
+          *goff<int16_t>(pcm + (size_t)b0 * 320, (uint32_t)((s * 320 + tau) * 2)) = (int16_t)v;
         } else {
-          reinterpret_cast<float*>(cx.sbase(s) + st::D_UP3)[tau - 320] = y - P.up_sub;
+          *cx.at<float>(cx.soff(s) + (uint32_t)(st::D_UP3 + (tau - 320) * 4)) = y - P.up_sub;
         }
       }
   }

@@ -75,9 +75,9 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
 
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
-    int b = min(b0 + s, B - 1);
+    int sb = min(s, B - 1 - b0);
     *reinterpret_cast<f32x4*>(&XF[(t * S2 + s) * CS2 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(&in1[((size_t)b * 2 + t) * 256 + p4 * 4]);
+        *goff<const f32x4>(in1 + (size_t)b0 * 512, (uint32_t)(((sb * 2 + t) * 256 + p4 * 4) * 4));
   }
   __syncthreads();
 
@@ -91,7 +91,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
       int tau = t - (2 - j);
       f32x4 v;
       if (tau >= 0) v = lrelu4(*reinterpret_cast<const f32x4*>(&XF[(tau * S2 + s) * CS2 + p4 * 4]));
-      else v = *reinterpret_cast<const f32x4*>(cx.sbase(s) + st::E_R2_0 + ((2 + tau) * 256 + p4 * 4) * 4);
+      else v = *cx.at<const f32x4>(cx.soff(s) + (uint32_t)(st::E_R2_0 + ((2 + tau) * 256 + p4 * 4) * 4));
       acc = fma4(v, *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(&as_global(P.dw0.w)[j * 256 + p4 * 4]), acc);
     }
     *reinterpret_cast<f32x4*>(&DF[(t * S2 + s) * CS2 + p4 * 4]) = acc;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), j = (idx >> 6) / S2;
     if (cx.valid(s))
-      *reinterpret_cast<f32x4*>(cx.sbase(s) + st::E_R2_0 + (j * 256 + p4 * 4) * 4) =
+      *cx.at<f32x4>(cx.soff(s) + (uint32_t)(st::E_R2_0 + (j * 256 + p4 * 4) * 4)) =
           lrelu4(*reinterpret_cast<const f32x4*>(&XF[(j * S2 + s) * CS2 + p4 * 4]));
   }
   LYRA_TSTAMP(2);
@@ -162,13 +162,13 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
     *reinterpret_cast<int*>(&QB4[((2 + t) * S2 + s) * QS + w4 * 4]) =
         lut8w(LQ + 5 * 256, w);
     *reinterpret_cast<int*>(&QB4[(t * S2 + s) * QS + w4 * 4]) =
-        *reinterpret_cast<const int*>(cx.sbase(s) + st::E_D2 + t * 256 + w4 * 4);
+        *cx.at<const int>(cx.soff(s) + (uint32_t)(st::E_D2 + t * 256 + w4 * 4));
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
     int w4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
     if (cx.valid(s))
-      *reinterpret_cast<int*>(cx.sbase(s) + st::E_D2 + t * 256 + w4 * 4) =
+      *cx.at<int>(cx.soff(s) + (uint32_t)(st::E_D2 + t * 256 + w4 * 4)) =
           *reinterpret_cast<const int*>(&QB4[((2 + t) * S2 + s) * QS + w4 * 4]);
   }
   LYRA_TSTAMP(7);
@@ -184,7 +184,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
     int w4 = idx & 127, s = (idx >> 7) & (S2 - 1), j = (idx >> 7) / S2;
     int slot = (sphase[s] + j) & 1;
     *reinterpret_cast<int*>(&QC[(j * S2 + s) * QS5 + w4 * 4]) =
-        *reinterpret_cast<const int*>(cx.sbase(s) + st::E_BOTT + slot * 512 + w4 * 4);
+        *cx.at<const int>(cx.soff(s) + (uint32_t)(st::E_BOTT + slot * 512 + w4 * 4));
   }
   fold_rows8<2>(dacc[0]);   // lanes 32-63 take over N tiles 2, 3
 #pragma unroll
@@ -203,7 +203,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
     int w4 = idx & 127, s = idx >> 7;
     int slot = sphase[s] & 1;
     if (cx.valid(s))
-      *reinterpret_cast<int*>(cx.sbase(s) + st::E_BOTT + slot * 512 + w4 * 4) =
+      *cx.at<int>(cx.soff(s) + (uint32_t)(st::E_BOTT + slot * 512 + w4 * 4)) =
           *reinterpret_cast<const int*>(&QC[(2 * S2 + s) * QS5 + w4 * 4]);
   }
   LYRA_TSTAMP(8);
@@ -220,7 +220,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
       int s = q * 4 + e;
       int c8 = conv_code<MODE>(acc[0][0][e] + bias, M, sh, P.bott.zout);
       if (s < S2 && cx.valid(s)) {
-        feats[(size_t)(b0 + s) * 64 + n] = dequantize_f(c8, P.out);
+        *goff<float>(feats + (size_t)b0 * 64, (uint32_t)((s * 64 + n) * 4)) = dequantize_f(c8, P.out);
         if (codes_dbg) codes_dbg[(size_t)(b0 + s) * 64 + n] = (float)c8;
       }
     }
@@ -230,7 +230,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   LYRA_WG_END();
   if (tid < S2 && cx.valid(tid)) {
     int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(cx.sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+    *cx.at<int>(cx.soff(tid) + (uint32_t)(st::PHASE)) = ph >= st::PHASE_MOD ? 0 : ph;
   }
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);

@@ -56,7 +56,9 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   const auto warm = l2_warm<NT0, 1>(P.warm);
   const auto warm_code = code_warm<NT0>(code_bytes);
   LYRA_SYNC_KEEP();
-  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)max(sids[s], 0) * st::E0_BYTES; };
+  // uniform base + 32-bit per-lane offset (TileCtx::at): scalar-base global accesses, 32-bit address arithmetic
+  auto soff = [&](int s) -> uint32_t { return (uint32_t)max(sids[s], 0) * (uint32_t)st::E0_BYTES; };
+  auto gat = [&](uint32_t o) -> uint8_t LYRA_GLOBAL* { return (uint8_t LYRA_GLOBAL*)state + o; };
   auto valid = [&](int s) -> bool { return b0 + s < B && sids[s] >= 0; };   // id -1 = masked slot (TileCtx::valid)
 
   // The 5 history rows of the strided conv (needed only in phase D/E) are requested together with the PCM so
@@ -67,7 +69,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
     const int idx = tid + k * NT0;
     const int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
     halo[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (idx < 5 * S0 * 16) halo[k] = *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D0 + (j * 64 + p4 * 4) * 4);
+    if (idx < 5 * S0 * 16) halo[k] = *(const f32x4 LYRA_GLOBAL*)gat(soff(s) + (uint32_t)(st::E_D0 + (j * 64 + p4 * 4) * 4));
   }
 
   // ---- A. window = [48 history samples | 320 new samples] / 32768, AT16 order ----------------
@@ -76,12 +78,12 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
     int s = idx / 46, v = idx - s * 46;
     float x[8];
     if (v < 6) {
-      const f32x4* h = reinterpret_cast<const f32x4*>(sbase(s) + st::E_FIRST) + v * 2;
+      const f32x4 LYRA_GLOBAL* h = (const f32x4 LYRA_GLOBAL*)gat(soff(s) + (uint32_t)(st::E_FIRST + v * 32));
       f32x4 a = h[0], b = h[1];
       x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
     } else {
-      int b = min(b0 + s, B - 1);
-      i32x4 w = *reinterpret_cast<const i32x4*>(pcm + (size_t)b * 320 + (v - 6) * 8);
+      int sb = min(s, B - 1 - b0);
+      i32x4 w = *goff<const i32x4>(pcm + (size_t)b0 * 320, (uint32_t)(sb * 640 + (v - 6) * 16));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {  // Int16ToUnitScalar, dsp_utils.h:106-108
         x[2 * e] = (float)(int16_t)(w[e] & 0xffff) * (1.0f / 32768.0f);
@@ -94,7 +96,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   __syncthreads();
   for (int idx = tid; idx < S0 * 48; idx += NT0) {
     int s = idx / 48, i = idx - s * 48;
-    if (valid(s)) reinterpret_cast<float*>(sbase(s) + st::E_FIRST)[i] = PB[s * PBS + at16(320 + i)];
+    if (valid(s)) *(float LYRA_GLOBAL*)gat(soff(s) + (uint32_t)(st::E_FIRST + i * 4)) = PB[s * PBS + at16(320 + i)];
   }
   LYRA_TSTAMP(1);
 
@@ -135,7 +137,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   for (int idx = tid; idx < 5 * S0 * 16; idx += NT0) {
     int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;
     if (valid(s))
-      *reinterpret_cast<f32x4*>(sbase(s) + st::E_D0 + (j * 64 + p4 * 4) * 4) =
+      *(f32x4 LYRA_GLOBAL*)gat(soff(s) + (uint32_t)(st::E_D0 + (j * 64 + p4 * 4) * 4)) =
           *reinterpret_cast<const f32x4*>(&XB[((20 + j) * S0 + s) * CS0 + p4 * 4]);
   }
   LYRA_TSTAMP(4);
@@ -160,7 +162,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int R = i * 16 + q * 4 + e, tau = R / S0, s = R & (S0 - 1);
-          if (valid(s)) out0[((size_t)(b0 + s) * 4 + tau) * 128 + pc] = acc[i][j][e];
+          if (valid(s)) *goff<float>(out0 + (size_t)b0 * 512, (uint32_t)(((s * 4 + tau) * 128 + pc) * 4)) = acc[i][j][e];
         }
     }
   }
@@ -197,21 +199,22 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   const auto warm = l2_warm<NT1, 2>(P.warm);
   const auto warm_code = code_warm<NT1>(code_bytes);
   LYRA_SYNC_KEEP();
-  auto sbase = [&](int s) -> uint8_t* { return state + (size_t)max(sids[s], 0) * st::E1_BYTES; };
+  auto soff = [&](int s) -> uint32_t { return (uint32_t)max(sids[s], 0) * (uint32_t)st::E1_BYTES; };
+  auto gat = [&](uint32_t o) -> uint8_t LYRA_GLOBAL* { return (uint8_t LYRA_GLOBAL*)state + o; };
   auto valid = [&](int s) -> bool { return b0 + s < B && sids[s] >= 0; };
 
   TileCtx cx{state, sids, sphase, B - b0, st::E1_BYTES};
   const auto H0 = hist128_prefetch<S1, NT1>(cx, 1, st::E_R1_0);   // first block's history: same round trip as the input
   for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
-    int b = min(b0 + s, B - 1);
+    int sb = min(s, B - 1 - b0);
     *reinterpret_cast<f32x4*>(&XB[((2 + t) * S1 + s) * CS1 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(&in0[((size_t)b * 4 + t) * 128 + p4 * 4]);
+        *goff<const f32x4>(in0 + (size_t)b0 * 512, (uint32_t)(((sb * 4 + t) * 128 + p4 * 4) * 4));
   }
   for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {   // strided conv's 2 history rows: fetched with the input
     int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), j = (idx >> 5) / S1;
     *reinterpret_cast<f32x4*>(&XB[(j * S1 + s) * CS1 + p4 * 4]) =
-        *reinterpret_cast<const f32x4*>(sbase(s) + st::E_D1 + (j * 128 + p4 * 4) * 4);
+        *(const f32x4 LYRA_GLOBAL*)gat(soff(s) + (uint32_t)(st::E_D1 + (j * 128 + p4 * 4) * 4));
   }
   __syncthreads();
 
@@ -228,7 +231,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {
     int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), j = (idx >> 5) / S1;
     if (valid(s))
-      *reinterpret_cast<f32x4*>(sbase(s) + st::E_D1 + (j * 128 + p4 * 4) * 4) =
+      *(f32x4 LYRA_GLOBAL*)gat(soff(s) + (uint32_t)(st::E_D1 + (j * 128 + p4 * 4) * 4)) =
           *reinterpret_cast<const f32x4*>(&XB[((4 + j) * S1 + s) * CS1 + p4 * 4]);
   }
 
@@ -251,7 +254,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int R = i * 16 + q * 4 + e, tau = R / S1, s = R & (S1 - 1);
-          if (valid(s)) out1[((size_t)(b0 + s) * 2 + tau) * 256 + pc] = acc[i][j][e];
+          if (valid(s)) *goff<float>(out1 + (size_t)b0 * 512, (uint32_t)(((s * 2 + tau) * 256 + pc) * 4)) = acc[i][j][e];
         }
     }
   }
@@ -259,7 +262,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   LYRA_WSTAMP(103);
   if (tid < S1 && valid(tid)) {   // this region's ring phase (every thread read it into LDS before the first barrier)
     int ph = sphase[tid] + 1;
-    *reinterpret_cast<int*>(sbase(tid) + st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
+    *(int LYRA_GLOBAL*)gat(soff(tid) + (uint32_t)st::PHASE) = ph >= st::PHASE_MOD ? 0 : ph;
   }
   l2_warm_sink(warm, state, B);
   l2_warm_sink(warm_code, state, B);

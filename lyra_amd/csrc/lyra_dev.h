@@ -220,6 +220,22 @@ template <class T>
 __device__ __forceinline__ const T LYRA_GLOBAL* as_global(const T* p) {
   return (const T LYRA_GLOBAL*)p;
 }
+// A pointer every lane of the wave holds the same value of (a weight fragment base: it depends on the wave's index and on
+// kernel parameters only), moved to SGPRs: the loads through it then take the scalar-base form
+// `global_load ..., v_lane_offset, s[base:base+1]`, and stepping from K chunk to K chunk is scalar arithmetic instead of a
+// 64-bit vector add per load (the chunks are 1 KB apart, beyond the instruction's immediate offset after four of them).
+// base (wave-uniform: a kernel argument advanced by a tile offset) + a 32-bit per-lane BYTE offset, as a global pointer:
+// the access takes the scalar-base form and the lane arithmetic stays 32-bit.  Every buffer of the path is < 4 GB.
+template <class T, class U>
+__device__ __forceinline__ T LYRA_GLOBAL* goff(U* base, uint32_t byte_off) {
+  return (T LYRA_GLOBAL*)((uint8_t LYRA_GLOBAL*)base + byte_off);
+}
+template <class T>
+__device__ __forceinline__ const T LYRA_GLOBAL* wave_uniform(const T* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const T LYRA_GLOBAL*)(((uint64_t)hi << 32) | lo);
+}
 
 // Experiments on how co-resident workgroups share a SIMD (build flags, see DESIGN.md "what was tried"):
 //   LYRA_PRIO_MFMA   raise the wave's priority around every MFMA cluster (guide T5)
@@ -273,7 +289,7 @@ template <int MTW, int NTW, int KC, int KS, int INIT, int PF, class AOff>
 __device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                               f32x4 (&acc)[MTW][NTW], const f32x4 (&init)[NTW]) {
   const int lane = threadIdx.x & 63;
-  const f32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic) + lane;
+  const f32x4 LYRA_GLOBAL* bbase = wave_uniform(bfrag_generic);
   if (INIT == 2) {   // the splat lives in the LAST M tile's accumulator: the first MFMA of tile i reads it from there and
                      // tile MTW - 1 (issued last) overwrites it in place -- no register beyond the accumulators themselves
 #pragma unroll
@@ -284,7 +300,7 @@ __device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, cons
   for (int p = 0; p < PF; ++p)
     if (p < KC) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[p][j] = bfrag[(j * KS + LYRA_WCHUNK(p)) * 64];
+      for (int j = 0; j < NTW; ++j) bq[p][j] = bbase[(j * KS + LYRA_WCHUNK(p)) * 64 + lane];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[p][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, p));
     }
@@ -293,7 +309,7 @@ __device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, cons
     if (c + PF < KC) {
       const int sl = (c + PF) % (PF + 1);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[sl][j] = bfrag[(j * KS + LYRA_WCHUNK(c + PF)) * 64];
+      for (int j = 0; j < NTW; ++j) bq[sl][j] = bbase[(j * KS + LYRA_WCHUNK(c + PF)) * 64 + lane];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[sl][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, c + PF));
     }
@@ -352,7 +368,7 @@ template <int MTW, int NTW, int KC, class AOff>
 __device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32x4* bfrag_generic,
                                         i32x4 (&acc)[MTW][NTW]) {
   const int lane = threadIdx.x & 63;
-  const i32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic);
+  const i32x4 LYRA_GLOBAL* bfrag = wave_uniform(bfrag_generic);
 #pragma unroll
   for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -381,7 +397,7 @@ __device__ __forceinline__ void gemm_i8(const int8_t* lds, AOff a_off, const i32
 template <int NTW, int KC, class AOff>
 __device__ __forceinline__ void gemm_i8_t(const int8_t* lds, AOff a_off, const i32x4* bfrag_generic, i32x4 (&acc)[NTW]) {
   const int lane = threadIdx.x & 63;
-  const i32x4 LYRA_GLOBAL* bfrag = as_global(bfrag_generic);
+  const i32x4 LYRA_GLOBAL* bfrag = wave_uniform(bfrag_generic);
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     i32x4 w[NTW];

@@ -61,13 +61,13 @@ __device__ __forceinline__ RbqPre resblock_q_prefetch(const TileCtx& cx, int d, 
   const int R2 = 2 * d;
   const int base = (cx.sphase[s] * 2) % R2;
   RbqPre p;
-  const uint8_t* hp = cx.sbase(s) + off + w4 * 4;
+  const uint32_t hp = cx.soff(s) + (uint32_t)(off + w4 * 4);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     int r1 = base + t + d;
     r1 = r1 >= R2 ? r1 - R2 : r1;
-    p.h[t][0] = *reinterpret_cast<const int*>(hp + (base + t) * 256);   // row t - 2d (about to be replaced)
-    p.h[t][1] = *reinterpret_cast<const int*>(hp + r1 * 256);
+    p.h[t][0] = *cx.at<const int>(hp + (uint32_t)((base + t) * 256));   // row t - 2d (about to be replaced)
+    p.h[t][1] = *cx.at<const int>(hp + (uint32_t)(r1 * 256));
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) p.ww[j] = *reinterpret_cast<const int LYRA_GLOBAL*>(&as_global(dq.w)[j * 256 + w4 * 4]);
@@ -97,12 +97,12 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
   LYRA_TSTAMP(tb + 0);
   {  // a = LeakyReLU(X); depthwise over [a(t-2d), a(t-d), a(t)]; the ring row t-2d is replaced by a(t)
     const int base = (cx.sphase[s] * 2) % R2;
-    uint8_t* hp = cx.sbase(s) + off + w4 * 4;
+    const uint32_t hp = cx.soff(s) + (uint32_t)(off + w4 * 4);
     const bool valid = cx.valid(s);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int a = lut8w(la, *reinterpret_cast<const int*>(&QX[(t * S + s) * QS + w4 * 4]));
-      if (valid) *reinterpret_cast<int*>(hp + (base + t) * 256) = a;
+      if (valid) *cx.at<int>(hp + (uint32_t)((base + t) * 256)) = a;
       const int x[3] = {pre.h[t][0], pre.h[t][1], a};
       int o[4];
 #pragma unroll

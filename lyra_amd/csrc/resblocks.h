@@ -25,6 +25,20 @@ struct TileCtx {
   __device__ __forceinline__ uint8_t* sbase(int s) const { return state + (size_t)max(sids[s], 0) * stride; }
 #endif
   __device__ __forceinline__ bool valid(int s) const { return s < nvalid && sids[s] >= 0; }
+  // The same address as sbase(s) + byte_off, formed as UNIFORM base + 32-bit per-lane offset (a region is at most
+  // max_streams x 15 KB < 4 GB): the access takes the scalar-base form `global_load v, v_off, s[base:base+1]` and the
+  // per-lane address arithmetic is 32-bit (one v_add_u32 where the 64-bit form needs v_lshl_add_u64 / add + addc pairs).
+  __device__ __forceinline__ uint32_t soff(int s) const {
+#ifdef LYRA_STATE_ALIAS
+    return (uint32_t)(max(sids[s], 0) & 63) * (uint32_t)stride;
+#else
+    return (uint32_t)max(sids[s], 0) * (uint32_t)stride;
+#endif
+  }
+  template <class T>
+  __device__ __forceinline__ T LYRA_GLOBAL* at(uint32_t byte_off) const {
+    return (T LYRA_GLOBAL*)((uint8_t LYRA_GLOBAL*)state + byte_off);
+  }
 };
 
 // Requests one word of every 128-byte line of [off, off + bytes) of the tile's S streams (one load per thread): state a
@@ -38,7 +52,7 @@ __device__ __forceinline__ uint32_t state_touch(const TileCtx& cx, int off, int 
   uint32_t tok = 0;
   if (idx < S * n) {
     const int s = idx / n, l = idx - s * n;
-    tok = *reinterpret_cast<const uint32_t*>(cx.sbase(s) + ((l0 + l) << 7));
+    tok = *cx.at<const uint32_t>(cx.soff(s) + (uint32_t)((l0 + l) << 7));
   }
   return tok;
 }
@@ -87,16 +101,16 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     static_assert(RSTEP % S == 0, "one stream per thread");
     constexpr int TSTEP = RSTEP / S;
     const int sq = rq & (S - 1), tq = rq / S;
-    const char LYRA_GLOBAL* hb0 = as_global(reinterpret_cast<const char*>(cx.sbase(sq) + off)) + (tq * 64 + p4 * 4) * 4;
-    const char LYRA_GLOBAL* hb1 = hb0 + d * 256;
+    const uint32_t hb0 = cx.soff(sq) + (uint32_t)(off + (tq * 64 + p4 * 4) * 4);
+    const uint32_t hb1 = hb0 + (uint32_t)(d * 256);
     f32x4 h0[5], h1[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const int t = tq + k * TSTEP;
       h0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       h1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (t < 2 * d) h0[k] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hb0 + k * TSTEP * 256);
-      if (t < d) h1[k] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hb1 + k * TSTEP * 256);
+      if (t < 2 * d) h0[k] = *cx.at<const f32x4>(hb0 + k * TSTEP * 256);
+      if (t < d) h1[k] = *cx.at<const f32x4>(hb1 + k * TSTEP * 256);
     }
     // 1. a = lrelu(X) -> A
 #pragma unroll
@@ -140,7 +154,7 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     for (int k = 0; k < 5; ++k) {
       f32x4* item = reinterpret_cast<f32x4*>(&A[(rq + k * RSTEP) * CS + p4 * 4]);
       const int j = tq + k * TSTEP - (20 - R2);
-      if (j >= 0 && cx.valid(sq)) *reinterpret_cast<f32x4*>(cx.sbase(sq) + off + (j * 64 + p4 * 4) * 4) = *item;
+      if (j >= 0 && cx.valid(sq)) *cx.at<f32x4>(cx.soff(sq) + (uint32_t)(off + (j * 64 + p4 * 4) * 4)) = *item;
       *item = dreg[k];
     }
     __syncthreads();
@@ -188,7 +202,7 @@ __device__ __forceinline__ Hist128<1024 / NT> hist128_prefetch(const TileCtx& cx
   const int R2 = 2 * d;
   const bool ring = R2 > 4;
   const int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
-  const float LYRA_GLOBAL* hp = as_global(reinterpret_cast<const float*>(cx.sbase(s) + off)) + p4 * 4;
+  const uint32_t hp = cx.soff(s) + (uint32_t)(off + p4 * 16);
   Hist128<RPT> H;
 #pragma unroll
   for (int k = 0; k < RPT; ++k)
@@ -199,7 +213,7 @@ __device__ __forceinline__ Hist128<1024 / NT> hist128_prefetch(const TileCtx& cx
       if (tau < 0) {
         int row = R2 + tau;
         if (ring) { row = base + tau + R2; row = row >= R2 ? row - R2 : row; }
-        H.h[k][j] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(hp + row * 128);
+        H.h[k][j] = *cx.at<const f32x4>(hp + (uint32_t)(row * 512));
       }
     }
   return H;
@@ -234,7 +248,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
       const f32x4 w0 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww);
       const f32x4 w1 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 128);
       const f32x4 w2 = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(dww + 256);
-      float* hp = reinterpret_cast<float*>(cx.sbase(s) + off) + p4 * 4;
+      const uint32_t hp = cx.soff(s) + (uint32_t)(off + p4 * 16);
       const int base = ring ? (cx.sphase[s] * 4) % R2 : 0;
       const bool valid = cx.valid(s);
       const float* xq = &X[s * CS + p4 * 4];   // this thread's quad of row t at xq[t * S * CS]
@@ -254,9 +268,9 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
           if (ring) {
             int row = base + t;
             row = row >= R2 ? row - R2 : row;
-            *reinterpret_cast<f32x4*>(hp + row * 128) = a;
+            *cx.at<f32x4>(hp + (uint32_t)(row * 512)) = a;
           } else if (t >= 2) {
-            *reinterpret_cast<f32x4*>(hp + (t - 2) * 128) = a;
+            *cx.at<f32x4>(hp + (uint32_t)((t - 2) * 512)) = a;
           }
         }
       }
