@@ -125,6 +125,7 @@ struct lyra_hip_ctx {
   size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
   int tile_div[6] = {1, 1, 1, 1, 1, 1};   // tiles per workgroup of each stage kernel (LYRA_TILE_LOOP), see tile_div()
   bool chunk_local = false;                       // see wait_encode_side
+  uint32_t cu_pat[4] = {0, 0, 0, 0};              // CU mask pattern of the e / d / q / n streams (0: none), see make_stream_kind
   int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
   int last_B_enc = 0, last_B_dec = 0;
   // optional per-kernel timing with HIP events on the launching stream (bench.py roofline leg)
@@ -252,6 +253,19 @@ int check_ids_host(lyra_hip_ctx* c, const int32_t* ids, int B) {
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// A stream of kind e / d / q / n (0..3): with the kind's CU mask when one is configured (no priority then: the masked
+// streams do not compete for CUs), else with the given priority.
+hipError_t make_stream_kind(lyra_hip_ctx* c, hipStream_t* s, int kind, int priority) {
+  if (!c->cu_pat[kind]) return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority);
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu <= 0) ncu = 256;
+  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, c->cu_pat[kind]);
+  if (hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
+  (void)hipGetLastError();   // a runtime / partition mode without CU masking: an ordinary stream (placement is then left to the dispatcher)
+  c->cu_pat[kind] = 0;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority);
+}
 
 // EXPERIMENT hook (occupancy): LYRA_HIP_LDS_PAD_<kernel>=bytes asks for that much extra dynamic LDS per workgroup of a
 // stage kernel, i.e. fewer of its workgroups per CU and more room for the kernel running beside it.
@@ -739,10 +753,26 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     for (int i = 0; i < 3; ++i) prio[i] = v[i] >= 2 ? prio_hi : (v[i] == 1 ? (prio_lo + prio_hi) / 2 : prio_lo);
   }
   const unsigned evflags = hipEventDisableTiming | (getenv("LYRA_HIP_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+  // CU partitioning (tools/placement_probe.hip, profiles/r04_placement_probe.txt): two concurrent dispatches of <= 256
+  // workgroups are placed independently of each other -- of 2 x 128 workgroups 68 CUs get two and 68 none -- and a stage
+  // kernel lasts as long as its slowest tile.  Streams created with complementary CU masks keep the chains apart.
+  // The pattern is 32 bits repeated over the chip's CU mask; 0x00ff00ff / 0xff00ff00 give each side half of every XCD
+  // whether the runtime numbers the mask bits XCC-major or interleaved (probe: 2 x 128 workgroups on 256 distinct CUs).
+  // Measured (profiles/r04_cumask_batch_sweep.txt): +10-14 % at 256-1,024 streams, +2-5 % at 2,048 (whole tiles per CU on
+  // both halves), -4...-17 % at 1,536 and from 2,560 up (each chain then wants the whole chip in turn).  The choice is made
+  // once, from max_streams: a context for at most 1,024 streams runs the extractor + quantizer on one half of every XCD
+  // and the decoder + noise estimator on the other.  A masked stream has no priority (the chains no longer compete) and,
+  // created through hipExtStreamCreateWithCUMask, is a blocking stream with respect to the NULL stream.
+  if (max_streams <= 1024) { c->cu_pat[0] = c->cu_pat[2] = 0x00ff00ffu; c->cu_pat[1] = c->cu_pat[3] = 0xff00ff00u; }
+  if (const char* m = getenv("LYRA_HIP_CU_MASKS")) {   // "e,d,q,n" hex patterns; "0": none
+    c->cu_pat[0] = c->cu_pat[1] = c->cu_pat[2] = c->cu_pat[3] = 0;
+    sscanf(m, "%x,%x,%x,%x", &c->cu_pat[0], &c->cu_pat[1], &c->cu_pat[2], &c->cu_pat[3]);
+  }
+  auto make_stream = [&](hipStream_t* s, int kind, int priority) { return make_stream_kind(c, s, kind, priority); };
   for (int k = 0; k < c->nsub; ++k)
-    if (hipStreamCreateWithPriority(&c->se[k], hipStreamNonBlocking, prio[0]) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->sd[k], hipStreamNonBlocking, prio[1]) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->sq[k], hipStreamNonBlocking, prio[2]) != hipSuccess ||
+    if (make_stream(&c->se[k], 0, prio[0]) != hipSuccess ||
+        make_stream(&c->sd[k], 1, prio[1]) != hipSuccess ||
+        make_stream(&c->sq[k], 2, prio[2]) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[0][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[1][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_encs[2][k], evflags) != hipSuccess ||
@@ -750,7 +780,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
         hipEventCreateWithFlags(&c->ev_dec[0][k], evflags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_dec[1][k], evflags) != hipSuccess)
       return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
-  if (hipStreamCreateWithPriority(&c->sn, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+  if (make_stream(&c->sn, 3, prio_lo) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_noise[0], evflags) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_noise[1], evflags) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_rs_in[0], evflags) != hipSuccess ||
