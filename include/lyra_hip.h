@@ -51,7 +51,17 @@
  * i+2 is ordered after the decode that read it at step i.  A caller that
  * reuses ONE buffer set must lyra_hip_synchronize() (or lyra_hip_set_serial)
  * between steps.
- * The library streams are hipStreamNonBlocking: they do NOT order against the
+ * Small contexts (max_streams <= 1024) partition the chip: the encode-side and
+ * quantizer streams run on one half of every XCD's CUs, the decode-side and
+ * noise-estimator streams on the other (CU-masked streams).  At such batches a
+ * stage kernel is 64-256 workgroups on 256 CUs and two concurrent dispatches
+ * are placed independently of each other -- some CUs get two tiles, some none,
+ * and a kernel lasts as long as its slowest tile; kept apart, config #2
+ * (1,024 streams) gains 10 %.  Larger contexts share the whole chip (each chain
+ * wants all of it in turn); LYRA_HIP_CU_MASKS overrides either way.
+ * The library streams are hipStreamNonBlocking (CU-masked ones, created through
+ * hipExtStreamCreateWithCUMask, are ordinary blocking streams with respect to
+ * the NULL stream): they do NOT order against the
  * null stream or any stream of the caller.  A `_dev` caller that produces
  * inputs or consumes outputs on its own stream brackets the calls with
  * lyra_hip_wait_for_stream(ctx, s) (library work enqueued afterwards waits
@@ -116,13 +126,17 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  *                            Calls that are not split (resample, noise estimator,
  *                            small batches ...) are ordered after every chunk of
  *                            the split call before them and vice versa;
- *   LYRA_HIP_FUSED=<mask>    bit 0: the encoder side (extract / encode) as one
- *                            launch instead of three, bit 1: the decoder side
- *                            likewise (slower at B = 4096; default 0);
+ *   LYRA_HIP_FUSED=<mask>    (variant build `make parked` only) bit 0: the encoder side as one
+ *                            launch instead of three, bit 1: the decoder side likewise, bit 2: encoder
+ *                            stages 1 + 2 as one launch, bit 3: decoder stages 0 + 1 (all slower at
+ *                            B = 4096; default 0);
  *   LYRA_HIP_RVQ_WIDE=1      the 104 KB / 244-VGPR quantizer kernel;
  *   LYRA_HIP_FLAT_PRIO=1     all library streams at the same priority;
  *   LYRA_HIP_EVENT_FENCE=1   internal events with system-scope fences;
  *   LYRA_HIP_NO_CODE_WARM=1  skip the stage kernels' instruction pre-fetch;
+ *   LYRA_HIP_CU_MASKS=e,d,q,n  CU-mask patterns (32-bit hex, repeated over the chip) of the encode / decode / quantizer /
+ *                            noise streams; 0 = no mask (default: 00ff00ff,ff00ff00,00ff00ff,ff00ff00 when
+ *                            max_streams <= 1024, none above);
  *   LYRA_HIP_PRIO=e,d,q      stream priorities of the encode / decode / quantizer streams (0 lowest .. 2 highest);
  *   LYRA_HIP_TILE_DIV_<K>=k  launch stage kernel K (ENC_S0 .. DEC_S2) as k slices of its tiles,
  *   LYRA_HIP_LDS_PAD_<K>=b   give its workgroups b extra bytes of LDS (occupancy experiments). */

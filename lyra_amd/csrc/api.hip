@@ -536,6 +536,17 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
     for (int nt = cdiv(B, enc_s0_streams_per_wg()), g = cdiv(nt, c->tile_div[0]), t0 = 0; t0 < nt; t0 += g)
       hipLaunchKernelGGL(enc_s0_kernel, dim3(std::min(g, nt - t0)), dim3(enc_s0_threads()), enc_s0_lds_bytes() + c->lds_pad[0], st_,
                          M.d_enc0, d_pcm, d_ids, B, c->sm.base[st::R_E0], e0, c->cw[K_ENC_S0], t0); }
+#ifdef LYRA_PARKED
+  if ((c->fused & 4) && c->mode == 2) {   // stages 1 + 2 in one launch
+    for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
+    { ProfScope ps(c, K_ENC_S1, st_);
+      hipLaunchKernelGGL(enc_s12_xn_kernel, dim3(cdiv(B, 8)), dim3(512), enc_s12_lds_bytes(), st_, M.d_enc1, M.d_enc2, e0, d_ids, B,
+                         c->sm.base[st::R_E1], c->sm.base[st::R_E2], e1, d_feat, codes, c->cw[K_ENC_S1]); }
+    HIPCHK(c, hipGetLastError());
+    c->last_B_enc = B;
+    return 0;
+  }
+#endif
   { ProfScope ps(c, K_ENC_S1, st_);
     for (int nt = cdiv(B, enc_s1_streams_per_wg()), g = cdiv(nt, c->tile_div[1]), t0 = 0; t0 < nt; t0 += g)
       hipLaunchKernelGGL(enc_s1_kernel, dim3(std::min(g, nt - t0)), dim3(enc_s1_threads()), enc_s1_lds_bytes() + c->lds_pad[1], st_,
@@ -589,6 +600,19 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
       hipLaunchKernelGGL(c->mode == 2 ? dec_side_xn_kernel : c->mode ? dec_side_dr_kernel : dec_side_kernel, dim3(cdiv(B, 8)), dim3(512), dec_side_lds_bytes(), st_,
                          M.d_dec0, M.d_dec1, M.d_dec2, d_feat, d_ids, B, c->sm.base[st::R_D0], c->sm.base[st::R_D1],
                          c->sm.base[st::R_D2], d0, d1, d_pcm, d_pkt, num_stages, M.cb, c->cw[K_DEC_SIDE]); }
+    HIPCHK(c, hipGetLastError());
+    c->last_B_dec = B;
+    return 0;
+  }
+#endif
+#ifdef LYRA_PARKED
+  if ((c->fused & 8) && c->mode == 2) {   // stages 0 + 1 in one launch
+    { ProfScope ps(c, K_DEC_S0, st_);
+      hipLaunchKernelGGL(dec_s01_xn_kernel, dim3(cdiv(B, 8)), dim3(512), dec_s01_lds_bytes(), st_, M.d_dec0, M.d_dec1, d_feat, d_ids, B,
+                         c->sm.base[st::R_D0], c->sm.base[st::R_D1], d0, d1, d_pkt, num_stages, M.cb, c->cw[K_DEC_S0]); }
+    { ProfScope ps(c, K_DEC_S2, st_);
+      hipLaunchKernelGGL(dec_s2_kernel, dim3(cdiv(B, dec_s2_streams_per_wg())), dim3(dec_s2_threads()), dec_s2_lds_bytes() + c->lds_pad[5], st_,
+                         M.d_dec2, d1, d_ids, B, c->sm.base[st::R_D2], d_pcm, c->cw[K_DEC_S2], 0); }
     HIPCHK(c, hipGetLastError());
     c->last_B_dec = B;
     return 0;
@@ -811,6 +835,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       set_lds(enc_side_dr_kernel, enc_side_lds_bytes()) != hipSuccess || set_lds(dec_side_kernel, dec_side_lds_bytes()) != hipSuccess ||
       set_lds(dec_side_dr_kernel, dec_side_lds_bytes()) != hipSuccess ||
       set_lds(enc_side_xn_kernel, enc_side_lds_bytes()) != hipSuccess || set_lds(dec_side_xn_kernel, dec_side_lds_bytes()) != hipSuccess ||
+      set_lds(enc_s12_xn_kernel, enc_s12_lds_bytes()) != hipSuccess || set_lds(dec_s01_xn_kernel, dec_s01_lds_bytes()) != hipSuccess ||
 #endif
       set_lds(dec_s0_kernel, dec_s0_lds_bytes() + c->lds_pad[3]) != hipSuccess ||
       set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||

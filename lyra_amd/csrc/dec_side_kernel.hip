@@ -50,5 +50,14 @@ __global__ __launch_bounds__(512, 4) void dec_side_xn_kernel(const DecS0P* P0, c
   dec_side_body<2>(P0, P1, P2, feats, ids, B, st0, st1, st2, d0, d1, pcm, packets, num_stages, cb, code_bytes);
 }
 
+// Stages 0 + 1 only (both are 8-stream / 512-thread tiles already)
+size_t dec_s01_lds_bytes() { return cmax(dec_s0_lds(), dec_s1_lds()); }
+__global__ __launch_bounds__(512, 4) void dec_s01_xn_kernel(const DecS0P* P0, const DecS1P* P1, const float* feats, const int32_t* ids,
+                                                           int B, uint8_t* st0, uint8_t* st1, float* d0, float* d1,
+                                                           const uint8_t* packets, int num_stages, const float* cb, int code_bytes) {
+  dec_s0_body<2>(P0, feats, ids, B, st0, d0, packets, num_stages, cb, code_bytes);
+  __syncthreads();
+  dec_s1_body(*P1, d0, ids, B, st1, d1, 0);
+}
 
 }  // namespace lyra

@@ -51,5 +51,14 @@ __global__ __launch_bounds__(512, 4) void enc_side_xn_kernel(const EncS0P* P0, c
   enc_side_body<2>(P0, P1, P2, pcm, ids, B, st0, st1, st2, e0, e1, feats, codes_dbg, code_bytes);
 }
 
+// Stages 1 + 2 only (both are 8-stream / 512-thread tiles already): two kernel boundaries per side instead of three.
+size_t enc_s12_lds_bytes() { return cmax(enc_s1_lds(), enc_s2_lds()); }
+__global__ __launch_bounds__(512, 4) void enc_s12_xn_kernel(const EncS1P* P1, const EncS2P* P2, const float* e0, const int32_t* ids,
+                                                           int B, uint8_t* st1, uint8_t* st2, float* e1, float* feats,
+                                                           float* codes_dbg, int code_bytes) {
+  enc_s1_body(*P1, e0, ids, B, st1, e1, code_bytes);
+  __syncthreads();
+  enc_s2_body<2>(P2, e1, ids, B, st2, feats, codes_dbg, 0);
+}
 
 }  // namespace lyra

@@ -43,6 +43,9 @@ __global__ void enc_side_xn_kernel(const EncS0P* P0, const EncS1P* P1, const Enc
                                    const int32_t* ids, int B, uint8_t* st0, uint8_t* st1, uint8_t* st2, float* e0, float* e1,
                                    float* feats, float* codes_dbg, int code_bytes);
 size_t enc_side_lds_bytes();
+__global__ void enc_s12_xn_kernel(const EncS1P* P1, const EncS2P* P2, const float* e0, const int32_t* ids, int B, uint8_t* st1,
+                                  uint8_t* st2, float* e1, float* feats, float* codes_dbg, int code_bytes);
+size_t enc_s12_lds_bytes();
 size_t enc_s0_lds_bytes(); int enc_s0_streams_per_wg(); int enc_s0_threads();
 size_t enc_s1_lds_bytes(); int enc_s1_streams_per_wg(); int enc_s1_threads();
 size_t enc_s2_lds_bytes(); int enc_s2_streams_per_wg();
@@ -88,6 +91,10 @@ __global__ void dec_side_xn_kernel(const DecS0P* P0, const DecS1P* P1, const Dec
                                    const int32_t* ids, int B, uint8_t* st0, uint8_t* st1, uint8_t* st2, float* d0, float* d1,
                                    int16_t* pcm, const uint8_t* packets, int num_stages, const float* cb, int code_bytes);
 size_t dec_side_lds_bytes();
+__global__ void dec_s01_xn_kernel(const DecS0P* P0, const DecS1P* P1, const float* feats, const int32_t* ids, int B, uint8_t* st0,
+                                  uint8_t* st1, float* d0, float* d1, const uint8_t* packets, int num_stages, const float* cb,
+                                  int code_bytes);
+size_t dec_s01_lds_bytes();
 size_t dec_s0_lds_bytes(); int dec_s0_streams_per_wg();
 size_t dec_s1_lds_bytes(); int dec_s1_streams_per_wg(); int dec_s1_threads();
 size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg(); int dec_s2_threads();
