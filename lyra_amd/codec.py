@@ -357,12 +357,16 @@ class LyraHip:
         return [self.L.lyra_hip_profile_kernel_name(i).decode() for i in range(n)]
 
     def profile_enable(self, on=True, only=None, every=1):
-        """Bracket kernel launches with HIP events: all kernels, or only the named one; every `every`-th launch."""
+        """Bracket kernel launches with HIP events: all kernels, or only the named one(s); every `every`-th launch."""
         self._chk(self.L.lyra_hip_profile_sample(self.h, int(every)))
         mask = 0
         if on:
             names = self.profile_kernel_names()
-            mask = (1 << names.index(only)) if only else (1 << len(names)) - 1
+            if only:
+                for k in ([only] if isinstance(only, str) else only):
+                    mask |= 1 << names.index(k)
+            else:
+                mask = (1 << len(names)) - 1
         self._chk(self.L.lyra_hip_profile_enable(self.h, mask))
 
     def profile_read(self):

@@ -16,6 +16,9 @@ extern "C" int lyra_hip_debug_wgtrace_d0(long long* out) {
 #ifndef LYRA_I8_WAVES
 #define LYRA_I8_WAVES 4   // waves per SIMD the int8 stage kernels are compiled for (5 -> at most 96 VGPRs)
 #endif
+#ifndef LYRA_D0XN_WAVES
+#define LYRA_D0XN_WAVES LYRA_I8_WAVES   // ... and the xnnpack-mode kernel on its own
+#endif
 
 #ifndef LYRA_C64_WAVES
 #define LYRA_C64_WAVES 4   // waves per SIMD the 64-channel stage kernels are compiled for (3 -> up to 168 VGPRs, no spills)
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_dr_kernel(const De
   dec_s0_body<1>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
 // mode 2 "xnnpack" (the default): XNNPACK's QS8 arithmetic
-__global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_xn_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+__global__ __launch_bounds__(NTD0, LYRA_D0XN_WAVES) void dec_s0_xn_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                           const int32_t* __restrict__ ids, int B,
                                                           uint8_t* __restrict__ state, float* __restrict__ out0,
                                                           const uint8_t* __restrict__ packets, int num_stages,

@@ -16,6 +16,9 @@ extern "C" int lyra_hip_debug_wgtrace_s2(long long* out) {
 #ifndef LYRA_I8_WAVES
 #define LYRA_I8_WAVES 4   // waves per SIMD the int8 stage kernels are compiled for (5 -> at most 96 VGPRs)
 #endif
+#ifndef LYRA_E2XN_WAVES
+#define LYRA_E2XN_WAVES LYRA_I8_WAVES   // ... and the xnnpack-mode kernel on its own
+#endif
 
 namespace lyra {
 
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_dr_kernel(const Enc
   enc_s2_body<1>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
 // mode 2 "xnnpack" (the default): XNNPACK's QS8 arithmetic
-__global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_xn_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+__global__ __launch_bounds__(NT2, LYRA_E2XN_WAVES) void enc_s2_xn_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ feats,
                                                          float* __restrict__ codes_dbg, int code_bytes, int tile0) {
