@@ -89,6 +89,9 @@ KERNEL_WORK = {
     "enc_s2_kernel": dict(f32=132608, i8=519168,
                           moved=2048 + (2048 + 2048) + (1024 + 512) + (1024 + 512) + (512 + 512) + (1024 + 512) + 512 + 8,
                           ref_bytes=2 * 256 * 4 + 2 * (26 * 256 + 2 * 256 + 2 * 512) * 4 + 256),
+    # ALGORITHMIC work = the graph's: 3 fp32 ops per (codeword, dim) term + the residual update.  The kernel certifies most
+    # indices from 46 x 16 x 64 MFMA MACs per frame (1.7 % of the step's matrix work) and runs the graph's chain only for the
+    # frames whose margin test fails (csrc/misc_kernels.hip rvq_encode_kernel); its floor stays priced on the graph's work.
     "rvq_encode_kernel": dict(f32=0, i8=0, moved=256 + 23, ref_bytes=256 + 23, flops=3 * 16 * 64 * 46 + 3 * 64 * 46),
     "rvq_decode_kernel": dict(f32=0, i8=0, moved=23 + 256, ref_bytes=23 + 256, flops=64 * 46),
     "dec_s0_kernel": dict(f32=24576, i8=758272,

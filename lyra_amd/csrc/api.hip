@@ -125,6 +125,7 @@ struct lyra_hip_ctx {
   size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
   int tile_div[6] = {1, 1, 1, 1, 1, 1};   // tiles per workgroup of each stage kernel (LYRA_TILE_LOOP), see tile_div()
   bool chunk_local = false;                       // see wait_encode_side
+  unsigned* d_rvq_stats = nullptr;                // rvq_encode_kernel: [0] frame-stages on the exact chain, [1] wavefront-stages (debug_read 5)
   uint32_t cu_pat[4] = {0, 0, 0, 0};              // CU mask pattern of the e / d / q / n streams (0: none), see make_stream_kind
   int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
   int last_B_enc = 0, last_B_dec = 0;
@@ -568,12 +569,13 @@ int launch_rvq_encode(lyra_hip_ctx* c, int k, int B, const float* d_feat, int nu
   hipStream_t st_ = on_quantizer_stream ? c->sq[k] : c->se[k];
   { ProfScope ps(c, K_RVQ_ENC, st_);
 #ifdef LYRA_PARKED
-    const auto kern = c->rvq_wide ? rvq_encode_wide_kernel : rvq_encode_kernel;
-#else
-    const auto kern = rvq_encode_kernel;
+    if (c->rvq_wide) {   // 1: the all-exact chain kernel of rounds 2-3, 2: its 104 KB / 244-VGPR form
+      hipLaunchKernelGGL(c->rvq_wide == 2 ? rvq_encode_wide_kernel : rvq_encode_chain_kernel, dim3(cdiv(B, 16)), dim3(256), 0, st_,
+                         c->model.cb, d_feat, B, num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes);
+    } else
 #endif
-    hipLaunchKernelGGL(kern, dim3(cdiv(B, 16)), dim3(256), 0, st_, c->model.cb, d_feat, B,
-                       num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes); }
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3(cdiv(B, 16)), dim3(64), 0, st_, c->model.cb, c->model.cbn, d_feat, B,
+                       num_stages, d_idx, d_pkt, d_mask_ids, d_pkt_bytes, c->d_rvq_stats); }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -815,6 +817,8 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
+  if (hipMalloc((void**)&c->d_rvq_stats, 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->d_rvq_stats, 0, 4 * sizeof(unsigned)) != hipSuccess)
+    return bail(LYRA_HIP_ENOMEM, "hipMalloc(rvq stats) failed");
   {
     size_t off = 0;
     for (int r = 0; r < st::R_COUNT; ++r) {   // region sizes are multiples of 256 bytes: every base stays aligned
@@ -901,6 +905,7 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   if (c->ev_ahead_last) (void)hipEventDestroy(c->ev_ahead_last);
   if (c->sn) (void)hipStreamDestroy(c->sn);
   if (c->d_state) (void)hipFree(c->d_state);
+  if (c->d_rvq_stats) (void)hipFree(c->d_rvq_stats);
   free_model(&c->model);
   delete c;
 }
@@ -1731,6 +1736,15 @@ long lyra_hip_debug_read(lyra_hip_ctx* c, int which, float* host_out, long capac
     case 2: src = c->d_codes; n = (long)c->last_B_enc * 64; break;
     case 3: src = c->d_d0; n = (long)c->last_B_dec * 4 * 128; break;
     case 4: src = c->d_d1; n = (long)c->last_B_dec * 20 * 64; break;
+    case 5: {   // the quantizer's screen: frame-stages / wavefront-stages that took the exact chain since creation
+      if (capacity < 2) return fail(c, LYRA_HIP_EINVAL, "debug buffer needs 2 floats");
+      int rc5 = sync_all(c);
+      if (rc5) return rc5;
+      unsigned h[4];
+      HIPCHK(c, hipMemcpy(h, c->d_rvq_stats, sizeof h, hipMemcpyDeviceToHost));
+      host_out[0] = (float)h[0]; host_out[1] = (float)h[1];
+      return 2;
+    }
     default: return fail(c, LYRA_HIP_EINVAL, "unknown debug buffer %d", which);
   }
   if (n > capacity) return fail(c, LYRA_HIP_EINVAL, "debug buffer needs %ld floats", n);

@@ -102,7 +102,11 @@ size_t dec_s2_lds_bytes(); int dec_s2_streams_per_wg(); int dec_s2_threads();
 // ---- RVQ / packets / log-mel / state ---------------------------------------------------------------
 // cb: codebooks, natural layout [46][16][64]
 // mask_ids (optional): frame i is skipped (empty packet, packet_bytes[i] = 0) where mask_ids[i] < 0
-__global__ void rvq_encode_kernel(const float* cb, const float* feats, int B, int num_stages, int32_t* indices,
+// cbn: [46][16] |c|^2 per codeword, then [46] 2^-14 max |c|^2 per stage (model.hip); stats (optional): [0] frame-stages that took
+// the exact chain, [1] wavefront-stages that entered it
+__global__ void rvq_encode_kernel(const float* cb, const float* cbn, const float* feats, int B, int num_stages, int32_t* indices,
+                                  uint8_t* packets, const int32_t* mask_ids, int32_t* packet_bytes, unsigned* stats);
+__global__ void rvq_encode_chain_kernel(const float* cb, const float* feats, int B, int num_stages, int32_t* indices,
                                   uint8_t* packets, const int32_t* mask_ids, int32_t* packet_bytes);
 __global__ void rvq_encode_wide_kernel(const float* cb, const float* feats, int B, int num_stages, int32_t* indices,
                                   uint8_t* packets, const int32_t* mask_ids, int32_t* packet_bytes);

@@ -166,18 +166,232 @@ __device__ __forceinline__ void rvq_encode_body(const float* __restrict__ cb, co
   }
 }
 
-// The shipped form: windows of two stages (26 KB of LDS), one register set (<= 128 VGPRs): next to this kernel's one
-// wavefront per SIMD three wavefronts of a stage kernel still fit, and the other side's stage kernel keeps most of its
-// tiles resident while the quantizer runs (the 8-stage / two-register-set form is 104 KB and 244 VGPRs: faster alone,
-// but it evicts the co-running kernel).
-__global__ __launch_bounds__(256, 4) void rvq_encode_kernel(const float* __restrict__ cb, const float* __restrict__ feats,
+// =============================================================================================
+// The shipped quantizer: CERTIFIED SCREENING on the matrix pipe, the exact chain only where the screen cannot decide.
+//
+// The reference's argmin is over S_k = the sequentially rounded fp32 sum above.  In exact arithmetic
+// T_k = |r - c_k|^2 = |c_k|^2 - 2 r.c_k + |r|^2, and the 16 x 16 dot products of a stage's 16 codewords with 16 frames are
+// ONE dense [16 x 64] x [64 x 16] GEMM: 16 v_mfma_f32_16x16x4_f32 per stage and wavefront instead of 4 x 192 dependent
+// vector instructions per 4 frames.  A_k = N_k - 2 P_k (N_k = |c_k|^2 from the host, P_k the MFMA dot product) ranks the
+// codewords up to a rounding error that is bounded rigorously (u = 2^-24, C = max_k |c_k| of the stage, any Rb >= |r|^2):
+//     |S_k - T_k|           <= 67 u T_k                         (66 roundings on non-negative terms)
+//     |A_k - (T_k - |r|^2)| <= 2 u |c_k|^2 + 142 u |r||c_k|     (N rounded once, <= 70 roundings on the dot product, one on A)
+//     => S_j > S_k strictly whenever A_j - A_k > 280 u (|r| + C)^2, and (|r| + C)^2 <= 2 (Rb + C^2).
+// The scores are compared as KEYS: bits(A_k + Rb + M) -- positive, so they order as integers -- with the low four bits
+// replaced by k (a perturbation below 2^-19 of the score: one integer minimum yields winner AND index).  With the margin
+//     M = 2^-14 (Rb + C^2)  >=  (560 u + 2^-16)(Rb + C^2)
+// every codeword whose key exceeds the smallest key by more than M cannot be the reference's ARG_MIN.  If exactly one
+// codeword is left it IS the reference's index -- certified, no exact sum computed.  Otherwise (near-ties, exact ties,
+// NaNs: count != 1) the frame takes the exact chain -- the graph's three fp32 operations per term in ascending order, first
+// minimum -- for all 16 codewords.  (On speech about one frame-stage in a thousand does: lyra_hip_debug_read(5).)
+// Rb is carried from stage to stage: |r'|^2 <= T_winner + 7 u (..)^2 <= A_min + M + Rb + (error) => Rb' = (key_min + 2 M)(1 + 2^-10).
+// The residual update r <- r - (r + (q - r)) is the graph's, bit for bit, so the residual the next stage sees -- and
+// every index -- is the reference's.
+//
+// One wavefront = 16 frames = one MFMA N tile.  Lane (n = lane & 15, q = lane >> 4) owns dims 16 q .. 16 q + 15 of frame n
+// (B operand of MFMA kk: dim 16 q + kk) and, as A operand, the same dims of codeword n -- both are plain 64-byte reads of
+// the natural layouts, no repacking.  D[codeword 4 q + e][frame n]: a lane holds four codewords' scores of ONE frame, so
+// the argmin is three minima in registers and a two-step all-reduce over the four 16-lane rows; the winner is then known
+// to exactly the four lanes that hold the frame's residual.  Its dims come back from the A-fragment registers of lane
+// (winner, q) by ds_bpermute: the codebook never passes through LDS or memory a second time, and the certified path has
+// no barrier.
+// =============================================================================================
+// All-reduce over the four 16-lane rows of a wavefront, register to register: v_permlane16_swap (odd rows of the first
+// operand <-> even rows of the second) pairs rows 0|1 and 2|3, v_permlane32_swap (upper half <-> lower half) pairs the halves.
+__device__ __forceinline__ unsigned rows_min_u32(unsigned v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = min(a[0], a[1]);
+  const auto s = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // [lo, lo], [hi, hi]
+  return min(s[0], s[1]);
+}
+__device__ __forceinline__ unsigned rows_add_u32(unsigned v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = a[0] + a[1];
+  const auto s = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return s[0] + s[1];
+}
+
+__global__ __launch_bounds__(64) void rvq_encode_kernel(const float* __restrict__ cb, const float* __restrict__ cbn,
+                                                        const float* __restrict__ feats, int B, int num_stages,
+                                                        int32_t* __restrict__ indices, uint8_t* __restrict__ packets,
+                                                        const int32_t* __restrict__ mask_ids,
+                                                        int32_t* __restrict__ packet_bytes, unsigned* __restrict__ stats) {
+  __shared__ __attribute__((aligned(16))) float rs[16 * 68];   // residuals of the tile, [frame][64 (+4 pad)]: exact path / prologue
+  __shared__ int win[16];                                       // exact path: winners by frame
+  const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+  const int x16 = (lane ^ 16) << 2;
+  const int frame = blockIdx.x * 16 + n;
+  const int f = min(frame, B - 1);
+  const bool live = frame < B && !(mask_ids && mask_ids[f] < 0);
+  const float LYRA_GLOBAL* cbg = as_global(cb) + (size_t)n * 64 + q * 16;   // this lane's 16 dims of codeword n, stage 0
+  const float kUp = 1.0009765625f;   // 1 + 2^-10
+  f32x4 r4[4], b4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r4[i] = *reinterpret_cast<const f32x4*>(&feats[(size_t)f * 64 + q * 16 + i * 4]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b4[i] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(cbg + i * 4);
+  float Rb;   // >= |r|^2 of frame n (the same in its four lanes)
+  {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = __builtin_fmaf(r4[i][e], r4[i][e], part);
+    part = part + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x16, __builtin_bit_cast(int, part)));
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+    Rb = (__uint_as_float(s[0]) + __uint_as_float(s[1])) * kUp;
+  }
+  const int nbytes = (num_stages + 1) >> 1;
+  int cur = 0;
+  // Two fragment sets: stage k multiplies with set k & 1 while the winner of stage k - 1 is still read out of the other;
+  // that one is then refilled with stage k + 1 (L2, in flight under the whole stage).
+  f32x4 fa[4], fb[4], Na, Nb;
+  float ca, cbb;
+  int vz = 0;
+  asm volatile("" : "+v"(vz));   // a VECTOR load for the stage scalar: a scalar load would share the LDS counter the bpermutes wait on
+  auto fetch = [&](int k, f32x4 (&fr)[4], f32x4& Nn, float& c2s) {
+    const int kc = min(k, 45);
+    const float LYRA_GLOBAL* g = cbg + (size_t)kc * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fr[i] = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(g + i * 4);
+    Nn = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(cbn) + kc * 16 + q * 4);   // |c|^2 of codewords 4 q + e
+    c2s = as_global(cbn)[46 * 16 + kc + vz];                                                // 2^-14 C^2, rounded up
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = b4[i];
+  Na = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(cbn) + q * 4);
+  ca = as_global(cbn)[46 * 16];
+  fetch(1, fb, Nb, cbb);
+  // the screen of one stage: P[e] = c_{4q+e} . r of frame n  ->  the stage's index (certified, or from the exact chain)
+  auto screen = [&](int k, const f32x4& P, const f32x4& Nn, float c2s) -> int {
+    const float M = __builtin_fmaf(Rb, 0x1p-14f, c2s);
+    const float off = Rb + M;
+    unsigned key[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = __builtin_fmaf(-2.f, P[e], Nn[e]) + off;   // > 0 (or NaN / huge: then nothing is certified)
+      key[e] = (__float_as_uint(a) & ~15u) | (unsigned)(q * 4 + e);
+    }
+    const unsigned kmin = rows_min_u32(min(min(key[0], key[1]), min(key[2], key[3])));
+    const float thr = __uint_as_float(kmin) + M;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cnt += __uint_as_float(key[e]) <= thr ? 1u : 0u;
+    cnt = rows_add_u32(cnt);
+    int best = (int)(kmin & 15u);
+    // a score that is not an ordinary positive float (negative beyond the bound, NaN, Inf) certifies nothing
+    const bool amb = cnt != 1u || !(__uint_as_float(kmin) < 0x1p126f) || (int)kmin < 0;
+    const unsigned long long any_amb = __builtin_amdgcn_ballot_w64(amb);
+    if (any_amb) {   // (wave-uniform) the exact chain for the frames the screen could not certify
+      unsigned fm = (unsigned)any_amb & 0xffffu;   // a frame's four lanes agree
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&rs[n * 68 + q * 16 + i * 4]) = r4[i];
+      __syncthreads();
+      if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned)__builtin_popcount(fm)); atomicAdd(&stats[1], 1u); }
+      while (fm) {   // four flagged frames per pass: lane (slot = q, codeword = n)
+        unsigned rest = fm;
+        int fr = -1;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          const int bit = rest ? __builtin_ctz(rest) : -1;
+          if (sl == q) fr = bit;
+          if (rest) rest &= rest - 1;
+        }
+        fm = rest;
+        const float* rr = &rs[max(fr, 0) * 68];
+        const float LYRA_GLOBAL* cc = as_global(cb) + ((size_t)k * 16 + n) * 64;
+        float sum = 0.f;
+#pragma unroll 2
+        for (int d4 = 0; d4 < 16; ++d4) {   // (rare path: kept small, its registers must not set the kernel's footprint)
+          const f32x4 x = *reinterpret_cast<const f32x4*>(rr + d4 * 4);
+          const f32x4 c = *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(cc + d4 * 4);
+          const f32x4 df = x - c;
+          const f32x4 sq = df * df;
+          sum = sum + sq[0]; sum = sum + sq[1]; sum = sum + sq[2]; sum = sum + sq[3];
+        }
+        // ARG_MIN = first minimum (sums of squares: non-negative floats order like their bit patterns)
+        unsigned mbits = __builtin_bit_cast(unsigned, sum);
+#define LYRA_ROR_MINU(N) \
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(mbits) : "v"(mbits));
+        LYRA_ROR_MINU(8) LYRA_ROR_MINU(4) LYRA_ROR_MINU(2) LYRA_ROR_MINU(1)
+#undef LYRA_ROR_MINU
+        const unsigned long long holders = __builtin_amdgcn_ballot_w64(sum == __builtin_bit_cast(float, mbits));
+        const int xbest = __builtin_ctz((unsigned)(holders >> (lane & 48)) | 0x10000u) & 15;   // (& 15: NaN distances only)
+        if (n == 0 && fr >= 0) win[fr] = xbest;
+      }
+      __syncthreads();
+      if (amb) best = win[n];
+      __syncthreads();   // win[] and rs[] are free again
+    }
+    Rb = __builtin_fmaf(2.f, M, __uint_as_float(kmin)) * kUp;
+    if (q == 0 && live) {
+      if (indices) indices[(size_t)frame * 46 + k] = best;
+      if (packets) {
+        if (k & 1) packets[(size_t)frame * nbytes + (k >> 1)] = (uint8_t)(cur | best);
+        else cur = best << 4;
+      }
+    }
+    return best;
+  };
+  // stage k >= 1: the residual update of stage k - 1 -- r <- r - (r + (q - r)), the graph's three separate fp32 ops, the
+  // winner's dims out of lane (codeword best, q)'s fragments -- feeds this stage's MFMA chain dim by dim
+  auto step = [&](int k, int best, f32x4 (&prev)[4], f32x4& Nprev, float& cprev, const f32x4 (&curf)[4], const f32x4& Ncur,
+                  float ccur) -> int {
+    const int src = (q * 16 + best) * 4;
+    f32x4 qv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const i32x4 bi = __builtin_bit_cast(i32x4, prev[i]);
+      const i32x4 qi = {__builtin_amdgcn_ds_bpermute(src, bi[0]), __builtin_amdgcn_ds_bpermute(src, bi[1]),
+                        __builtin_amdgcn_ds_bpermute(src, bi[2]), __builtin_amdgcn_ds_bpermute(src, bi[3])};
+      qv[i] = __builtin_bit_cast(f32x4, qi);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all 16 in flight at once (the scheduler otherwise trickles them in pairs, each with its own wait)
+    fetch(k + 1, prev, Nprev, cprev);   // (the bpermutes above have read `prev`)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 P[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // two chains: a dependent MFMA waits ~50 cycles, an independent one 32
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t1 = qv[i][e] - r4[i][e];
+        const float t2 = r4[i][e] + t1;
+        r4[i][e] = r4[i][e] - t2;
+        P[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(curf[i][e], r4[i][e], P[e & 1], 0, 0, 0);
+      }
+    return screen(k, P[0] + P[1], Ncur, ccur);
+  };
+  int best;
+  {
+    f32x4 P[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      P[kk & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kk >> 2][kk & 3], r4[kk >> 2][kk & 3], P[kk & 1], 0, 0, 0);
+    best = screen(0, P[0] + P[1], Na, ca);
+  }
+#pragma unroll 1
+  for (int k = 1; k < num_stages; k += 2) {
+    best = step(k, best, fa, Na, ca, fb, Nb, cbb);
+    if (k + 1 < num_stages) best = step(k + 1, best, fb, Nb, cbb, fa, Na, ca);
+  }
+  if (q == 0 && frame < B && packet_bytes) packet_bytes[frame] = live ? nbytes : 0;
+  if (q == 0 && live) {
+    if (packets && (num_stages & 1)) packets[(size_t)frame * nbytes + (num_stages >> 1)] = (uint8_t)cur;
+    if (indices)
+      for (int k = num_stages; k < 46; ++k) indices[(size_t)frame * 46 + k] = -1;
+  }
+}
+
+#ifdef LYRA_PARKED   // the all-exact chain kernels of rounds 2-3: bit-identical, kept for A/B in the variant build
+// windows of two stages (26 KB of LDS), one register set (<= 128 VGPRs)
+__global__ __launch_bounds__(256, 4) void rvq_encode_chain_kernel(const float* __restrict__ cb, const float* __restrict__ feats,
                                                             int B, int num_stages, int32_t* __restrict__ indices,
                                                             uint8_t* __restrict__ packets,
                                                             const int32_t* __restrict__ mask_ids,
                                                             int32_t* __restrict__ packet_bytes) {
   rvq_encode_body<2, false>(cb, feats, B, num_stages, indices, packets, mask_ids, packet_bytes);
 }
-#ifdef LYRA_PARKED   // the 104 KB / 244-VGPR form: measured, not shipped
+// the 104 KB / 244-VGPR form
 __global__ __launch_bounds__(256) void rvq_encode_wide_kernel(const float* __restrict__ cb, const float* __restrict__ feats,
                                                               int B, int num_stages, int32_t* __restrict__ indices,
                                                               uint8_t* __restrict__ packets,

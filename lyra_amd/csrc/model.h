@@ -44,6 +44,7 @@ struct Model {
   DecS0P dec0; DecS1P dec1; DecS2P dec2;
   const float* cb = nullptr;   // [46][16][64]
   const float* cbt = nullptr;  // [46][64][16]
+  const float* cbn = nullptr;  // [46][16] |c|^2 (rounded from double), then [46] 2^-14 max |c|^2 of the stage, rounded up: rvq_encode's screen
   MelP mel;            // = mel_rate[1]
   MelP mel_rate[4];    // log-mel tables of an extractor created for 8 / 16 / 32 / 48 kHz (model.hip)
   ResetP reset;

@@ -524,6 +524,18 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
           for (int d = 0; d < 64; ++d) tr[((size_t)k * 64 + d) * 16 + j] = cb[((size_t)k * 16 + j) * 64 + d];
       B.put(&M->cb, nat);
       B.put(&M->cbt, tr);
+      std::vector<float> nrm(46 * 16 + 64, 0.f);
+      for (int k = 0; k < 46; ++k) {
+        double mx = 0.0;
+        for (int j = 0; j < 16; ++j) {
+          double n2 = 0.0;
+          for (int d = 0; d < 64; ++d) n2 += (double)cb[((size_t)k * 16 + j) * 64 + d] * (double)cb[((size_t)k * 16 + j) * 64 + d];
+          nrm[k * 16 + j] = (float)n2;
+          mx = std::max(mx, std::sqrt(n2));
+        }
+        nrm[46 * 16 + k] = std::nextafter((float)(mx * mx * (1.0 + 1e-6) / 16384.0), INFINITY);   // 2^-14 C^2, rounded up
+      }
+      B.put(&M->cbn, nrm);
     }
   }
   // ---- log-mel tables: periodic Hann 640, radix-2 twiddles, 160-band two-tap mel -----------

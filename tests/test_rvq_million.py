@@ -75,6 +75,49 @@ def test_gpu_rvq_ties_first_minimum(tmp_path):
     assert np.array_equal(got, want)
     assert not np.any(got[:, 0] == 9) and np.all(got[:, 5] == 0) and not np.any(got[:, 45] == 1)
     assert np.any(got[:, 0] == 3) and np.any(got[:, 1] == 2)
+    # exact ties can only be resolved by the exact chain: the screen (csrc/misc_kernels.hip rvq_encode_kernel) must have
+    # handed at least every stage-5 frame (sixteen equal codewords) to it
+    frames, waves = ctx.debug_read(5, 2)
+    assert frames >= feats.shape[0] and waves >= feats.shape[0] / 16
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rvq_screen_adversarial_inputs(oracle_exact):
+    """The quantizer certifies most indices from MFMA dot products and a rigorous error margin; whatever the margin cannot
+    decide -- and whatever is not an ordinary float -- goes to the exact chain.  Inputs chosen to sit on those edges: zeros,
+    denormals, 1e-30 .. 1e18 magnitudes (squares overflow), Inf / NaN rows, vectors equidistant from two codewords up to
+    the last bits.  Every index equal to the oracle's all-exact chain."""
+    import lyra_amd
+    ctx = lyra_amd.LyraHip(max_streams=64)
+    rng = np.random.default_rng(77)
+    base = rng.normal(0, 3, size=(4096, 64)).astype(np.float32)
+    sets = [np.zeros((64, 64), np.float32), np.full((64, 64), 1e-40, np.float32)]
+    for scale in (1e-30, 1e-12, 1e-6, 1.0, 1e3, 1e9, 1e15, 1e18, 3e19, 1e30):
+        sets.append((base[:512] * np.float32(scale)).astype(np.float32))
+    weird = base[:256].copy()
+    weird[0::4, 5] = np.inf
+    weird[1::4, 9] = -np.inf
+    weird[2::4, 63] = np.nan
+    sets.append(weird)
+    # midpoints of two codewords of stage 0 (+ a few ulps): the two best distances agree to the last bits
+    import struct as _s
+    blob = open(PACK, "rb").read()
+    n = _s.unpack_from("<I", blob, 8)[0]
+    for i in range(n):
+        name, dtype, ndim, s0, s1, s2, s3, o, nb = _s.unpack_from("<56sII4IQQ", blob, 16 + 96 * i)
+        if name.rstrip(b"\0") == b"rvq.codebooks":
+            cb = np.frombuffer(blob, np.float32, 46 * 16 * 64, o).reshape(46, 16, 64)
+    a, b = rng.integers(0, 16, 4096), rng.integers(0, 16, 4096)
+    mid = ((cb[0, a].astype(np.float64) + cb[0, b]) / 2).astype(np.float32)
+    mid[1::2] = np.nextafter(mid[1::2], np.float32(np.inf))
+    sets.append(mid)
+    feats = np.concatenate(sets)
+    with np.errstate(all="ignore"):
+        want = oracle_exact.rvq_encode_batch(feats, 46, threads=16)
+    got = ctx.rvq_encode(feats, 184)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} mismatching (row, stage) pairs, first {bad[:5].tolist()}"
     ctx.close()
 
 
@@ -102,4 +145,8 @@ def test_gpu_rvq_million_vectors(golden_dir, oracle_exact):
     # fewer stages: a prefix, -1 beyond (lyra/residual_vector_quantizer.cc:143-157 convention)
     got = ctx.rvq_encode(feats[:4096], 64)
     assert np.array_equal(got[:, :16], want[:4096, :16]) and np.all(got[:, 16:] == -1)
+    # how often the screen had to fall back to the exact chain: a property of the data (near-ties), not of correctness --
+    # but if it were the rule rather than the exception the kernel would be the old one with extra steps
+    frames, waves = ctx.debug_read(5, 2)
+    assert frames / (46.0 * feats.shape[0]) < 0.02, "exact-chain rate above 2 % of frame-stages"
     ctx.close()
