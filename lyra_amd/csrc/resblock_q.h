@@ -26,6 +26,12 @@ __device__ __forceinline__ int pack8(int a, int b, int c, int d) {
   return (int)(lo | hi);
 }
 
+// byte e of three registers -> (x0[e], x1[e], x2[e], 0)
+__device__ __forceinline__ int taps3(int x0, int x1, int x2, int e) {
+  const unsigned t01 = __builtin_amdgcn_perm((unsigned)x1, (unsigned)x0, 0x0c0c0000u | ((4u + e) << 8) | (unsigned)e);
+  return (int)__builtin_amdgcn_perm((unsigned)x2, t01, 0x0c000100u | ((4u + e) << 16));
+}
+
 // ---- lookup tables (LDS) ----------------------------------------------------------------------------
 __device__ __forceinline__ int lut8(const int8_t* lut, int c8) { return (int)lut[c8 + 128]; }
 // four packed codes at once
@@ -99,17 +105,19 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
     const int base = (cx.sphase[s] * 2) % R2;
     const uint32_t hp = cx.soff(s) + (uint32_t)(off + w4 * 4);
     const bool valid = cx.valid(s);
+    // channel e's three taps side by side in one dword -- (tap0, tap1, tap2, 0): two v_perm_b32 -- so that the 3-tap sum is ONE
+    // v_dot4_i32_i8 per channel and row (was three sign extensions + three multiply-adds; integer arithmetic, identical)
+    int wq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wq[e] = taps3(pre.ww[0], pre.ww[1], pre.ww[2], e);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int a = lut8w(la, *reinterpret_cast<const int*>(&QX[(t * S + s) * QS + w4 * 4]));
       if (valid) *cx.at<int>(hp + (uint32_t)((base + t) * 256)) = a;
-      const int x[3] = {pre.h[t][0], pre.h[t][1], a};
       int o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int acc = pre.b[e];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc += sx8(x[j], e) * sx8(pre.ww[j], e);
+        const int acc = __builtin_amdgcn_sdot4(taps3(pre.h[t][0], pre.h[t][1], a, e), wq[e], pre.b[e], false);
         o[e] = conv_code<MODE>(acc, pre.M[e], pre.sh[e], dq.zout);
       }
       *reinterpret_cast<int*>(&QD[(t * S + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
