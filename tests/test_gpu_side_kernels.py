@@ -1,6 +1,7 @@
 """GPU (-m gpu): the one-launch-per-side kernels (csrc/enc_side_kernel.hip, dec_side_kernel.hip; PARKED: only in the
 build variant lyra_amd/variants/parked.so = `make -C lyra_amd/csrc parked`, there opt-in through LYRA_HIP_FUSED, bit 0
-encoder side, bit 1 decoder side) against the seven-launch path: packets and PCM bit-identical
+encoder side, bit 1 decoder side, bits 2 / 3 the pairwise-fused stage kernels; LYRA_HIP_RVQ_WIDE: the all-exact quantizer chain
+kernels) against the seven-launch path: packets and PCM bit-identical
 over several hops (ring phases advance), ragged tile (B not a multiple of 8), scattered stream ids, both requantisation
 modes.  The seven-launch path itself is pinned to the oracle in test_gpu_parity.py, which can also be run whole with
 LYRA_HIP_FUSED=3 in the environment."""
@@ -15,19 +16,21 @@ pytestmark = pytest.mark.gpu
 PARKED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lyra_amd", "variants", "parked.so")
 
 
-def _ctx(fused, requant):
+def _ctx(fused, requant, rvq_chain=0):
     import lyra_amd
     if not os.path.exists(PARKED):
         pytest.skip("lyra_amd/variants/parked.so not built (make -C lyra_amd/csrc parked)")
-    old = os.environ.get("LYRA_HIP_FUSED")
+    saved = {k: os.environ.get(k) for k in ("LYRA_HIP_FUSED", "LYRA_HIP_RVQ_WIDE")}
     os.environ["LYRA_HIP_FUSED"] = str(fused)
+    os.environ["LYRA_HIP_RVQ_WIDE"] = str(rvq_chain)
     try:
         return lyra_amd.LyraHip(max_streams=4200, requant=requant, library=PARKED)
     finally:
-        if old is None:
-            del os.environ["LYRA_HIP_FUSED"]
-        else:
-            os.environ["LYRA_HIP_FUSED"] = old
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("requant", ["xnnpack", "exact", "gemmlowp_double"])
@@ -39,8 +42,12 @@ def test_side_kernels_equal_stage_kernels(requant, B, bits):
     pcm[1] //= 50
     ids = rng.permutation(4200)[:B].astype(np.int32)
     outs = []
-    for fused in (0, 3, 1, 2):
-        c = _ctx(fused, requant)
+    # bits 2 / 3 (round 4): encoder stages 1 + 2 / decoder stages 0 + 1 as one launch each (mode xnnpack only).  The last
+    # two: the all-exact quantizer chain kernels of rounds 2-3 (LYRA_HIP_RVQ_WIDE = 1, 2) against the screened quantizer
+    # the default build ships -- every packet equal means every certified index was the chain's index
+    variants = [(0, 0), (3, 0), (1, 0), (2, 0)] + ([(4, 0), (8, 0), (12, 0)] if requant == "xnnpack" else []) + [(0, 1), (0, 2)]
+    for fused, rvq_chain in variants:
+        c = _ctx(fused, requant, rvq_chain)
         try:
             run = []
             for t in range(T):
