@@ -9,6 +9,7 @@ extern "C" int lyra_hip_debug_timing_misc(long long* out) {
 
 namespace lyra {
 
+#ifdef LYRA_PARKED
 // The 64-term distance chain of one codeword, dims in ascending order: df = r - c, sq = df * df, sum = sum + sq, three
 // separate fp32 operations per term as the graph's SUB / MUL / SUM (residual_vector_quantizer.cc:77-110 runs them
 // through the `encode` subgraph).  `mine` = the lane's four residual dims; lane d4 of the row holds dims 4*d4..4*d4+3.
@@ -37,8 +38,9 @@ __device__ __forceinline__ void rvq_terms(float& sum, float m0, float m1, float 
 }
 
 // =============================================================================================
-// RVQ encode: replaces quantizer.tflite `encode` (555 ops) + the bit-string assembly of
-// ResidualVectorQuantizer::Quantize (lyra/residual_vector_quantizer.cc:77-110) + Packet<>::Pack
+// RVQ encode, ALL-EXACT CHAIN FORM (rounds 1-3; since round 4 only in the variant build, for A/B and as the witness the
+// shipped kernel is tested against, tests/test_gpu_side_kernels.py): quantizer.tflite `encode` (555 ops) + the bit-string
+// assembly of ResidualVectorQuantizer::Quantize (lyra/residual_vector_quantizer.cc:77-110) + Packet<>::Pack
 // (lyra/packet.h:91-122).  16 lanes = the 16 codewords of a stage; each lane runs the 64-term
 // squared-distance sum in the oracle's order (separate multiply and add, d ascending), then a
 // 16-lane DPP argmin with lowest-index tie break (ARG_MIN = first minimum).  4 frames per wavefront,
@@ -166,8 +168,12 @@ __device__ __forceinline__ void rvq_encode_body(const float* __restrict__ cb, co
   }
 }
 
+#endif   // LYRA_PARKED (chain form)
+
 // =============================================================================================
-// The shipped quantizer: CERTIFIED SCREENING on the matrix pipe, the exact chain only where the screen cannot decide.
+// RVQ encode: replaces quantizer.tflite `encode` (555 ops) + the bit-string assembly of ResidualVectorQuantizer::Quantize
+// (lyra/residual_vector_quantizer.cc:77-110) + Packet<>::Pack (lyra/packet.h:91-122).
+// CERTIFIED SCREENING on the matrix pipe, the graph's exact chain only where the screen cannot decide.
 //
 // The reference's argmin is over S_k = the sequentially rounded fp32 sum above.  In exact arithmetic
 // T_k = |r - c_k|^2 = |c_k|^2 - 2 r.c_k + |r|^2, and the 16 x 16 dot products of a stage's 16 codewords with 16 frames are
