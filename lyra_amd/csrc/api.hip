@@ -766,15 +766,16 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   }
   // The internal events only order work of this device's streams against each other: no system-scope fence (cache
   // write-back) when they are recorded -- a recorded event costs ~5.5 us of stream bubble with it (rocprofv3 timeline).
-  // The decoder chain (three kernels + two event packets per step) is the longest of the three streams' chains: its
-  // workgroups are dispatched first (highest stream priority), the extractor and the quantizer fill in.  With equal
-  // priorities the pipeline has two steady states, 0.315 and 0.33-0.355 ms per step at B = 4096 (in the slow one the
-  // quantizer runs beside decoder stage 0, both VALU-bound); with this it stays in the fast one.
+  // Stream priorities.  Rounds 2-3 ran the decoder chain at the highest priority: the quantizer then was a 9 M-instruction
+  // vector kernel that must not run beside decoder stage 0.  With the screened quantizer (round 4: 1.5 M instructions, one
+  // wavefront per 16 frames) that reason is gone, and the decoder-first schedule turned out BIMODAL -- 0.290 or 0.305 ms
+  // per step at B = 4096 from run to run on one box, depending on which chain ends up waiting for the other -- while the
+  // small quantizer at the highest priority and both chains equal gives 0.290 every time (profiles/r04_prio_ab2.txt).
   int prio_lo = 0, prio_hi = 0;
   if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
-  int prio[3] = {prio_lo, getenv("LYRA_HIP_FLAT_PRIO") ? prio_lo : prio_hi, prio_lo};
+  int prio[3] = {prio_lo, prio_lo, getenv("LYRA_HIP_FLAT_PRIO") ? prio_lo : prio_hi};
   if (const char* p = getenv("LYRA_HIP_PRIO")) {   // experiment hook: "e,d,q" each 0 = lowest .. 2 = highest
-    int v[3] = {0, 2, 0};
+    int v[3] = {0, 0, 2};
     sscanf(p, "%d,%d,%d", &v[0], &v[1], &v[2]);
     for (int i = 0; i < 3; ++i) prio[i] = v[i] >= 2 ? prio_hi : (v[i] == 1 ? (prio_lo + prio_hi) / 2 : prio_lo);
   }

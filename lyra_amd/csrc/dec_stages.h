@@ -370,9 +370,11 @@ constexpr int NTD1 = LYRA_S1_THREADS;
 // tiles are then shifted UP by one input row (8 of a tile's 16 rows: a 32-lane rotation) so that C row (b, s) sits on
 // A row (b - 1, s), block 4 enters as the bare bias, and pass 2 continues the chains with taps 5..9.
 // Block 4 = bias + x[3] . W[5..9] is the carried tail.  A wave computes NTW of the 20 N tiles starting at tile0.
+// HB: LDS scratch of this wave (NTW x 4 x 64 floats): block 0 -- complete after pass 1 -- waits there for the epilogue
+// instead of in 4 NTW registers across pass 2 (at the 128-VGPR cap they spilled).
 template <int NTW>
 __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, const DecS1P& P, const TileCtx& cx,
-                                             int b0, float* __restrict__ out1, int tile0) {
+                                             int b0, float* __restrict__ out1, int tile0, float* HB) {
   const int lane = threadIdx.x & 63;
   const int m = lane & 15, q = lane >> 4;
   f32x4 acc[2][NTW];
@@ -392,7 +394,6 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
   }
   LYRA_TSTAMP(54);
   LYRA_WSTAMP(114);
-  f32x4 head[NTW];
   const bool lo = lane < 32;
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
@@ -400,7 +401,7 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float a = acc[0][j][e], bb = acc[1][j][e];   // a = [Y(b0) | Y(b1)], bb = [Y(b2) | Y(b3)]  (lanes 0-31 | 32-63)
-      head[j][e] = a;                              // lanes 0-31: block 0, complete
+      HB[(j * 4 + e) * 64 + lane] = a;             // lanes 0-31: block 0, complete (parked in LDS, read back by the same lane)
       rot32_pair(a, bb);                           // a = [Y(b1) | Y(b0)], bb = [Y(b3) | Y(b2)]
       acc[0][j][e] = lo ? a : bb;                  // blocks 1 | 2
       acc[1][j][e] = lo ? bb : biasb;              // blocks 3 | 4 (block 4 starts from the bare bias)
@@ -435,7 +436,7 @@ __device__ __forceinline__ void dec_s1_tconv(const float* XB, const float* SB, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int s = q_e * 4 + e;
-        const float y = head[j][e] + SB[(jj * SD1 + s) * 72 + co];
+        const float y = HB[(j * 4 + e) * 64 + lane_e] + SB[(jj * SD1 + s) * 72 + co];
         if (cx.valid(s)) *goff<float>(out1 + (size_t)b0 * 1280, (uint32_t)(((s * 20 + jj) * 64 + pc) * 4)) = y;
       }
     }
@@ -497,9 +498,13 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   LYRA_TSTAMP(53);
   LYRA_WSTAMP(113);
   // transposed conv k10/s5: 20 N tiles over the waves (5 each with 4 waves; 3,3,3,3,2,2,2,2 with 8)
-  if (NTD1 == 256) dec_s1_tconv<5>(XB, SB, P, cx, b0, out1, wave * 5);
-  else if (wave < 4) dec_s1_tconv<3>(XB, SB, P, cx, b0, out1, wave * 3);
-  else dec_s1_tconv<2>(XB, SB, P, cx, b0, out1, 12 + (wave - 4) * 2);
+  // (DB and PB, 2 x 17 KB, are free once the residual blocks are done: the waves' head scratch, 20 KB in all, fits)
+  constexpr int HEAD_TILES = NTD1 == 256 ? 5 : 3;
+  static_assert((NTD1 / 64) * HEAD_TILES * 256 <= 2 * 4 * SD1 * CS1, "head scratch fits into DB + PB");
+  float* HB = DB + wave * (HEAD_TILES * 4 * 64);
+  if (NTD1 == 256) dec_s1_tconv<5>(XB, SB, P, cx, b0, out1, wave * 5, HB);
+  else if (wave < 4) dec_s1_tconv<3>(XB, SB, P, cx, b0, out1, wave * 3, HB);
+  else dec_s1_tconv<2>(XB, SB, P, cx, b0, out1, 12 + (wave - 4) * 2, HB);
 #ifdef LYRA_WGTRACE_D1
   __syncthreads();
   LYRA_WG_END();
