@@ -138,7 +138,8 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  *                            noise streams; 0 = no mask (default: 00ff00ff,ff00ff00,00ff00ff,ff00ff00 when
  *                            max_streams <= 1024, none above);
  *   LYRA_HIP_PRIO=e,d,q      stream priorities of the encode / decode / quantizer streams (0 lowest .. 2 highest;
- *                            default 0,0,2: the two chains equal, the small quantizer first);
+ *                            default 0,0,2: the two chains equal, the small quantizer first; 0,2,0 = rounds 2-3:
+ *                            decoder chain first -- better for blocking decode calls beside an encoder, bimodal for the `_dev` pipeline);
  *   LYRA_HIP_TILE_DIV_<K>=k  launch stage kernel K (ENC_S0 .. DEC_S2) as k slices of its tiles,
  *   LYRA_HIP_LDS_PAD_<K>=b   give its workgroups b extra bytes of LDS (occupancy experiments). */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);

@@ -770,7 +770,10 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   // vector kernel that must not run beside decoder stage 0.  With the screened quantizer (round 4: 1.5 M instructions, one
   // wavefront per 16 frames) that reason is gone, and the decoder-first schedule turned out BIMODAL -- 0.290 or 0.305 ms
   // per step at B = 4096 from run to run on one box, depending on which chain ends up waiting for the other -- while the
-  // small quantizer at the highest priority and both chains equal gives 0.290 every time (profiles/r04_prio_ab2.txt).
+  // small quantizer at the highest priority and both chains equal gives 0.290-0.292 every time (profiles/r04_prio_ab2.txt,
+  // r04_prio_ab4.txt; the decoder chain one level up is bimodal again: r04_prio_ab5.txt).  The price: a blocking decode call
+  // no longer overtakes an encode running beside it -- BatchLyraEncoder + BatchLyraDecoder on two host threads 6.4 M
+  // frames/s instead of 7.2 M (LYRA_HIP_PRIO=0,2,0 restores the old schedule for such a service).
   int prio_lo = 0, prio_hi = 0;
   if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
   int prio[3] = {prio_lo, prio_lo, getenv("LYRA_HIP_FLAT_PRIO") ? prio_lo : prio_hi};
