@@ -107,3 +107,39 @@ def test_noise_stream_accessor_and_twin_fetch_recovery():
         assert rc == 0, ctx.last_error()
     finally:
         ctx.close()
+
+
+def test_cu_partitioned_small_context_equals_whole_chip_context(monkeypatch):
+    """Contexts of <= 1024 streams create their streams with complementary CU masks (include/lyra_hip.h "Streams"); the
+    same work on whole-chip streams (LYRA_HIP_CU_MASKS=0) and on the opposite halves must give the same packets and PCM --
+    a CU mask changes where workgroups run, never what they compute -- also through the pipelined `_dev` entry point."""
+    import torch
+    import lyra_amd
+    B, bits, T = 300, 120, 6
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    pcm = torch.randint(-32768, 32768, (T, B, 320), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
+    ids = torch.arange(B, device=dev, dtype=torch.int32)
+    nb = lyra_amd.packet_size(bits)
+
+    def run(masks):
+        if masks is None:
+            monkeypatch.delenv("LYRA_HIP_CU_MASKS", raising=False)
+        else:
+            monkeypatch.setenv("LYRA_HIP_CU_MASKS", masks)
+        ctx = lyra_amd.LyraHip(max_streams=B)
+        try:
+            pk = [torch.zeros((B, nb), device=dev, dtype=torch.uint8) for _ in range(2)]
+            out = [torch.zeros((B, 320), device=dev, dtype=torch.int16) for _ in range(2)]
+            ctx.run_steps_dev(ids, bits, T, d_pcm_ring=pcm, d_packets=pk, d_pcm_out=out, encode=True, decode=True)
+            ctx.synchronize()
+            return [p.cpu().numpy() for p in pk], [o.cpu().numpy() for o in out]
+        finally:
+            ctx.close()
+
+    want = run("0")                                            # ordinary priority streams on the whole chip
+    for masks in (None, "ff00ff00,00ff00ff,ff00ff00,00ff00ff", "0000ffff,ffff0000,0000ffff,ffff0000"):
+        got = run(masks)
+        for a, b in zip(want[0] + want[1], got[0] + got[1]):
+            assert np.array_equal(a, b), f"masks {masks}"
