@@ -341,6 +341,13 @@ int lyra_hip_stream_wait(lyra_hip_ctx* ctx, void* caller_stream);
 /* on != 0: encode-side calls also wait for the MOST RECENT decode-side call, i.e. the library streams run
  * strictly in call order (one buffer set suffices; per-kernel timings are free of cross-stream contention). */
 int lyra_hip_set_serial(lyra_hip_ctx* ctx, int on);
+/* Stream priorities of the encode-side / decode-side / quantizer streams, 0 (lowest) .. 2 (highest); default 0, 0, 2.  The
+ * context is drained and the three streams are created anew (HIP fixes a priority at creation).  A context that serves
+ * BLOCKING decode calls beside another context's encoder (BatchLyraDecoder next to BatchLyraEncoder) wants its decode side
+ * first -- (0, 2, 2), the schedule of rounds 2-3: the decode kernels win the arbitration and the call returns sooner
+ * (7.2 M vs 6.4 M frames/s on two host threads); the `_dev` pipeline of one context wants the default (see
+ * LYRA_HIP_PRIO under lyra_hip_create).  CU-masked streams (contexts of <= 1024 streams) have no priority. */
+int lyra_hip_set_stream_priorities(lyra_hip_ctx* ctx, int encode_side, int decode_side, int quantizer);
 
 /* Per-stream state footprint in HBM (bytes) and the context's stream capacity. */
 size_t lyra_hip_state_bytes_per_stream(void);

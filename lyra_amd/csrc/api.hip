@@ -1437,6 +1437,31 @@ int lyra_hip_stream_wait(lyra_hip_ctx* c, void* caller_stream) {
   return 0;
 }
 
+// The encode-side, decode-side and quantizer streams at new priorities (0 lowest .. 2 highest; HIP fixes a stream's
+// priority at creation, so the streams are drained, destroyed and created again; CU masks, events and all bookkeeping stay).
+int lyra_hip_set_stream_priorities(lyra_hip_ctx* c, int enc, int dec, int quant) {
+  if (!c) return LYRA_HIP_EINVAL;
+  if (enc < 0 || enc > 2 || dec < 0 || dec > 2 || quant < 0 || quant > 2)
+    return fail(c, LYRA_HIP_EINVAL, "stream priorities are 0 (lowest) .. 2 (highest)");
+  DEVSCOPE(c);
+  int rc = sync_all(c);
+  if (rc) return rc;
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+  auto level = [&](int v) { return v >= 2 ? hi : (v == 1 ? (lo + hi) / 2 : lo); };
+  for (int k = 0; k < c->nsub; ++k) {
+    hipStream_t* st3[3] = {&c->se[k], &c->sd[k], &c->sq[k]};
+    const int want[3] = {level(enc), level(dec), level(quant)};
+    for (int i = 0; i < 3; ++i) {
+      hipStream_t fresh = nullptr;
+      HIPCHK(c, make_stream_kind(c, &fresh, i, want[i]));
+      (void)hipStreamDestroy(*st3[i]);
+      *st3[i] = fresh;
+    }
+  }
+  return 0;
+}
+
 int lyra_hip_set_serial(lyra_hip_ctx* c, int on) {
   if (!c) return LYRA_HIP_EINVAL;
   c->serial = on != 0;

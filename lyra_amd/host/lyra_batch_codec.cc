@@ -166,6 +166,9 @@ std::unique_ptr<BatchLyraDecoder> BatchLyraDecoder::Create(int sample_rate_hz, i
     LOG(ERROR) << "New model could not be instantiated.";
     return nullptr;
   }
+  // DecodeSamples blocks until its samples are on the host: next to an encoder context on another thread the decode
+  // kernels should win the arbitration (include/lyra_hip.h lyra_hip_set_stream_priorities)
+  if (lyra_hip_set_stream_priorities(ctx, 0, 2, 2) != 0) LOG(WARNING) << "stream priorities: " << lyra_hip_last_error(ctx);
   return std::unique_ptr<BatchLyraDecoder>(new BatchLyraDecoder(ctx, sample_rate_hz, num_streams));
 }
 

@@ -143,3 +143,40 @@ def test_cu_partitioned_small_context_equals_whole_chip_context(monkeypatch):
         got = run(masks)
         for a, b in zip(want[0] + want[1], got[0] + got[1]):
             assert np.array_equal(a, b), f"masks {masks}"
+
+
+def test_set_stream_priorities_recreates_streams_and_keeps_results():
+    """lyra_hip_set_stream_priorities drains the context and creates its three main streams anew; state, ordering and results
+    are unaffected (the decoder twin asks for decode-side-first this way, host/lyra_batch_codec.cc)."""
+    import torch
+    import lyra_amd
+    B, bits, T = 2100, 184, 5     # > 1024 streams: ordinary (priority) streams
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    pcm = torch.randint(-32768, 32768, (2 * T, B, 320), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
+    ids = torch.arange(B, device=dev, dtype=torch.int32)
+    nb = lyra_amd.packet_size(bits)
+    L = lyra_amd.codec._load()
+    L.lyra_hip_set_stream_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+
+    def run(switch):
+        ctx = lyra_amd.LyraHip(max_streams=B)
+        try:
+            pk = [torch.zeros((B, nb), device=dev, dtype=torch.uint8) for _ in range(2)]
+            out = [torch.zeros((B, 320), device=dev, dtype=torch.int16) for _ in range(2)]
+            kw = dict(d_pcm_ring=pcm, d_packets=pk, d_pcm_out=out, encode=True, decode=True)
+            ctx.run_steps_dev(ids, bits, T, first_step=0, **kw)
+            if switch:   # in the middle of a session, with work in flight
+                old = ctx.stream_handles() if hasattr(ctx, "stream_handles") else None
+                assert L.lyra_hip_set_stream_priorities(ctx.h, 0, 2, 2) == 0
+                assert L.lyra_hip_set_stream_priorities(ctx.h, 3, 0, 0) != 0 and b"0 (lowest)" in L.lyra_hip_last_error(ctx.h)
+            ctx.run_steps_dev(ids, bits, T, first_step=T, **kw)
+            ctx.synchronize()
+            return [p.cpu().numpy() for p in pk], [o.cpu().numpy() for o in out]
+        finally:
+            ctx.close()
+
+    a, b = run(False), run(True)
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert np.array_equal(x, y)
