@@ -125,6 +125,7 @@ def _load(path=None):
     L.lyra_hip_wait_for_stream.argtypes = [vp, vp]
     L.lyra_hip_stream_wait.argtypes = [vp, vp]
     L.lyra_hip_set_serial.argtypes = [vp, ci]
+    L.lyra_hip_set_stream_priorities.argtypes = [vp, ci, ci, ci]
     L.lyra_hip_state_bytes_per_stream.restype = C.c_size_t
     L.lyra_hip_max_streams.argtypes = [vp]
     L.lyra_hip_profile_enable.argtypes = [vp, C.c_uint]
@@ -355,6 +356,10 @@ class LyraHip:
     def profile_kernel_names(self):
         n = self.L.lyra_hip_profile_kernel_count()
         return [self.L.lyra_hip_profile_kernel_name(i).decode() for i in range(n)]
+
+    def set_stream_priorities(self, encode_side=0, decode_side=0, quantizer=2):
+        """Priorities (0 lowest .. 2 highest) of the context's three main streams; drains the context (include/lyra_hip.h)."""
+        self._chk(self.L.lyra_hip_set_stream_priorities(self.h, int(encode_side), int(decode_side), int(quantizer)))
 
     def profile_enable(self, on=True, only=None, every=1):
         """Bracket kernel launches with HIP events: all kernels, or only the named one(s); every `every`-th launch."""

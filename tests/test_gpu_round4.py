@@ -158,7 +158,6 @@ def test_set_stream_priorities_recreates_streams_and_keeps_results():
     ids = torch.arange(B, device=dev, dtype=torch.int32)
     nb = lyra_amd.packet_size(bits)
     L = lyra_amd.codec._load()
-    L.lyra_hip_set_stream_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
 
     def run(switch):
         ctx = lyra_amd.LyraHip(max_streams=B)
@@ -168,8 +167,7 @@ def test_set_stream_priorities_recreates_streams_and_keeps_results():
             kw = dict(d_pcm_ring=pcm, d_packets=pk, d_pcm_out=out, encode=True, decode=True)
             ctx.run_steps_dev(ids, bits, T, first_step=0, **kw)
             if switch:   # in the middle of a session, with work in flight
-                old = ctx.stream_handles() if hasattr(ctx, "stream_handles") else None
-                assert L.lyra_hip_set_stream_priorities(ctx.h, 0, 2, 2) == 0
+                ctx.set_stream_priorities(0, 2, 2)
                 assert L.lyra_hip_set_stream_priorities(ctx.h, 3, 0, 0) != 0 and b"0 (lowest)" in L.lyra_hip_last_error(ctx.h)
             ctx.run_steps_dev(ids, bits, T, first_step=T, **kw)
             ctx.synchronize()
