@@ -346,7 +346,8 @@ int lyra_hip_set_serial(lyra_hip_ctx* ctx, int on);
  * BLOCKING decode calls beside another context's encoder (BatchLyraDecoder next to BatchLyraEncoder) wants its decode side
  * first -- (0, 2, 2), the schedule of rounds 2-3: the decode kernels win the arbitration and the call returns sooner
  * (7.2 M vs 6.4 M frames/s on two host threads); the `_dev` pipeline of one context wants the default (see
- * LYRA_HIP_PRIO under lyra_hip_create).  CU-masked streams (contexts of <= 1024 streams) have no priority. */
+ * LYRA_HIP_PRIO under lyra_hip_create).  CU-masked streams (contexts of <= 1024 streams) have no priority.  Handles obtained
+ * earlier from lyra_hip_stream() / lyra_hip_stream_decode() / lyra_hip_stream_quantizer() are invalid afterwards. */
 int lyra_hip_set_stream_priorities(lyra_hip_ctx* ctx, int encode_side, int decode_side, int quantizer);
 
 /* Per-stream state footprint in HBM (bytes) and the context's stream capacity. */
