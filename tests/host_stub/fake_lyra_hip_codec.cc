@@ -66,6 +66,7 @@ int lyra_hip_encode(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* p
   return 0;
 }
 int lyra_hip_set_encoder_sample_rate(lyra_hip_ctx*, int) { return 0; }
+int lyra_hip_set_stream_priorities(lyra_hip_ctx*, int, int, int) { return 0; }
 int lyra_hip_encode_dtx(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, int num_bits, uint8_t* packets,
                         int32_t* packet_bytes) {
   const int nbytes = (num_bits + 7) / 8;
