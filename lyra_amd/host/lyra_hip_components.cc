@@ -1,9 +1,15 @@
 // lyra_hip_components.cc -- see lyra_hip_components.h.  Plain C++17 over the C ABI (include/lyra_hip.h); no HIP here.
 #include "lyra_hip_components.h"
 
+#include <algorithm>
 #include <atomic>
 #include <bitset>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <sched.h>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -24,116 +30,230 @@ constexpr int kMaxBits = 4 * LYRA_HIP_MAX_STAGES;
 // calls queueing on the context's call mutex.  A Combiner turns whatever calls of one kind are waiting into ONE batched
 // call of the C ABI: a caller appends its request; if nobody is executing it becomes the leader, takes everything that
 // is pending (its own request included), runs the batch and wakes the others; requests that arrive while a batch is on
-// the GPU form the next batch (group commit -- no timer, no added latency for a lone caller).  Results are per stream
-// and bit-identical to the B = 1 calls (the kernels are batch-invariant, tests/test_gpu_parity.py).
-struct CombinerStats { std::atomic<long> calls{0}, batches{0}, largest{0}; };
+// the GPU form the next batch (group commit).  Results are per stream and bit-identical to the B = 1 calls (the kernels
+// are batch-invariant, tests/test_gpu_parity.py).
+//
+// Round 5 (the per-object path ran at 27-33 k hops/s on 64-1,024 threads, below the 42 k of the CPU oracle on the same
+// cores: profiles/r04_plugin_mt_throughput.txt -- batches of 10-60 requests and a condition variable that woke EVERY
+// waiter of a kind after every batch):
+//  * every thread sleeps on a Waiter of its own and is woken exactly once, when its own request is done (or when it is
+//    handed the leadership); a finished batch is woken as a tree (the leader wakes the first kFan members, member i wakes
+//    members kFan * i + 1 ... kFan * i + kFan), so the wake-ups of a 1,000-request batch run on all host cores instead
+//    of serially on the leader;
+//  * leadership is handed to the oldest pending request before the finished batch is woken: the next device call starts
+//    while the previous batch's callers are still being scheduled;
+//  * adaptive gathering: callers that drive their codecs in lock-step (N threads, one hop each per round) arrive over
+//    the time the scheduler needs to wake them.  A leader that finds fewer requests pending than the previous batches of
+//    this kind held waits for the stragglers -- until that many are pending, at most kGatherBaseUs + kGatherPerReqUs per
+//    expected request (capped at kGatherMaxUs).  A lone caller (previous batches of one request) never waits, so a
+//    single codec's latency is unchanged (plugin_demo --bench); when callers leave, the expectation follows the batches
+//    actually seen within two calls.
+struct CombinerStats { std::atomic<long> calls{0}, batches{0}, largest{0}, gather_us{0}, exec_us{0}, timeouts{0}; };
+struct Waiter {   // one per host thread (thread_local, shared: a waker may still hold it while the thread exits)
+  std::mutex m;
+  std::condition_variable cv;
+};
 template <class Req>
 class Combiner {
  public:
+  enum { kPending = 0, kDone = 1, kLead = 2 };
+  // tunables (environment, read once; the defaults are what tools/plugin_mt_bench.sh measured best on a 256-core host)
+  static long EnvLong(const char* name, long dflt) { const char* v = std::getenv(name); return v ? std::atol(v) : dflt; }
+  const int kFan = (int)std::max(1L, EnvLong("LYRA_HIP_COMBINER_FAN", 4));
+  const long kQuietUs = EnvLong("LYRA_HIP_COMBINER_QUIET_US", 40);
+  const long kGatherBaseUs = EnvLong("LYRA_HIP_COMBINER_GATHER_US", 100), kGatherPerReqUs = 2, kGatherMaxUs = 3000;
+  const bool kYield = EnvLong("LYRA_HIP_COMBINER_YIELD", 1) != 0;
   template <class Exec>   // exec(std::vector<Req*>&): sets every request's rc
   void Run(Req* r, Exec exec) {
+    thread_local std::shared_ptr<Waiter> me = std::make_shared<Waiter>();
+    r->waiter = me;
+    r->state = kPending;
     std::unique_lock<std::mutex> l(mu_);
     pending_.push_back(r);
-    while (!r->done) {
-      if (busy_) { cv_.wait(l); continue; }
-      busy_ = true;
-      std::vector<Req*> batch;
-      batch.swap(pending_);
+    npending_.store((long)pending_.size(), std::memory_order_relaxed);
+    if (busy_) {
       l.unlock();
-      exec(batch);
-      stats.calls += (long)batch.size();
-      stats.batches += 1;
-      long big = stats.largest.load();
-      while ((long)batch.size() > big && !stats.largest.compare_exchange_weak(big, (long)batch.size())) {}
-      l.lock();
-      for (Req* q : batch) q->done = true;
-      busy_ = false;
-      cv_.notify_all();
+      {
+        std::unique_lock<std::mutex> lw(me->m);
+        me->cv.wait(lw, [&] { return r->state != kPending; });
+      }
+      if (r->state == kDone) {   // woken by the batch's leader or by the member above this one in the wake tree
+        WakeChildren(r);
+        return;
+      }
+      l.lock();                  // kLead: the previous leader handed the (still busy) combiner to this request
+    } else {
+      busy_ = true;
     }
+    // ---- leader ----
+    const long expect = std::max(last_[0], last_[1]);
+    if (expect > 1 && (long)pending_.size() < expect) {
+      // gather: requests are still arriving (the callers of the previous batch are being scheduled); take them along --
+      // until as many as before are pending, or nothing has arrived for kQuietUs, or the budget is spent.  Polled with
+      // sched_yield(): the threads that are about to arrive get this core.
+      l.unlock();
+      const auto g0 = std::chrono::steady_clock::now();
+      const auto deadline = g0 + std::chrono::microseconds(std::min(kGatherMaxUs, kGatherBaseUs + kGatherPerReqUs * expect));
+      auto last_arrival = g0;
+      long seen = npending_.load(std::memory_order_relaxed);
+      for (;;) {
+        if (kYield) sched_yield(); else __builtin_ia32_pause();
+        const auto now = std::chrono::steady_clock::now();
+        const long have = npending_.load(std::memory_order_relaxed);
+        if (have != seen) { seen = have; last_arrival = now; }
+        if (have >= expect || now >= deadline || now - last_arrival >= std::chrono::microseconds(kQuietUs)) break;
+      }
+      stats.gather_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g0).count();
+      if (seen < expect) stats.timeouts += 1;
+      l.lock();
+    }
+    auto batch = std::make_shared<std::vector<Req*>>();
+    batch->swap(pending_);
+    npending_.store(0, std::memory_order_relaxed);
+    l.unlock();
+    const auto e0 = std::chrono::steady_clock::now();
+    exec(*batch);
+    stats.exec_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - e0).count();
+    const long n = (long)batch->size();
+    stats.calls += n;
+    stats.batches += 1;
+    long big = stats.largest.load();
+    while (n > big && !stats.largest.compare_exchange_weak(big, n)) {}
+    Req* next = nullptr;
+    l.lock();
+    last_[1] = last_[0];
+    last_[0] = n;
+    if (pending_.empty()) busy_ = false; else next = pending_.front();   // else: busy_ stays set for `next`
+    l.unlock();
+    if (next) Signal(next, kLead);
+    // wake the batch: this request's slot in the tree is taken by the batch's first other member
+    std::vector<Req*>& b = *batch;
+    int self = 0;
+    for (int i = 0; i < (int)b.size(); ++i) if (b[i] == r) { self = i; break; }
+    std::swap(b[0], b[self]);   // the leader is the root (index 0) and needs no wake-up
+    for (int i = 0; i < (int)b.size(); ++i) { b[i]->tree = batch; b[i]->tree_index = i; }
+    WakeChildren(r);
   }
   CombinerStats stats;
  private:
+  static void Signal(Req* q, int state) {
+    std::shared_ptr<Waiter> w = q->waiter;   // q lives on its caller's stack and may be gone right after the store
+    { std::lock_guard<std::mutex> lw(w->m); q->state = state; }
+    w->cv.notify_one();
+  }
+  // member i of a finished batch wakes members kFan * i + 1 ... kFan * i + kFan (all still blocked, so their requests
+  // are alive; the vector itself is shared, the leader may have returned)
+  void WakeChildren(Req* r) {
+    const std::shared_ptr<std::vector<Req*>> tree = std::move(r->tree);
+    if (!tree) return;
+    const long n = (long)tree->size(), i = r->tree_index;
+    for (long c = kFan * i + 1; c <= kFan * i + kFan && c < n; ++c) Signal((*tree)[c], kDone);
+  }
   std::mutex mu_;
-  std::condition_variable cv_;
   std::vector<Req*> pending_;
+  std::atomic<long> npending_{0};       // pending_.size(), readable without mu_ by the gathering leader
   bool busy_ = false;
+  long last_[2] = {1, 1};               // sizes of the two latest batches
 };
 struct HopReq {   // one hop in, one vector out, of one stream
-  int32_t id; const void* in; void* out; int arg; int rc; bool done;
+  int32_t id; const void* in; void* out; int arg; int rc;
+  int state = 0;                                   // Combiner: kPending / kDone / kLead, guarded by waiter->m
+  std::shared_ptr<Waiter> waiter;
+  std::shared_ptr<std::vector<HopReq*>> tree;      // the finished batch this request belongs to, and its place in it
+  long tree_index = 0;
 };
 
-// One GPU context per process, shared by all plugin objects; each object owns a stream id.
+// Two GPU contexts per process, shared by all plugin objects; each object owns a stream id (valid in both).
+// The C ABI wants the calls on ONE context serialised (they share its staging buffers), and the plugin contract makes every
+// hop four blocking device calls: with one context the four kinds of calls queue behind one mutex.  Encoder state and
+// decoder state of a stream are disjoint (state_layout.h: one region per kernel), so the extractor-side kinds (Extract,
+// log-mel, Quantize) run on one context and the decoder-side kinds (DecodeToLossyFeatures, AddFeatures + GenerateSamples)
+// on a second one: two device calls in flight, on streams that the small-context CU partition already keeps on
+// complementary halves of the chip.  The second context costs one more copy of the 3 MB of weights and of the (unused
+// half of the) per-stream state.
 class SharedContext {
  public:
   static SharedContext& Get() { static SharedContext s; return s; }
   int device = 0;
   int max_streams = 1024;
+  enum Side { kEncSide, kDecSide, kSides };
 
   lyra_hip_ctx* Acquire(const std::string& model_dir, int* stream_id) {
     std::lock_guard<std::mutex> l(mu_);
-    if (!ctx_) {
-      if (lyra_hip_create(model_dir.c_str(), device, max_streams, LYRA_HIP_REQUANT_DEFAULT, &ctx_) != 0) {
-        LOG(ERROR) << "lyra_hip_create failed: " << lyra_hip_last_error(nullptr);
-        ctx_ = nullptr;
-        return nullptr;
-      }
+    if (!side_[0].ctx) {
+      for (int k = 0; k < kSides; ++k)
+        if (lyra_hip_create(model_dir.c_str(), device, max_streams, LYRA_HIP_REQUANT_DEFAULT, &side_[k].ctx) != 0) {
+          LOG(ERROR) << "lyra_hip_create failed: " << lyra_hip_last_error(nullptr);
+          side_[k].ctx = nullptr;
+          DestroyAll();
+          return nullptr;
+        }
       for (int i = max_streams - 1; i >= 0; --i) free_.push_back(i);
     }
     if (free_.empty()) { LOG(ERROR) << "No free stream slot (SetMaxStreams)."; return nullptr; }
     const int32_t id = free_.back();
-    {
-      // The C ABI wants every call on a context serialised, and the reset touches the same staging buffers
-      // and id-stamp table as Extract / Generate running on other threads' objects: take the call mutex.
-      std::lock_guard<std::mutex> lc(call_mu_);
-      if (lyra_hip_reset_streams(ctx_, &id, 1) != 0) {
-        LOG(ERROR) << "lyra_hip_reset_streams failed: " << lyra_hip_last_error(ctx_);
-        if (users_ == 0) { lyra_hip_destroy(ctx_); ctx_ = nullptr; free_.clear(); }
+    for (int k = 0; k < kSides; ++k) {
+      // The reset touches the same staging buffers and id-stamp table as the calls running on other threads' objects:
+      // take the context's call mutex.
+      std::lock_guard<std::mutex> lc(side_[k].call_mu);
+      if (lyra_hip_reset_streams(side_[k].ctx, &id, 1) != 0) {
+        LOG(ERROR) << "lyra_hip_reset_streams failed: " << lyra_hip_last_error(side_[k].ctx);
+        if (users_ == 0) DestroyAll();
         return nullptr;   // the slot stays on the free list
       }
     }
     free_.pop_back();
     ++users_;
     *stream_id = id;
-    return ctx_;
+    return side_[0].ctx;
   }
   void Release(int stream_id) {
     std::lock_guard<std::mutex> l(mu_);
     free_.push_back(stream_id);
-    if (--users_ == 0) {
-      std::lock_guard<std::mutex> lc(call_mu_);   // no call of another thread may still be inside the context
-      lyra_hip_destroy(ctx_);
-      ctx_ = nullptr;
-      free_.clear();
-    }
+    if (--users_ == 0) DestroyAll();
   }
-  std::mutex& call_mutex() { return call_mu_; }  // the C ABI wants calls on one context serialised
 
   // ---- combined calls (see Combiner) ---------------------------------------------------------------------
   enum Kind { kExtract, kLogMel, kGenerate, kQuantize, kDequantize, kKinds };
-  // in / out element counts and sizes per request of each kind
-  int Call(Kind kind, lyra_hip_ctx* ctx, int32_t id, const void* in, void* out, int arg = 0) {
-    HopReq r{id, in, out, arg, -1, false};
-    comb_[kind].Run(&r, [&](std::vector<HopReq*>& batch) { Execute(kind, ctx, batch); });
+  static Side SideOf(Kind kind) { return kind == kGenerate || kind == kDequantize ? kDecSide : kEncSide; }
+  const char* LastError(Kind kind) { return lyra_hip_last_error(side_[SideOf(kind)].ctx); }
+  int Call(Kind kind, int32_t id, const void* in, void* out, int arg = 0) {
+    HopReq r{id, in, out, arg, -1};
+    comb_[kind].Run(&r, [&](std::vector<HopReq*>& batch) { Execute(kind, batch); });
     return r.rc;
   }
   const CombinerStats& stats(Kind kind) const { return comb_[kind].stats; }
 
  private:
-  void Execute(Kind kind, lyra_hip_ctx* ctx, std::vector<HopReq*>& batch) {
+  struct PerSide {
+    lyra_hip_ctx* ctx = nullptr;
+    std::mutex call_mu;               // the C ABI wants the calls on one context serialised
+    std::vector<int32_t> ids;         // staging of a combined call (guarded by call_mu)
+    std::vector<uint8_t> in, out;
+  };
+  void DestroyAll() {                 // mu_ held
+    for (int k = 0; k < kSides; ++k) {
+      std::lock_guard<std::mutex> lc(side_[k].call_mu);   // no call of another thread may still be inside the context
+      if (side_[k].ctx) lyra_hip_destroy(side_[k].ctx);
+      side_[k].ctx = nullptr;
+    }
+    free_.clear();
+  }
+  void Execute(Kind kind, std::vector<HopReq*>& batch) {
     if (kind == kQuantize) {   // requests of different bit rates cannot share a call: one call per rate present
       std::vector<HopReq*> todo(batch), same, rest;   // (the caller still needs `batch` to mark its requests done)
       while (!todo.empty()) {
         same.clear();
         rest.clear();
         for (HopReq* q : todo) (q->arg == todo[0]->arg ? same : rest).push_back(q);
-        ExecuteUniform(kind, ctx, same);
+        ExecuteUniform(kind, same);
         todo.swap(rest);
       }
       return;
     }
-    ExecuteUniform(kind, ctx, batch);
+    ExecuteUniform(kind, batch);
   }
-  void ExecuteUniform(Kind kind, lyra_hip_ctx* ctx, std::vector<HopReq*>& batch) {
+  void ExecuteUniform(Kind kind, std::vector<HopReq*>& batch) {
     static const size_t kIn[kKinds] = {kHop * sizeof(int16_t), kHop * sizeof(int16_t), kNumFeatures * sizeof(float),
                                        kNumFeatures * sizeof(float), LYRA_HIP_MAX_STAGES * sizeof(int32_t)};
     static const size_t kOut[kKinds] = {kNumFeatures * sizeof(float), LYRA_HIP_NUM_MEL * sizeof(float),
@@ -141,21 +261,22 @@ class SharedContext {
                                         kNumFeatures * sizeof(float)};
     const int B = (int)batch.size();
     int rc;
-    std::lock_guard<std::mutex> l(call_mu_);
+    PerSide& S = side_[SideOf(kind)];
+    std::lock_guard<std::mutex> l(S.call_mu);
     if (B == 1) {   // the common uncontended case: no staging copies
       HopReq* q = batch[0];
-      rc = Dispatch(kind, ctx, &q->id, 1, q->in, q->out, q->arg);
+      rc = Dispatch(kind, S.ctx, &q->id, 1, q->in, q->out, q->arg);
     } else {
-      ids_.resize(B);
-      in_.resize((size_t)B * kIn[kind]);
-      out_.resize((size_t)B * kOut[kind]);
+      S.ids.resize(B);
+      S.in.resize((size_t)B * kIn[kind]);
+      S.out.resize((size_t)B * kOut[kind]);
       for (int i = 0; i < B; ++i) {
-        ids_[i] = batch[i]->id;
-        std::memcpy(in_.data() + (size_t)i * kIn[kind], batch[i]->in, kIn[kind]);
+        S.ids[i] = batch[i]->id;
+        std::memcpy(S.in.data() + (size_t)i * kIn[kind], batch[i]->in, kIn[kind]);
       }
-      rc = Dispatch(kind, ctx, ids_.data(), B, in_.data(), out_.data(), batch[0]->arg);
+      rc = Dispatch(kind, S.ctx, S.ids.data(), B, S.in.data(), S.out.data(), batch[0]->arg);
       if (rc == 0)
-        for (int i = 0; i < B; ++i) std::memcpy(batch[i]->out, out_.data() + (size_t)i * kOut[kind], kOut[kind]);
+        for (int i = 0; i < B; ++i) std::memcpy(batch[i]->out, S.out.data() + (size_t)i * kOut[kind], kOut[kind]);
     }
     for (HopReq* q : batch) q->rc = rc;
   }
@@ -170,10 +291,8 @@ class SharedContext {
     }
   }
   Combiner<HopReq> comb_[kKinds];
-  std::vector<int32_t> ids_;        // staging of a combined call (guarded by call_mu_)
-  std::vector<uint8_t> in_, out_;
-  std::mutex mu_, call_mu_;
-  lyra_hip_ctx* ctx_ = nullptr;
+  PerSide side_[kSides];
+  std::mutex mu_;
   std::vector<int> free_;
   int users_ = 0;
 };
@@ -202,8 +321,8 @@ class SoundStreamEncoderHip : public FeatureExtractorInterface {
       return std::nullopt;
     }
     std::vector<float> out(kNumFeatures);
-    if (SharedContext::Get().Call(SharedContext::kExtract, h_.ctx(), h_.id(), audio.data(), out.data()) != 0) {
-      LOG(ERROR) << "Unable to run the SoundStream encoder: " << lyra_hip_last_error(h_.ctx());
+    if (SharedContext::Get().Call(SharedContext::kExtract, h_.id(), audio.data(), out.data()) != 0) {
+      LOG(ERROR) << "Unable to run the SoundStream encoder: " << SharedContext::Get().LastError(SharedContext::kExtract);
       return std::nullopt;
     }
     return out;
@@ -222,7 +341,7 @@ class LogMelHip : public FeatureExtractorInterface {
       return std::nullopt;
     }
     std::vector<float> out(LYRA_HIP_NUM_MEL);
-    if (SharedContext::Get().Call(SharedContext::kLogMel, h_.ctx(), h_.id(), audio.data(), out.data()) != 0)
+    if (SharedContext::Get().Call(SharedContext::kLogMel, h_.id(), audio.data(), out.data()) != 0)
       return std::nullopt;
     return out;
   }
@@ -246,7 +365,7 @@ class ResidualVectorQuantizerHip : public VectorQuantizerInterface {
     if (static_cast<int>(features.size()) != kNumFeatures) return std::nullopt;
     if (num_bits == 0) return std::string();
     int32_t idx[LYRA_HIP_MAX_STAGES];
-    if (SharedContext::Get().Call(SharedContext::kQuantize, h_.ctx(), h_.id(), features.data(), idx, num_bits) != 0) {
+    if (SharedContext::Get().Call(SharedContext::kQuantize, h_.id(), features.data(), idx, num_bits) != 0) {
       LOG(ERROR) << "Unable to invoke the quantize runner.";
       return std::nullopt;
     }
@@ -269,7 +388,7 @@ class ResidualVectorQuantizerHip : public VectorQuantizerInterface {
     for (int i = 0; i < LYRA_HIP_MAX_STAGES; ++i)
       idx[i] = i < num_bits / 4 ? static_cast<int32_t>(std::bitset<4>(quantized.substr(4 * i, 4)).to_ulong()) : -1;
     std::vector<float> out(kNumFeatures);
-    if (SharedContext::Get().Call(SharedContext::kDequantize, h_.ctx(), h_.id(), idx, out.data()) != 0) {
+    if (SharedContext::Get().Call(SharedContext::kDequantize, h_.id(), idx, out.data()) != 0) {
       LOG(ERROR) << "Unable to invoke the decode runner.";
       return std::nullopt;
     }
@@ -287,7 +406,7 @@ class LyraGanModelHip : public GenerativeModel {
   bool RunConditioning(const std::vector<float>& features) override {
     hop_.resize(kHop);
     if (static_cast<int>(features.size()) != kNumFeatures) return false;
-    return SharedContext::Get().Call(SharedContext::kGenerate, h_.ctx(), h_.id(), features.data(), hop_.data()) == 0;
+    return SharedContext::Get().Call(SharedContext::kGenerate, h_.id(), features.data(), hop_.data()) == 0;
   }
   std::optional<std::vector<int16_t>> RunModel(int num_samples) override {
     return std::vector<int16_t>(hop_.begin() + next_sample_in_hop(), hop_.begin() + next_sample_in_hop() + num_samples);
@@ -312,6 +431,9 @@ HipCallStats GetHipCallStats() {
     const CombinerStats& c = SharedContext::Get().stats(static_cast<SharedContext::Kind>(k));
     st.calls += c.calls.load();
     st.device_calls += c.batches.load();
+    st.gather_us += c.gather_us.load();
+    st.exec_us += c.exec_us.load();
+    st.gather_timeouts += c.timeouts.load();
     if (c.largest.load() > st.largest_batch) st.largest_batch = c.largest.load();
   }
   return st;

@@ -25,7 +25,7 @@ std::unique_ptr<FeatureExtractorInterface> CreateLogMelExtractor(const ghc::file
 
 // How the plugin calls of this process were served so far: calls made by plugin objects, device calls they became, and
 // the largest number of streams one device call carried.
-struct HipCallStats { long calls = 0, device_calls = 0, largest_batch = 0; };
+struct HipCallStats { long calls = 0, device_calls = 0, largest_batch = 0, gather_us = 0, exec_us = 0, gather_timeouts = 0; };
 HipCallStats GetHipCallStats();
 
 // Process-wide settings of the shared context (call before the first Create*).

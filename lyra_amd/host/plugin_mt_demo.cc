@@ -4,7 +4,10 @@
 // pcm_in is [frames][streams][320] int16; thread s owns the extractor / quantizer / generative model of stream s and
 // runs all frames of it.  Writes one '0'/'1' line per (frame, stream) and the decoded PCM in the input's layout; prints
 // how many plugin calls became how many device calls.
+#include <sched.h>
+
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,8 +21,33 @@
 
 using namespace chromemedia::codec;
 
+// A container that is given a CPU *quota* (cgroup v2 cpu.max) smaller than the CPUs it may run on -- 16 CPUs' worth of time on
+// a 256-CPU host is what the GPU boxes of this pool have -- spreads a thousand codec threads over all 256 run queues; CFS
+// hands the quota out in per-CPU slices, the pool is empty after a few dozen CPUs took one, and every thread that wakes up on
+// another CPU waits for the next 100 ms period (cpu.stat: nr_throttled / throttled_usec), whoever it was about to wake up
+// included.  Keeping the process on as many CPUs as the quota is worth avoids that.  LYRA_DEMO_CPUS=n overrides, 0 = leave.
+static int LimitAffinityToCpuQuota() {
+  long want = -1;
+  if (const char* e = std::getenv("LYRA_DEMO_CPUS")) want = std::atol(e);
+  if (want < 0) {
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string quota; long period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0) want = (long)std::ceil(std::atof(quota.c_str()) / (double)period);
+  }
+  if (want <= 0) return 0;
+  cpu_set_t have, keep;
+  if (sched_getaffinity(0, sizeof(have), &have) != 0) return 0;
+  if (CPU_COUNT(&have) <= want) return 0;
+  CPU_ZERO(&keep);
+  long n = 0;
+  for (int c = 0; c < CPU_SETSIZE && n < want; ++c) if (CPU_ISSET(c, &have)) { CPU_SET(c, &keep); ++n; }
+  return sched_setaffinity(0, sizeof(keep), &keep) == 0 ? (int)n : 0;
+}
+
 int main(int argc, char** argv) {
   if (argc != 7) { std::fprintf(stderr, "usage: %s model_dir pcm_in num_streams num_bits bits_out pcm_out\n", argv[0]); return 2; }
+  const int cpus = LimitAffinityToCpuQuota();
+  if (cpus) std::fprintf(stderr, "affinity limited to %d CPUs (the container's CPU quota)\n", cpus);
   const std::string model_dir = argv[1];
   const int n = std::atoi(argv[3]), num_bits = std::atoi(argv[4]);
   std::ifstream in(argv[2], std::ios::binary);
@@ -68,7 +96,8 @@ int main(int argc, char** argv) {
   std::ofstream pcm_out(argv[6], std::ios::binary);
   pcm_out.write(reinterpret_cast<const char*>(out.data()), out.size() * 2);
   const HipCallStats st = GetHipCallStats();
-  std::printf("plugin_calls %ld device_calls %ld largest_batch %ld\n", st.calls, st.device_calls, st.largest_batch);
+  std::printf("plugin_calls %ld device_calls %ld largest_batch %ld  (leaders: %.3f s in device calls, %.3f s gathering, %ld gathers timed out)\n",
+              st.calls, st.device_calls, st.largest_batch, st.exec_us * 1e-6, st.gather_us * 1e-6, st.gather_timeouts);
   // one hop per plugin call and stream, every call a blocking host call (the reference's plugin contract): what the
   // call-combining layer makes of `n` threads driving `n` codecs
   std::printf("threads %d frames_per_stream %d seconds %.4f frames_per_s %.1f (extract + quantize + dequantize + generate per frame)\n",

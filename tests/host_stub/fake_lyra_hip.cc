@@ -7,15 +7,16 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <thread>
 
 #include "../../include/lyra_hip.h"
 
-struct lyra_hip_ctx { int max_streams; };
+struct lyra_hip_ctx { int max_streams; std::atomic<int> in_call{0}; };
 static std::atomic<long> g_calls{0}, g_rows{0};
-static std::atomic<int> g_in_call{0}, g_overlap{0};
+static std::atomic<int> g_overlap{0};
 
 extern "C" long fake_device_calls() { return g_calls.load(); }
 extern "C" long fake_device_rows() { return g_rows.load(); }
@@ -23,13 +24,14 @@ extern "C" int fake_overlapping_calls() { return g_overlap.load(); }   // calls 
 
 namespace {
 struct CallScope {
-  CallScope(int B) {
-    if (g_in_call.fetch_add(1) != 0) g_overlap.fetch_add(1);   // the C ABI wants calls on a context serialised
+  lyra_hip_ctx* c;
+  CallScope(lyra_hip_ctx* c_, int B) : c(c_) {
+    if (c->in_call.fetch_add(1) != 0) g_overlap.fetch_add(1);   // the C ABI wants the calls on ONE context serialised
     g_calls += 1;
     g_rows += B;
-    std::this_thread::sleep_for(std::chrono::microseconds(300));
+    { static const int us = getenv("FAKE_CALL_US") ? atoi(getenv("FAKE_CALL_US")) : 300; if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us)); }
   }
-  ~CallScope() { g_in_call.fetch_sub(1); }
+  ~CallScope() { c->in_call.fetch_sub(1); }
 };
 bool distinct(const int32_t* ids, int B) {
   std::set<int32_t> s(ids, ids + B);
@@ -39,41 +41,41 @@ bool distinct(const int32_t* ids, int B) {
 
 extern "C" {
 int lyra_hip_create(const char*, int, int max_streams, int, lyra_hip_ctx** out) {
-  *out = new lyra_hip_ctx{max_streams};
+  *out = new lyra_hip_ctx; (*out)->max_streams = max_streams;
   return 0;
 }
 void lyra_hip_destroy(lyra_hip_ctx* c) { delete c; }
 const char* lyra_hip_last_error(const lyra_hip_ctx*) { return "fake"; }
 int lyra_hip_reset_streams(lyra_hip_ctx*, const int32_t*, int) { return 0; }
 int lyra_hip_extract(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, float* feats) {
-  CallScope s(B);
+  CallScope s(c, B);
   if (B > c->max_streams || !distinct(ids, B)) return LYRA_HIP_EINVAL;
   for (int b = 0; b < B; ++b)
     for (int i = 0; i < 64; ++i) feats[b * 64 + i] = (float)ids[b] * 1000.f + (float)pcm[b * 320 + i] + (float)i * 0.5f;
   return 0;
 }
-int lyra_hip_logmel(lyra_hip_ctx*, const int32_t* ids, int B, const int16_t* pcm, float* mel) {
-  CallScope s(B);
+int lyra_hip_logmel(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, float* mel) {
+  CallScope s(c, B);
   if (!distinct(ids, B)) return LYRA_HIP_EINVAL;
   for (int b = 0; b < B; ++b)
     for (int i = 0; i < 160; ++i) mel[b * 160 + i] = (float)ids[b] + (float)pcm[b * 320 + i] * 0.25f;
   return 0;
 }
-int lyra_hip_generate(lyra_hip_ctx*, const int32_t* ids, int B, const float* feats, int16_t* pcm) {
-  CallScope s(B);
+int lyra_hip_generate(lyra_hip_ctx* c, const int32_t* ids, int B, const float* feats, int16_t* pcm) {
+  CallScope s(c, B);
   if (!distinct(ids, B)) return LYRA_HIP_EINVAL;
   for (int b = 0; b < B; ++b)
     for (int i = 0; i < 320; ++i) pcm[b * 320 + i] = (int16_t)((int)feats[b * 64 + (i & 63)] % 1000 + ids[b] + i);
   return 0;
 }
-int lyra_hip_rvq_encode(lyra_hip_ctx*, int B, const float* feats, int num_bits, int32_t* idx) {
-  CallScope s(B);
+int lyra_hip_rvq_encode(lyra_hip_ctx* c, int B, const float* feats, int num_bits, int32_t* idx) {
+  CallScope s(c, B);
   for (int b = 0; b < B; ++b)
     for (int k = 0; k < 46; ++k) idx[b * 46 + k] = k < num_bits / 4 ? (((int)feats[b * 64 + k] + k) & 15) : -1;
   return 0;
 }
-int lyra_hip_rvq_decode(lyra_hip_ctx*, int B, const int32_t* idx, float* feats) {
-  CallScope s(B);
+int lyra_hip_rvq_decode(lyra_hip_ctx* c, int B, const int32_t* idx, float* feats) {
+  CallScope s(c, B);
   for (int b = 0; b < B; ++b)
     for (int i = 0; i < 64; ++i) feats[b * 64 + i] = (float)(idx[b * 46 + (i % 46)] + 2 * i);
   return 0;

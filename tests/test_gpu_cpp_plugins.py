@@ -64,7 +64,7 @@ def test_cpp_plugins_many_threads_combined_calls(oracle_default, golden_dir, tmp
             assert lines[f * n + s_] == want, f"bit string differs at hop {f}, stream {s_}"
     out = np.fromfile(pout, np.int16).reshape(T, n, 320)
     assert np.array_equal(out, ref["pcm"])
-    first = r.stdout.splitlines()[0].split()          # "plugin_calls N device_calls M largest_batch K"; a throughput line follows
+    first = [l for l in r.stdout.splitlines() if l.startswith("plugin_calls")][0].split()[:6]   # "plugin_calls N device_calls M largest_batch K (...)"
     stats = dict(zip(first[0::2], map(int, first[1::2])))
     assert stats["plugin_calls"] == 4 * T * n
     assert stats["device_calls"] < stats["plugin_calls"] and stats["largest_batch"] >= 2, stats
