@@ -227,6 +227,13 @@ def test_cpp_plugin_layer_host_logic_against_fake_abi(tmp_path):
     st = dict(zip(r.stdout.split()[0::2], map(int, r.stdout.split()[1::2])))
     assert st["plugin_calls"] == 24 * 20 * 5 == st["fake_rows"] and st["overlapping"] == 0
     assert st["device_calls"] < st["plugin_calls"] and st["largest_batch"] >= 2, st
+    # many more threads than cores: batches of dozens of requests, woken as a tree, leadership handed on, leaders gathering
+    # stragglers; the extractor-side and decoder-side kinds run on two contexts (the fake counts overlap per context)
+    r = subprocess.run([exe, "160", "8"], capture_output=True, text=True, timeout=300, env=dict(os.environ, FAKE_CALL_US="50"))
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    st = dict(zip(r.stdout.split()[0::2], map(int, r.stdout.split()[1::2])))
+    assert st["plugin_calls"] == 160 * 8 * 5 == st["fake_rows"] and st["overlapping"] == 0
+    assert st["largest_batch"] >= 4 and st["device_calls"] * 2 < st["plugin_calls"], st
 
 
 REF_MODEL_DIR = "/root/reference/lyra/model_coeffs"
