@@ -43,11 +43,12 @@ constexpr int kMaxBits = 4 * LYRA_HIP_MAX_STAGES;
 //  * leadership is handed to the oldest pending request before the finished batch is woken: the next device call starts
 //    while the previous batch's callers are still being scheduled;
 //  * adaptive gathering: callers that drive their codecs in lock-step (N threads, one hop each per round) arrive over
-//    the time the scheduler needs to wake them.  A leader that finds fewer requests pending than the previous batches of
-//    this kind held waits for the stragglers -- until that many are pending, at most kGatherBaseUs + kGatherPerReqUs per
-//    expected request (capped at kGatherMaxUs).  A lone caller (previous batches of one request) never waits, so a
-//    single codec's latency is unchanged (plugin_demo --bench); when callers leave, the expectation follows the batches
-//    actually seen within two calls.
+//    the time the scheduler needs to wake them.  A leader that finds fewer requests pending than the previous two batches
+//    of this kind held takes the stragglers along: it polls (sched_yield: the arriving threads get the core) until that
+//    many are pending, or nothing has arrived for kQuietUs, or kGatherBaseUs + kGatherPerReqUs per expected request
+//    (capped at kGatherMaxUs) have passed.  A lone caller (previous batches of one request) never waits, so a single
+//    codec's latency is unchanged (plugin_demo --bench); when callers leave, the expectation follows the batches actually
+//    seen within two calls.
 struct CombinerStats { std::atomic<long> calls{0}, batches{0}, largest{0}, gather_us{0}, exec_us{0}, timeouts{0}; };
 struct Waiter {   // one per host thread (thread_local, shared: a waker may still hold it while the thread exits)
   std::mutex m;
@@ -57,12 +58,12 @@ template <class Req>
 class Combiner {
  public:
   enum { kPending = 0, kDone = 1, kLead = 2 };
-  // tunables (environment, read once; the defaults are what tools/plugin_mt_bench.sh measured best on a 256-core host)
+  // tunables (environment, read once; tools/plugin_mt_sweep.sh: 10-150 us of quiet time and fan-outs 2-16 are within
+  // run-to-run spread of each other at 256 and 1,024 threads)
   static long EnvLong(const char* name, long dflt) { const char* v = std::getenv(name); return v ? std::atol(v) : dflt; }
   const int kFan = (int)std::max(1L, EnvLong("LYRA_HIP_COMBINER_FAN", 4));
   const long kQuietUs = EnvLong("LYRA_HIP_COMBINER_QUIET_US", 40);
   const long kGatherBaseUs = EnvLong("LYRA_HIP_COMBINER_GATHER_US", 100), kGatherPerReqUs = 2, kGatherMaxUs = 3000;
-  const bool kYield = EnvLong("LYRA_HIP_COMBINER_YIELD", 1) != 0;
   template <class Exec>   // exec(std::vector<Req*>&): sets every request's rc
   void Run(Req* r, Exec exec) {
     thread_local std::shared_ptr<Waiter> me = std::make_shared<Waiter>();
@@ -97,7 +98,7 @@ class Combiner {
       auto last_arrival = g0;
       long seen = npending_.load(std::memory_order_relaxed);
       for (;;) {
-        if (kYield) sched_yield(); else __builtin_ia32_pause();
+        sched_yield();
         const auto now = std::chrono::steady_clock::now();
         const long have = npending_.load(std::memory_order_relaxed);
         if (have != seen) { seen = have; last_arrival = now; }

@@ -11,8 +11,6 @@ run LYRA_HIP_COMBINER_QUIET_US=0
 run LYRA_HIP_COMBINER_QUIET_US=10
 run LYRA_HIP_COMBINER_QUIET_US=40
 run LYRA_HIP_COMBINER_QUIET_US=150
-run LYRA_HIP_COMBINER_QUIET_US=40 LYRA_HIP_COMBINER_YIELD=0
-run LYRA_HIP_COMBINER_QUIET_US=150 LYRA_HIP_COMBINER_YIELD=0
 run LYRA_HIP_COMBINER_QUIET_US=40 LYRA_HIP_COMBINER_FAN=16
 run LYRA_HIP_COMBINER_QUIET_US=40 LYRA_HIP_COMBINER_FAN=2
 run LYRA_HIP_COMBINER_QUIET_US=400 LYRA_HIP_COMBINER_GATHER_US=1000
