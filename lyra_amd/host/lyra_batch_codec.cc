@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 
@@ -155,7 +156,7 @@ int GetNumSamplesToGenerate(int num_samples_requested, int samples_generated_so_
 
 BatchLyraDecoder::BatchLyraDecoder(lyra_hip_ctx* ctx, int sample_rate_hz, int num_streams)
     : ctx_(ctx), sample_rate_hz_(sample_rate_hz), num_streams_(num_streams), streams_(num_streams),
-      leftover_(num_streams) {}
+      all_ids_(Iota(num_streams)), leftover_(num_streams) {}
 
 std::unique_ptr<BatchLyraDecoder> BatchLyraDecoder::Create(int sample_rate_hz, int num_channels,
                                                             const ghc::filesystem::path& model_path,
@@ -179,8 +180,7 @@ bool BatchLyraDecoder::is_comfort_noise(int stream) const {
 }
 
 bool BatchLyraDecoder::SetEncodedPackets(absl::Span<const uint8_t> encoded) {
-  const std::vector<int32_t> all = Iota(num_streams_);
-  return SetEncodedPackets(absl::MakeConstSpan(all), encoded);
+  return SetEncodedPackets(absl::MakeConstSpan(all_ids_), encoded);
 }
 
 bool BatchLyraDecoder::SetEncodedPackets(absl::Span<const int32_t> streams, absl::Span<const uint8_t> encoded) {
@@ -206,8 +206,8 @@ bool BatchLyraDecoder::SetEncodedPackets(absl::Span<const int32_t> streams, absl
     Entry e;
     e.estimated = false;
     e.bits = bits;
-    e.packet.assign(encoded.begin() + i * packet_size, encoded.begin() + (i + 1) * packet_size);
-    st.queue.push_back(std::move(e));   // DecodeToLossyFeatures + AddFeatures: done on the device when the hop starts
+    std::memcpy(e.packet, encoded.data() + i * packet_size, static_cast<size_t>(packet_size));
+    st.queue.push_back(e);   // DecodeToLossyFeatures + AddFeatures: done on the device when the hop starts
   }
   return true;
 }
@@ -281,21 +281,24 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
 // streams that start a hop, one call that cuts / cross-fades every stream's slice into the request's output, one
 // noise-estimator call for the received hops that completed.  Nothing synchronises here.
 bool BatchLyraDecoder::EnqueueInternal(int n) {
-  for (Stream& st : streams_) st.done = 0;
-  std::vector<int32_t> active, need_packet[3], need_estimated, need_cng, need_noise;
+  std::vector<int32_t>(&need_packet)[3] = need_packet_;
+  std::vector<int32_t>&need_estimated = need_estimated_, &need_cng = need_cng_, &need_noise = need_noise_;
+  std::vector<uint8_t>(&packets)[3] = packets_;
+  std::vector<lyra_hip_twin_slice>& slices = slices_;
   static const int kBits[3] = {64, 120, 184};
-  std::vector<uint8_t> packets;
-  std::vector<lyra_hip_twin_slice> slices;
-  while (true) {
-    active.clear();
-    for (int s = 0; s < num_streams_; ++s)
-      if (streams_[s].done < n) active.push_back(s);
-    if (active.empty()) break;
+  // ONE pass over the streams per round (round 5: the state machine, the gathering of the device calls' arguments and
+  // GenerateSamples' bookkeeping used to be separate passes over all streams, with a pass in front to find the active ones;
+  // at 4,096 streams the passes were most of a request's host time).  Nothing here depends on a device result: a stream's
+  // bookkeeping is done as soon as its arguments are gathered.
+  for (bool first = true;; first = false) {
     for (auto& v : need_packet) v.clear();
+    for (auto& v : packets) v.clear();
     need_estimated.clear(); need_cng.clear(); need_noise.clear(); slices.clear();
-    // ---- host: the state machine up to the two model calls --------------------------------------------------------
-    for (int32_t s : active) {
+    for (int32_t s = 0; s < num_streams_; ++s) {
       Stream& st = streams_[s];
+      if (first) st.done = 0;
+      if (st.done >= n) continue;
+      // ---- the state machine up to the two model calls ----------------------------------------------------------------
       st.n_gen = GetNumSamplesToGenerate(n, st.done, st.concealment_progress, gan_available(st), cng_available(st));
       st.packet_received = gan_available(st) > 0 && st.concealment_progress == 0;
       if (st.packet_received) st.fade_direction = kFadeFromCNG;
@@ -316,10 +319,15 @@ bool BatchLyraDecoder::EnqueueInternal(int n) {
           LOG(ERROR) << "Model could not be run on features.";
           return false;
         }
-        if (st.next_in_hop == 0) {
+        if (st.next_in_hop == 0) {   // RunConditioning: this stream starts a hop
           const Entry& e = st.queue.front();
-          if (e.estimated) need_estimated.push_back(s);
-          else need_packet[e.bits == 64 ? 0 : (e.bits == 120 ? 1 : 2)].push_back(s);
+          if (e.estimated) {
+            need_estimated.push_back(s);
+          } else {
+            const int k = e.bits == 64 ? 0 : (e.bits == 120 ? 1 : 2);
+            need_packet[k].push_back(s);
+            packets[k].insert(packets[k].end(), e.packet, e.packet + (kBits[k] + 7) / 8);
+          }
         }
       }
       if (st.cng_n > 0 && cng_available(st) == 0) {   // RunComfortNoiseGenerator (:328-340)
@@ -341,17 +349,24 @@ bool BatchLyraDecoder::EnqueueInternal(int n) {
         need_noise.push_back(s);
       }
       slices.push_back(sl);
+      // ---- bookkeeping of GenerativeModel::GenerateSamples (generative_model_interface.h:88-101) ----------------------
+      if (st.gen_n > 0) {
+        st.next_in_hop += st.gen_n;
+        if (st.next_in_hop == kBatchHopSamples) { st.next_in_hop = 0; st.queue.pop_front(); }
+      }
+      if (st.cng_n > 0) {
+        st.cng_next += st.cng_n;
+        if (st.cng_next == kBatchHopSamples) { st.cng_next = 0; st.cng_has_hop = false; }
+      }
+      st.fade_progress = st.next_fade;
+      st.done += st.n_gen;
     }
+    if (slices.empty()) break;   // every stream has its n samples
     // ---- device: RunConditioning of every stream that starts a hop ----------------------------------------------------
     for (int k = 0; k < 3; ++k) {
       const std::vector<int32_t>& ids = need_packet[k];
       if (ids.empty()) continue;
-      const int nb = (kBits[k] + 7) / 8;
-      packets.resize(ids.size() * nb);
-      for (size_t i = 0; i < ids.size(); ++i)
-        std::copy(streams_[ids[i]].queue.front().packet.begin(), streams_[ids[i]].queue.front().packet.end(),
-                  packets.begin() + i * nb);
-      if (lyra_hip_twin_decode(ctx_, ids.data(), static_cast<int>(ids.size()), packets.data(), kBits[k]) != 0) {
+      if (lyra_hip_twin_decode(ctx_, ids.data(), static_cast<int>(ids.size()), packets[k].data(), kBits[k]) != 0) {
         LOG(ERROR) << "Model could not be run on features: " << lyra_hip_last_error(ctx_);
         return false;
       }
@@ -374,20 +389,6 @@ bool BatchLyraDecoder::EnqueueInternal(int n) {
     if (!need_noise.empty() && lyra_hip_twin_noise(ctx_, need_noise.data(), static_cast<int>(need_noise.size())) != 0) {
       LOG(ERROR) << "Could not update noise estimator on decoder output: " << lyra_hip_last_error(ctx_);
       return false;
-    }
-    // ---- host: bookkeeping of GenerativeModel::GenerateSamples (generative_model_interface.h:88-101) -------------------
-    for (int32_t s : active) {
-      Stream& st = streams_[s];
-      if (st.gen_n > 0) {
-        st.next_in_hop += st.gen_n;
-        if (st.next_in_hop == kBatchHopSamples) { st.next_in_hop = 0; st.queue.pop_front(); }
-      }
-      if (st.cng_n > 0) {
-        st.cng_next += st.cng_n;
-        if (st.cng_next == kBatchHopSamples) { st.cng_next = 0; st.cng_has_hop = false; }
-      }
-      st.fade_progress = st.next_fade;
-      st.done += st.n_gen;
     }
   }
   return true;

@@ -25,6 +25,7 @@
 #include <optional>
 #include <vector>
 
+#include "../../include/lyra_hip.h"
 #include "absl/types/span.h"
 #include "include/ghc/filesystem.hpp"
 
@@ -104,9 +105,25 @@ class BatchLyraDecoder {
  private:
   BatchLyraDecoder(lyra_hip_ctx* ctx, int sample_rate_hz, int num_streams);
   // GenerativeModel's FIFO bookkeeping (generative_model_interface.h:45-134) without the model.
-  struct Entry { bool estimated; int bits; std::vector<uint8_t> packet; };
+  // (plain data: a stream gets a packet per hop, and at 4,096 streams a heap block per packet and a deque per stream were
+  // most of DecodeSamples' host time -- round 5, profiles/r05_batch_twins_host_time.txt)
+  struct Entry { bool estimated; int bits; uint8_t packet[(4 * LYRA_HIP_MAX_STAGES + 7) / 8]; };
+  class HopQueue {   // FIFO of the few conditioning inputs a stream holds (usually 0-2): a vector and a head index
+   public:
+    size_t size() const { return v_.size() - head_; }
+    bool empty() const { return head_ == v_.size(); }
+    const Entry& front() const { return v_[head_]; }
+    void push_back(const Entry& e) { v_.push_back(e); }
+    void pop_front() {
+      if (++head_ == v_.size()) { v_.clear(); head_ = 0; }
+      else if (head_ >= 32 && 2 * head_ >= v_.size()) { v_.erase(v_.begin(), v_.begin() + head_); head_ = 0; }
+    }
+   private:
+    std::vector<Entry> v_;
+    size_t head_ = 0;
+  };
   struct Stream {
-    std::deque<Entry> queue;              // generative model: queued conditioning inputs
+    HopQueue queue;                       // generative model: queued conditioning inputs
     int next_in_hop = 0;                  // generative model: next_sample_in_hop_ (the hop itself lives on the device)
     bool cng_has_hop = false;             // comfort noise generator: one hop at most is ever queued
     int cng_next = 0;
@@ -126,6 +143,11 @@ class BatchLyraDecoder {
   int sample_rate_hz_;
   int num_streams_;
   std::vector<Stream> streams_;
+  std::vector<int32_t> all_ids_;                 // 0 .. num_streams - 1
+  // scratch of EnqueueInternal (kept across calls: no allocation per request)
+  std::vector<int32_t> need_packet_[3], need_estimated_, need_cng_, need_noise_;
+  std::vector<uint8_t> packets_[3];
+  std::vector<lyra_hip_twin_slice> slices_;
   std::vector<std::vector<int16_t>> leftover_;   // BufferedResampler::leftover_samples_ per stream (same length for all)
   std::vector<int16_t> external_;                // a request's resampled samples when leftovers have to be spliced in
 };
