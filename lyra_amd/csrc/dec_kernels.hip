@@ -52,6 +52,9 @@ __global__ __launch_bounds__(NTD0, LYRA_D0XN_WAVES) void dec_s0_xn_kernel(const 
                                                           const uint8_t* __restrict__ packets, int num_stages,
                                                           const float* __restrict__ cb, int code_bytes, int tile0) {
   if (((int)blockIdx.x + tile0) * SD0 >= B) return;
+#ifdef LYRA_I8_PRIO
+  __builtin_amdgcn_s_setprio(LYRA_I8_PRIO);
+#endif
   dec_s0_body<2>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
 

@@ -45,6 +45,9 @@ __global__ __launch_bounds__(NT2, LYRA_E2XN_WAVES) void enc_s2_xn_kernel(const E
                                                          uint8_t* __restrict__ state, float* __restrict__ feats,
                                                          float* __restrict__ codes_dbg, int code_bytes, int tile0) {
   if (((int)blockIdx.x + tile0) * S2 >= B) return;
+#ifdef LYRA_I8_PRIO   // experiment: the int8 stages are latency chains with little issue demand -- let them go first
+  __builtin_amdgcn_s_setprio(LYRA_I8_PRIO);
+#endif
   enc_s2_body<2>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
 

@@ -224,6 +224,9 @@ __global__ __launch_bounds__(64) void rvq_encode_kernel(const float* __restrict_
                                                         int32_t* __restrict__ packet_bytes, unsigned* __restrict__ stats) {
   __shared__ __attribute__((aligned(16))) float rs[16 * 68];   // residuals of the tile, [frame][64 (+4 pad)]: exact path / prologue
   __shared__ int win[16];                                       // exact path: winners by frame
+#ifdef LYRA_RVQ_PRIO   // experiment: the quantizer's lone wavefronts win the issue arbitration against the co-resident stage kernels
+  __builtin_amdgcn_s_setprio(LYRA_RVQ_PRIO);
+#endif
   const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
   const int x16 = (lane ^ 16) << 2;
   const int frame = blockIdx.x * 16 + n;
