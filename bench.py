@@ -166,6 +166,9 @@ def parse(argv=None):
     ap.add_argument("--verify-streams", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="bring the process group up (RCCL on a GPU box) even with ONE rank: the N > 1 code path -- "
+                         "init, barriers around the timed region, max / sum all-reduce, rank gather -- on a 1-GPU box")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="CPU-only: exercise the multi-rank plumbing (gloo) without touching a GPU")
     ap.add_argument("--stub-context", action="store_true",
@@ -206,9 +209,15 @@ def dist_env():
     return rank, world, local
 
 
+def pg_active():
+    """A process group is up: world > 1, or world == 1 under --force-dist (the RCCL path exercised with one rank)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def reduce_job(local_seconds, local_units, world, backend_device):
     """max-over-ranks time, sum-over-ranks units (the only collectives of the whole job)."""
-    if world == 1:
+    if world == 1 and not pg_active():
         return local_seconds, local_units
     import torch
     import torch.distributed as dist
@@ -796,7 +805,7 @@ def rank_summary(res, args, wl):
 
 
 def gather_ranks(summary, world):
-    if world == 1:
+    if world == 1 and not pg_active():
         return [summary]
     import torch.distributed as dist
     out = [None] * world
@@ -915,20 +924,27 @@ def main(argv=None):
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or args.force_dist
+    if use_pg:
         import torch.distributed as dist
+        if world == 1 and "MASTER_ADDR" not in os.environ:   # --force-dist typed without a launcher: a one-rank rendezvous
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local))
         if stub:
             dist.init_process_group("gloo", init_method="env://")
         else:
             dist.init_process_group("nccl", init_method="env://", device_id=dev)
     wl = resolve_workload(args, world)
     first_id, _ = shard_ids(wl["total"], rank, world)
-    image = broadcast_weights(rank, dev) if (args.bcast_weights and world > 1) else None
+    image = broadcast_weights(rank, dev) if (args.bcast_weights and use_pg) else None
     sh = StubShard(rank, first_id, wl, args, weights_image=image) if stub else Shard(local, first_id, wl, args,
                                                                                      weights_image=image)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             import torch.distributed as dist
             dist.barrier()
 
@@ -944,6 +960,8 @@ def main(argv=None):
                           "timing barrier and the result reduction only"
                           + (", self-spawned from `python bench.py --gpus N`" if os.environ.get("LYRA_BENCH_RESPAWNED") else ""))
         out["ranks"] = world
+        if use_pg and world == 1:
+            out["process_group"] = "forced at one rank (--force-dist): barrier, max / sum reduction and rank gather ran over " + backend
         if world > 1:   # a straggler must be visible: every rank's own clock, dominant kernel and self-check
             out["per_rank_ms_per_step"] = [r["ms_per_step"] for r in per_rank]
             out["per_rank"] = per_rank
@@ -956,8 +974,9 @@ def main(argv=None):
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -195,6 +195,23 @@ def test_bench_eight_ranks_config5_and_default_respawn():
     assert r["verified"] is True and all(p["verified"] for p in r["per_rank"])
 
 
+def test_bench_force_dist_one_rank_gloo():
+    """--force-dist: ONE rank, process group up anyway (gloo here, RCCL on the GPU box -- tests/test_gpu_bench_verify.py):
+    the N > 1 code path (rendezvous, weight broadcast, barriers, max / sum reduction, rank gather, teardown) on one rank,
+    typed without a launcher."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stub-context", "--force-dist", "--bcast-weights", "--steps", "5",
+           "--warmup", "2", "--no-cpu-baseline", "--latency-steps", "0", "--no-kernel-table", "--ramp-steps", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["ranks"] == 1 and "forced at one rank" in r["process_group"]
+    assert abs(r["value"] - 4096 * 5 / (5 * 1e-4)) < 1.0
+    assert r["stub"]["weights_bytes"] == os.path.getsize(os.path.join(ROOT, "lyra_amd", "assets", "lyra_v1.lyrapack"))
+
+
 def test_bench_roofline_bookkeeping():
     """Pure functions of bench.py: per-kernel bounds and the whole-step roofline of every leg."""
     sys.path.insert(0, ROOT)

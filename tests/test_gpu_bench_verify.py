@@ -3,6 +3,9 @@ serialised kernel table, 64 ramp steps, the timed lyra_hip_run_steps_dev region,
 cycled) is replayed by the CPU oracle and the GPU's final packets / PCM must be bit-equal -- for every BASELINE config the
 bench offers (lyra_benchmark_lib.cc:121-160 is the loop being replaced).  A negative control shows the check has teeth."""
 import json
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -40,3 +43,23 @@ def test_bench_verify_has_teeth():
     sh.args.requant = "exact"
     assert sh.verify(64)["verified"] is False
     sh.ctx.close()
+
+
+def test_bench_rccl_path_with_one_rank():
+    """The N > 1 code path of bench.py has only ever met gloo on CPU (no multi-GPU box was available to this build):
+    `--force-dist` brings the RCCL process group up with ONE rank, so init_process_group("nccl"), the weight broadcast,
+    the barriers around the timed region, the max / sum all-reduce on device tensors, all_gather_object and the teardown
+    run on a real GPU -- launched exactly as the driver launches N ranks (torch.distributed.run, 127.0.0.1)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--bcast-weights",
+           "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--latency-steps", "0", "--verify-streams", "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["ranks"] == 1 and "RCCL" in r["process_group"]
+    assert r["verified"] is True and r["value"] > 1e6 and r["roofline"]["frac"] > 0.1
