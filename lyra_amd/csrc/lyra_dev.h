@@ -285,9 +285,34 @@ __device__ __forceinline__ void wg_schedule_hint() {
 // INIT: 0 = the chains start from 0, 1 = acc carries values in (a chain continued from an earlier GEMM), 2 = the chains
 // start from init[j] (the bias splat of N tile j): the first MFMA of every chain takes it as its C operand directly,
 // so no accumulator is written (or even allocated) before the first products arrive.
+// The first PF weight chunks (and the bias splats) of a GEMM, requested by gemm_f32_wprefetch BEFORE the barrier / elementwise
+// phase that precedes the GEMM: an L2 round trip (500+ cycles, more under load) per GEMM otherwise stands between the barrier
+// and the first MFMA -- hidden by the other resident tiles at 4,096 streams, fully exposed with one tile per CU.
+template <int NTW, int PF>
+struct WPre { f32x4 b[PF][NTW]; f32x4 init[NTW]; };
+
+template <int NTW, int KC, int KS, int PF>
+__device__ __forceinline__ WPre<NTW, PF> gemm_f32_wprefetch(const f32x4* bfrag_generic, const float* bias, int n0) {
+  const int lane = threadIdx.x & 63;
+  const f32x4 LYRA_GLOBAL* bbase = wave_uniform(bfrag_generic);
+  WPre<NTW, PF> pre;
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) pre.b[p][j] = bbase[(j * KS + LYRA_WCHUNK(p < KC ? p : 0)) * 64 + lane];
+  const float LYRA_GLOBAL* b = as_global(bias) + n0 + (threadIdx.x & 15);
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const float v = b[j * 16];
+    pre.init[j] = (f32x4){v, v, v, v};
+  }
+  return pre;
+}
+
 template <int MTW, int NTW, int KC, int KS, int INIT, int PF, class AOff>
 __device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, const f32x4* bfrag_generic,
-                                              f32x4 (&acc)[MTW][NTW], const f32x4 (&init)[NTW]) {
+                                              f32x4 (&acc)[MTW][NTW], const f32x4 (&init)[NTW],
+                                              const f32x4 (*pre_b)[NTW] = nullptr) {
   const int lane = threadIdx.x & 63;
   const f32x4 LYRA_GLOBAL* bbase = wave_uniform(bfrag_generic);
   if (INIT == 2) {   // the splat lives in the LAST M tile's accumulator: the first MFMA of tile i reads it from there and
@@ -300,7 +325,7 @@ __device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, cons
   for (int p = 0; p < PF; ++p)
     if (p < KC) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[p][j] = bbase[(j * KS + LYRA_WCHUNK(p)) * 64 + lane];
+      for (int j = 0; j < NTW; ++j) bq[p][j] = pre_b ? pre_b[p][j] : bbase[(j * KS + LYRA_WCHUNK(p)) * 64 + lane];
 #pragma unroll
       for (int i = 0; i < MTW; ++i) aq[p][i] = *reinterpret_cast<const f32x4*>(lds + a_off(i, p));
     }
@@ -355,6 +380,16 @@ __device__ __forceinline__ void gemm_f32_bias(const float* lds, AOff a_off, cons
   }
   gemm_f32_core<MTW, NTW, KC, KS, 2, PF>(lds, a_off, bfrag_generic, acc, init);
 }
+
+// ... with the first weight chunks and the bias splats requested earlier (gemm_f32_wprefetch with the same NTW, KC, KS, PF)
+template <int MTW, int NTW, int KC, int KS = KC,
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+__device__ __forceinline__ void gemm_f32_pre(const float* lds, AOff a_off, const f32x4* bfrag_generic,
+                                             const WPre<NTW, PF>& pre, f32x4 (&acc)[MTW][NTW]) {
+  gemm_f32_core<MTW, NTW, KC, KS, 2, PF>(lds, a_off, bfrag_generic, acc, pre.init, pre.b);
+}
+template <int MTW, int NTW>
+constexpr int gemm_pf() { return 4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3); }
 
 // ... from splats the caller already holds
 template <int MTW, int NTW, int KC, int KS = KC,
