@@ -462,23 +462,34 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
 #ifdef LYRA_WGTRACE_D1   // per-workgroup trace of THIS kernel instead of dec_s0 (tools/archive/wg_trace_full.py)
   LYRA_WG_BEGIN();
 #endif
+  // the stage input does not depend on the stream ids: requested with them, ahead of the barrier (see enc_s1_body)
+  int my_id = 0;
+  if (tid < SD1) my_id = ids[min(b0 + tid, B - 1)];
+  constexpr int XIN = (4 * SD1 * 32) / NTD1;
+  f32x4 xin[XIN];
+#pragma unroll
+  for (int k = 0; k < XIN; ++k) {
+    const int idx = tid + k * NTD1;
+    int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
+    int sb = min(s, B - 1 - b0);
+    xin[k] = *goff<const f32x4>(in0 + (size_t)b0 * 512, (uint32_t)(((sb * 4 + t) * 128 + p4 * 4) * 4));
+  }
   if (tid < SD1) {
-    int id = ids[min(b0 + tid, B - 1)];
-    sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::D1_BYTES + st::PHASE);
+    sids[tid] = my_id;
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(my_id, 0) * st::D1_BYTES + st::PHASE);
   }
   const auto warm = l2_warm<NTD1, 2>(P.warm);
   const auto warm_code = code_warm<NTD1>(code_bytes);
+#pragma unroll
+  for (int k = 0; k < XIN; ++k) {
+    const int idx = tid + k * NTD1;
+    int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
+    *reinterpret_cast<f32x4*>(&XB[(t * SD1 + s) * CS1 + p4 * 4]) = xin[k];
+  }
   LYRA_SYNC_KEEP();
   TileCtx cx{state, sids, sphase, B - b0, st::D1_BYTES};
   const auto H0 = hist128_prefetch<SD1, NTD1>(cx, 1, st::D_R1_0);   // first block's history: same round trip as the input
-  for (int idx = tid; idx < 4 * SD1 * 32; idx += NTD1) {
-    int p4 = idx & 31, s = (idx >> 5) & (SD1 - 1), t = (idx >> 5) / SD1;
-    int sb = min(s, B - 1 - b0);
-    *reinterpret_cast<f32x4*>(&XB[(t * SD1 + s) * CS1 + p4 * 4]) =
-        *goff<const f32x4>(in0 + (size_t)b0 * 512, (uint32_t)(((sb * 4 + t) * 128 + p4 * 4) * 4));
-  }
-  for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {   // carried tail: fetched with the input, used at the end
+  for (int idx = tid; idx < 5 * SD1 * 16; idx += NTD1) {   // carried tail: used at the end
     int p4 = idx & 15, s = (idx >> 4) & (SD1 - 1), j = (idx >> 4) / SD1;
     *reinterpret_cast<f32x4*>(&SB[(j * SD1 + s) * 72 + p4 * 4]) =
         *cx.at<const f32x4>(cx.soff(s) + (uint32_t)(st::D_UP2 + (j * 64 + p4 * 4) * 4));
@@ -542,13 +553,11 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
 #ifdef LYRA_WGTRACE_D2
   LYRA_WG_BEGIN();
 #endif
-  if (tid < SD2) sids[tid] = ids[min(b0 + tid, B - 1)];
-  const auto warm = l2_warm<NTD2, 1>(P.warm);
-  const auto warm_code = code_warm<NTD2>(code_bytes);
-  LYRA_SYNC_KEEP();
-  TileCtx cx{state, sids, nullptr, B - b0, st::D2_BYTES};   // T = 20 >= every 2*dilation: no ring, no phase
+  int my_id = 0;
+  if (tid < SD2) my_id = ids[min(b0 + tid, B - 1)];
   const int wn = wave & 3, wm = wave >> 2;
   const int pcol = at16(wn * 16 + (lane & 15));
+  // the stage input does not depend on the stream ids: requested with them, ahead of the barrier (see enc_s1_body)
   f32x4 xr[5][1];  // residual stream in registers (MFMA C layout)
 #pragma unroll
   for (int i = 0; i < 5; ++i)
@@ -558,6 +567,11 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
       int sb = min(s, B - 1 - b0);
       xr[i][0][e] = *goff<const float>(in1 + (size_t)b0 * 1280, (uint32_t)(((sb * 20 + t) * 64 + pcol) * 4));
     }
+  if (tid < SD2) sids[tid] = my_id;
+  const auto warm = l2_warm<NTD2, 1>(P.warm);
+  const auto warm_code = code_warm<NTD2>(code_bytes);
+  LYRA_SYNC_KEEP();
+  TileCtx cx{state, sids, nullptr, B - b0, st::D2_BYTES};   // T = 20 >= every 2*dilation: no ring, no phase
   for (int idx = tid; idx < 7 * SD2 * 16; idx += NTD2) {
     int p4 = idx & 15, s = (idx >> 4) & (SD2 - 1), j = (idx >> 4) / SD2;
     int row = j < 3 ? j : 20 + j;

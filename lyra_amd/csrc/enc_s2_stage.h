@@ -57,12 +57,29 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   LYRA_TSTAMP(0);
   LYRA_WSTAMP(100);
   LYRA_WG_BEGIN();
+  // the stage input does not depend on the stream ids: requested with them, ahead of the barrier (see enc_s1_body)
+  int my_id = 0;
+  if (tid < S2) my_id = ids[min(b0 + tid, B - 1)];
+  constexpr int XIN = (2 * S2 * 64) / NT2;
+  f32x4 xin[XIN];
+#pragma unroll
+  for (int k = 0; k < XIN; ++k) {
+    const int idx = tid + k * NT2;
+    int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
+    int sb = min(s, B - 1 - b0);
+    xin[k] = *goff<const f32x4>(in1 + (size_t)b0 * 512, (uint32_t)(((sb * 2 + t) * 256 + p4 * 4) * 4));
+  }
   if (tid < S2) {
-    int id = ids[min(b0 + tid, B - 1)];
-    sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::E2_BYTES + st::PHASE);
+    sids[tid] = my_id;
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(my_id, 0) * st::E2_BYTES + st::PHASE);
   }
   load_luts<NT2>(LQ, P.lr_lut, NLR, LA, P.add_lut, NADD);
+#pragma unroll
+  for (int k = 0; k < XIN; ++k) {
+    const int idx = tid + k * NT2;
+    int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
+    *reinterpret_cast<f32x4*>(&XF[(t * S2 + s) * CS2 + p4 * 4]) = xin[k];
+  }
   const auto warm = l2_warm<NT2, 1>(P.warm);
   const auto warm_code = code_warm<NT2>(code_bytes);
   LYRA_SYNC_KEEP();
@@ -73,13 +90,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   const uint32_t touch0 = state_touch<S2, NT2>(cx, st::E_R2_0, 2 * 256 * 4);
   const uint32_t touch1 = state_touch<S2, NT2>(cx, st::E_D2, 2 * 256 + 2 * 512);
 
-  for (int idx = tid; idx < 2 * S2 * 64; idx += NT2) {
-    int p4 = idx & 63, s = (idx >> 6) & (S2 - 1), t = (idx >> 6) / S2;
-    int sb = min(s, B - 1 - b0);
-    *reinterpret_cast<f32x4*>(&XF[(t * S2 + s) * CS2 + p4 * 4]) =
-        *goff<const f32x4>(in1 + (size_t)b0 * 512, (uint32_t)(((sb * 2 + t) * 256 + p4 * 4) * 4));
-  }
-  __syncthreads();
+  __syncthreads();   // (the touches above are in flight; XF was written before the ids barrier)
 
   LYRA_TSTAMP(1);
   // ---- resblock 0, fp32 half: depthwise (dil 1, history 2 rows, replaced) + pointwise 256->256 ----

@@ -191,13 +191,31 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   wg_schedule_hint();
   LYRA_TSTAMP(70);
   LYRA_WSTAMP(102);
+  // The stage input does not depend on the stream ids (only on the tile): requested in the same round trip as the ids, in
+  // front of the barrier the ids sit behind -- one dependent memory trip less at the head of the kernel's chain.
+  int my_id = 0;
+  if (tid < S1) my_id = ids[min(b0 + tid, B - 1)];
+  constexpr int XIN = (4 * S1 * 32) / NT1;
+  f32x4 xin[XIN];
+#pragma unroll
+  for (int k = 0; k < XIN; ++k) {
+    const int idx = tid + k * NT1;
+    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
+    int sb = min(s, B - 1 - b0);
+    xin[k] = *goff<const f32x4>(in0 + (size_t)b0 * 512, (uint32_t)(((sb * 4 + t) * 128 + p4 * 4) * 4));
+  }
   if (tid < S1) {
-    int id = ids[min(b0 + tid, B - 1)];
-    sids[tid] = id;
-    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(id, 0) * st::E1_BYTES + st::PHASE);
+    sids[tid] = my_id;
+    sphase[tid] = *reinterpret_cast<const int*>(state + (size_t)max(my_id, 0) * st::E1_BYTES + st::PHASE);
   }
   const auto warm = l2_warm<NT1, 2>(P.warm);
   const auto warm_code = code_warm<NT1>(code_bytes);
+#pragma unroll
+  for (int k = 0; k < XIN; ++k) {
+    const int idx = tid + k * NT1;
+    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
+    *reinterpret_cast<f32x4*>(&XB[((2 + t) * S1 + s) * CS1 + p4 * 4]) = xin[k];
+  }
   LYRA_SYNC_KEEP();
   auto soff = [&](int s) -> uint32_t { return (uint32_t)max(sids[s], 0) * (uint32_t)st::E1_BYTES; };
   auto gat = [&](uint32_t o) -> uint8_t LYRA_GLOBAL* { return (uint8_t LYRA_GLOBAL*)state + o; };
@@ -205,13 +223,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
 
   TileCtx cx{state, sids, sphase, B - b0, st::E1_BYTES};
   const auto H0 = hist128_prefetch<S1, NT1>(cx, 1, st::E_R1_0);   // first block's history: same round trip as the input
-  for (int idx = tid; idx < 4 * S1 * 32; idx += NT1) {
-    int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), t = (idx >> 5) / S1;
-    int sb = min(s, B - 1 - b0);
-    *reinterpret_cast<f32x4*>(&XB[((2 + t) * S1 + s) * CS1 + p4 * 4]) =
-        *goff<const f32x4>(in0 + (size_t)b0 * 512, (uint32_t)(((sb * 4 + t) * 128 + p4 * 4) * 4));
-  }
-  for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {   // strided conv's 2 history rows: fetched with the input
+  for (int idx = tid; idx < 2 * S1 * 32; idx += NT1) {   // strided conv's 2 history rows
     int p4 = idx & 31, s = (idx >> 5) & (S1 - 1), j = (idx >> 5) / S1;
     *reinterpret_cast<f32x4*>(&XB[(j * S1 + s) * CS1 + p4 * 4]) =
         *(const f32x4 LYRA_GLOBAL*)gat(soff(s) + (uint32_t)(st::E_D1 + (j * 128 + p4 * 4) * 4));
