@@ -329,7 +329,12 @@ def step_roofline(mode, legs, frames_per_s_per_gpu, traffic_table):
     t_hbm = moved / (PEAK_HBM_GBS * 1e9)
     traffic = None
     if traffic_table:
-        vals = [traffic_table.get(k, {}).get("hbm_bytes_per_frame") for k in names]
+        def per_frame(k):   # the int8 stages' kernels carry the arithmetic mode in their symbol (enc_s2_xn_kernel, dec_s0_dr_kernel)
+            for sym in (k, k.replace("_kernel", "_xn_kernel"), k.replace("_kernel", "_dr_kernel")):
+                if sym in traffic_table and isinstance(traffic_table[sym], dict):
+                    return traffic_table[sym].get("hbm_bytes_per_frame")
+            return None
+        vals = [per_frame(k) for k in names]
         if all(v is not None for v in vals):
             traffic = round(sum(vals), 1)
     common = {"kernel": "whole step: " + " + ".join(n.replace("_kernel", "") for n in names),
@@ -356,12 +361,12 @@ def step_roofline(mode, legs, frames_per_s_per_gpu, traffic_table):
 
 
 def load_issue_time(names):
-    """Offline SQ counters (profiles/r04_pmc_sq.txt, B = 4096): per SIMD, the time the matrix pipe is busy and the time the
+    """Offline SQ counters (profiles/r05_pmc_sq.txt, B = 4096): per SIMD, the time the matrix pipe is busy and the time the
     vector instructions take to issue, summed over the step's kernels.  On this part vector instructions do not hide under
     the MFMAs (tools/archive/mfma_valu_overlap_probe.hip), so the two add up; informational, not the roofline."""
     try:
         cur, tab = None, {}
-        for line in open(os.path.join(ROOT, "profiles", "r04_pmc_sq.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r05_pmc_sq.txt")):
             if line.strip() and not line.startswith(" "):
                 cur = line.strip()
                 tab[cur] = {}
@@ -375,12 +380,12 @@ def load_issue_time(names):
         simds, clk = 1024.0, 2.06e9     # 256 CUs x 4; the clock the chip sustains under this load
         matrix = vector = 0.0
         for k in names:
-            c = tab[k]
+            c = tab.get(k) or tab.get(k.replace("_kernel", "_xn_kernel")) or tab[k.replace("_kernel", "_dr_kernel")]
             matrix += c["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / clk
             per = 2.6 if k == "rvq_encode_kernel" else 4.3   # cycles per wave instruction: fp32 chains | integer / mixed
             vector += (c["SQ_INSTS_VALU"] - c.get("SQ_INSTS_MFMA", 0.0)) * per / simds / clk
         return {"matrix_pipe_us_per_step_at_B4096": round(matrix * 1e6, 1), "vector_issue_us_per_step_at_B4096": round(vector * 1e6, 1),
-                "source": "offline: SQ counters of profiles/r04_pmc_sq.txt at 2.06 GHz; vector instructions do not hide under "
+                "source": "offline: SQ counters of profiles/r05_pmc_sq.txt at 2.06 GHz; vector instructions do not hide under "
                           "MFMAs on gfx950 (profiles/r03_mfma_valu_overlap_probe.txt), so a SIMD's time is the sum"}
     except Exception:
         return None
@@ -652,9 +657,12 @@ class StubShard:
 
 
 def dominant_sample_every(K):
-    """Every how-many-th launch of the dominant kernel is bracketed inside the timed region: ~32 samples of a long run,
-    every second launch of a 20-step driver run (10 samples; bracketing all 20 would cost the headline ~3 %)."""
-    return max(2, K // 32) if K >= 4 else 1
+    """Every how-many-th launch of the two chain-leading kernels is bracketed inside the timed region: ~32 samples each of a
+    long run, every fourth launch of a 20-step driver run (5 samples each: an event record is a stream packet of its own,
+    and 2 x 10 pairs cost the 6 ms region ~1 % -- tools/k20_repeat.py without brackets 13.85 M, bench.py with them 13.69 M)."""
+    if K >= 64:
+        return K // 32
+    return max(2, K // 5) if K >= 4 else 1
 
 
 def latency_stats(samples):
