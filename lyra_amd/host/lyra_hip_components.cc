@@ -58,7 +58,7 @@ template <class Req>
 class Combiner {
  public:
   enum { kPending = 0, kDone = 1, kLead = 2 };
-  // tunables (environment, read once; tools/plugin_mt_sweep.sh: 10-150 us of quiet time and fan-outs 2-16 are within
+  // tunables (environment, read once; tools/archive/plugin_mt_sweep.sh: 10-150 us of quiet time and fan-outs 2-16 are within
   // run-to-run spread of each other at 256 and 1,024 threads)
   static long EnvLong(const char* name, long dflt) { const char* v = std::getenv(name); return v ? std::atol(v) : dflt; }
   const int kFan = (int)std::max(1L, EnvLong("LYRA_HIP_COMBINER_FAN", 4));
