@@ -225,6 +225,12 @@ def test_bench_roofline_bookkeeping():
     assert len(full[0]) == len(base[0]) + 4 and full[3] > base[3] and full[1] == base[1]
     r = bench.step_roofline("encdec", dict(rate=16000), 13.0e6, None)
     assert r["bound"] == "mfma" and abs(r["frac"] - 2 * base[1] * 13.0e6 / 157.3e12) < 1e-3
+    # the committed counter tables (profiles/traffic.json, r05_pmc_sq.txt) carry the int8 stages under their mode-suffixed
+    # symbols (enc_s2_xn_kernel): the whole-step traffic and issue-time figures must resolve them (they were null once)
+    r = bench.step_roofline("encdec", dict(rate=16000), 14.0e6, bench.load_traffic())
+    assert r["traffic"] is not None and 1.0 < r["traffic"] / r["moved_bytes_per_frame"] < 1.5
+    assert r["issue_time"]["matrix_pipe_us_per_step_at_B4096"] > 100
+    assert [bench.dominant_sample_every(k) for k in (20, 1000)] == [4, 31]
     st = bench.latency_stats([1e-4] * 99 + [5e-4])
     assert st["p50"] == 100.0 and st["p99"] == 100.0 and st["max"] == 500.0 and st["n"] == 100
 
