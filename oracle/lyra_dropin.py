@@ -24,6 +24,16 @@ def load(oracle, lib_path=None):
     """-> the library; `oracle` backs the audio_dsp shadows (log-mel of the NoiseEstimator, resampler, comfort noise)."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process (see lyra_amd/codec.py _load): the drop-in pulls in liblyra_hip.so and with it the
+        # system libamdhip64; a torch imported afterwards would be handed that copy instead of its own and find no GPU.
+        import importlib.util
+        import sys
+        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None and \
+                os.environ.get("LYRA_HIP_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         C.CDLL(os.path.join(HERE, "liblyra_oracle.so"), mode=C.RTLD_GLOBAL)
         L = C.CDLL(lib_path or LIB)
         vp, ci = C.c_void_p, C.c_int

@@ -63,7 +63,7 @@ def test_dropin_exports_and_runs_on_the_fake_abi(tmp_path):
         assert D.lyra_benchmark(o, 0, md) == -1                        # lyra_benchmark_lib.cc:204-207
         print("ok")
     """) % (ROOT, str(tmp_path / "model"))
-    env = dict(os.environ, LD_LIBRARY_PATH=str(fake) + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FAKE_CALL_US="0")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(fake) + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FAKE_CALL_US="0", LYRA_HIP_NO_TORCH_PRELOAD="1")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
     assert "feature_extractor:" in r.stderr and "total:" in r.stderr    # the reference's own table (BENCHMARK build)
