@@ -586,9 +586,11 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   LYRA_TSTAMP(62);
 #pragma unroll
   for (int i = 0; i < 5; ++i)
+{
+    const f32x4 a4 = lrelu4(xr[i][0]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
+    for (int e = 0; e < 4; ++e) XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = a4[e];
+  }
   __syncthreads();
   // tconv k64/s16, polyphase: blocks b = 0..22 (+1 of padding), rows (b, s); K = 4 x 64 (newest input first: chunk
   // group g reads input block b - g = LDS row b + 3 - g); N = 16 phases; every chain starts from the bias.

@@ -130,9 +130,11 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   // ---- D. a = lrelu(X) -> rows 5..24 (rows 0-4 already hold the strided conv's history) ----------------
 #pragma unroll
   for (int i = 0; i < 5; ++i)
+{
+    const f32x4 a4 = lrelu4(xr[i][0]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      XB[(5 * S0 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = lrelu(xr[i][0][e]);
+    for (int e = 0; e < 4; ++e) XB[(5 * S0 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = a4[e];
+  }
   __syncthreads();
   for (int idx = tid; idx < 5 * S0 * 16; idx += NT0) {
     int p4 = idx & 15, s = (idx >> 4) & (S0 - 1), j = (idx >> 4) / S0;

@@ -115,8 +115,11 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     // 1. a = lrelu(X) -> A
 #pragma unroll
     for (int i = 0; i < 5; ++i)
+{
+      const f32x4 a4 = lrelu4(xr[i][0]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = lrelu(xr[i][0][e]);
+      for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = a4[e];
+    }
     __syncthreads();
     LYRA_TSTAMP(10 + r * 8 + 1);
     // 2. depthwise k3 (dilation d), one tap at a time over the thread's 5 items: the chain value replaces the
@@ -172,8 +175,11 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 5; ++i)
+{
+        const f32x4 a4 = lrelu4(acc[i][0]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][0][e]);
+        for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = a4[e];
+      }
       __syncthreads();
       LYRA_TSTAMP(10 + r * 8 + 6);
     }
@@ -303,8 +309,11 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
         const int pcol = at16(ncol);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
+{
+          const f32x4 a4 = lrelu4(acc[i][j]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) P[(i * 16 + q * 4 + e) * CS + pcol] = lrelu(acc[i][j][e]);
+          for (int e = 0; e < 4; ++e) P[(i * 16 + q * 4 + e) * CS + pcol] = a4[e];
+        }
       }
       __syncthreads();
       LYRA_TSTAMP(40 + r * 8 + 4);

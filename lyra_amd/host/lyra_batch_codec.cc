@@ -184,6 +184,10 @@ bool BatchLyraDecoder::SetEncodedPackets(absl::Span<const uint8_t> encoded) {
 }
 
 bool BatchLyraDecoder::SetEncodedPackets(absl::Span<const int32_t> streams, absl::Span<const uint8_t> encoded) {
+  if (failed_) {
+    LOG(ERROR) << "This decoder failed in the middle of a request; its streams are out of step with the device. Create a new one.";
+    return false;
+  }
   if (streams.empty()) return encoded.empty();
   const int packet_size = static_cast<int>(encoded.size() / streams.size());
   const int bits = PacketSizeToBits(packet_size);
@@ -227,6 +231,10 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
     LOG(ERROR) << "Number of samples has to be non-negative.";
     return false;
   }
+  if (failed_) {
+    LOG(ERROR) << "This decoder failed in the middle of a request; its streams are out of step with the device. Create a new one.";
+    return false;
+  }
   if (out.size() != static_cast<size_t>(num_streams_) * num_samples) {
     LOG(ERROR) << "Output span has " << out.size() << " samples, expected " << static_cast<size_t>(num_streams_) * num_samples;
     return false;
@@ -246,6 +254,11 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
   }
   if (!EnqueueInternal(internal)) {
     (void)lyra_hip_twin_fetch(ctx_, num_streams_, 0, sample_rate_hz_, nullptr);   // abandon the half-assembled request
+    // EnqueueInternal does a stream's bookkeeping (packet consumed, fade / concealment progress) in the pass that gathers
+    // the device calls' arguments: after a failed round the host state of the streams handled so far has advanced while
+    // the device never ran that round.  The reference's LyraDecoder has no such window (one stream, one call); here the
+    // decoder refuses every further call instead of decoding from a state that no longer matches the device.
+    failed_ = true;
     return false;
   }
   const int produced = resampling ? static_cast<int>(static_cast<long>(internal) * sample_rate_hz_ / kBatchInternalSampleRateHz)
@@ -259,6 +272,7 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
   }
   if (lyra_hip_twin_fetch(ctx_, num_streams_, internal, sample_rate_hz_, dst) != 0) {
     LOG(ERROR) << "Could not decode samples: " << lyra_hip_last_error(ctx_);
+    failed_ = true;   // the request's samples are lost and the streams have moved on
     return false;
   }
   if (direct) return true;

@@ -142,6 +142,7 @@ class BatchLyraDecoder {
   lyra_hip_ctx* ctx_;
   int sample_rate_hz_;
   int num_streams_;
+  bool failed_ = false;                          // a device call failed mid-request: every further call is refused
   std::vector<Stream> streams_;
   std::vector<int32_t> all_ids_;                 // 0 .. num_streams - 1
   // scratch of EnqueueInternal (kept across calls: no allocation per request)
