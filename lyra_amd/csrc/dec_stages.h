@@ -466,6 +466,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   int my_id = 0;
   if (tid < SD1) my_id = ids[min(b0 + tid, B - 1)];
   constexpr int XIN = (4 * SD1 * 32) / NTD1;
+  static_assert((4 * SD1 * 32) % NTD1 == 0 && (4 * SD1 * 32) / NTD1 >= 1, "the unrolled input prefetch covers the stage input only when the thread count divides it");
   f32x4 xin[XIN];
 #pragma unroll
   for (int k = 0; k < XIN; ++k) {

@@ -61,6 +61,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   int my_id = 0;
   if (tid < S2) my_id = ids[min(b0 + tid, B - 1)];
   constexpr int XIN = (2 * S2 * 64) / NT2;
+  static_assert((2 * S2 * 64) % NT2 == 0 && (2 * S2 * 64) / NT2 >= 1, "the unrolled input prefetch covers the stage input only when the thread count divides it");
   f32x4 xin[XIN];
 #pragma unroll
   for (int k = 0; k < XIN; ++k) {

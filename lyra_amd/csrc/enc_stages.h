@@ -198,6 +198,7 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
   int my_id = 0;
   if (tid < S1) my_id = ids[min(b0 + tid, B - 1)];
   constexpr int XIN = (4 * S1 * 32) / NT1;
+  static_assert((4 * S1 * 32) % NT1 == 0 && (4 * S1 * 32) / NT1 >= 1, "the unrolled input prefetch covers the stage input only when the thread count divides it");
   f32x4 xin[XIN];
 #pragma unroll
   for (int k = 0; k < XIN; ++k) {
