@@ -50,7 +50,10 @@ One JSON line on rank 0:
   * `step_latency_us` = distribution of ONE isolated step (enqueue -> all outputs complete, nothing else in flight):
     min / mean / p50 / p99 / max / stddev over --latency-steps steps (lyra_benchmark_lib.cc:164-182 prints the same
     statistics per stage; a 20 ms-deadline codec cares about the tail, not the mean);
-  * `cpu_baseline` = the CPU oracle (a port, not the TFLite binary) on this box's host cores, bounded sample.
+  * `cpu_baseline` = the CPU oracle (a port, not the TFLite binary) on this box's host cores, bounded sample;
+    `cpu_baseline_xnnpack` = the same graphs with every arithmetic operator run by XNNPACK operator objects (the engine the
+    reference's TfLiteModelWrapper uses, as far as this image holds it: torch's XNNPACK), same cores, same sample shape.
+    Both run on rank 0 after the process group is gone.
 """
 import argparse
 import json
@@ -165,6 +168,8 @@ def parse(argv=None):
                          "vouches for the whole run).  Outside every timed region.")
     ap.add_argument("--verify-streams", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-confine", action="store_true",
+                    help="at --gpus N > 1 do not confine each rank to its share of the CPU quota (confine_rank_to_cpu_share)")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="bring the process group up (RCCL on a GPU box) even with ONE rank: the N > 1 code path -- "
@@ -246,11 +251,15 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(bits, mode, requant="xnnpack"):
-    """Oracle (CPU port of the same arithmetic) on the host cores, bounded to ~12 s."""
+def cpu_baseline(bits, mode, requant="xnnpack", engine="scalar"):
+    """The CPU leg on the host cores, bounded to ~12 s.  engine "scalar": oracle/lyra_oracle.c, the CPU port of the same
+    arithmetic (`cpu_baseline`, kind "port").  engine "xnnpack": the same graph plumbing with every arithmetic operator an
+    XNNPACK operator object, one stream per thread -- what TfLiteModelWrapper with use_xnn = true runs per Invoke()
+    (tflite_model_wrapper.cc:63-85, lyra_benchmark_lib.cc:85-160), on the XNNPACK torch's libtorch_cpu.so carries in this
+    image (`cpu_baseline_xnnpack`; bit-equal to the port on features / packets, tests/test_xnnpack_engine.py)."""
     from oracle import lyra_oracle
     lyra_oracle.build()
-    o = lyra_oracle.Oracle(mode=requant)
+    o = lyra_oracle.Oracle(mode=requant, engine=engine)
     cores = usable_cores()
     rng = np.random.Generator(np.random.PCG64(SEED))
     streams = cores * 2
@@ -263,15 +272,36 @@ def cpu_baseline(bits, mode, requant="xnnpack"):
     steps = int(max(16, min(4000, 12.0 * rate / streams)))
     rate, r = run(steps)
     split = r["stage_seconds"] / (streams * steps) * 1e3
-    out = {"value": round(rate, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": f"{streams} streams x {steps} frames, uniform full-scale int16 PCM, {bits} bits, encode+decode, "
-                     f"oracle/lyra_oracle.c one stream per thread",
+    what = ("oracle/lyra_oracle.c one stream per thread" if engine == "scalar" else
+            "oracle/lyra_oracle.c -DLO_XNNPACK: XNNPACK operators (create once, setup + run per frame), one stream per thread")
+    out = {"value": round(rate, 1), "unit": "frames/s", "cores": cores,
+           "kind": "port" if engine == "scalar" else "xnnpack-ops (torch's build, not TF 2.11's)",
+           "sample": f"{streams} streams x {steps} frames, uniform full-scale int16 PCM, {bits} bits, encode+decode, {what}",
            "ms_per_frame_per_core": {"extract": round(float(split[0]), 4), "quantize": round(float(split[1]), 4),
                                      "dequantize": round(float(split[2]), 4), "generate": round(float(split[3]), 4)}}
     if mode == "decode":   # the decode-only share of the same run (dequantize + generate stages)
         dec_ms = float(split[2] + split[3])
         out["decode_only_value"] = round(cores / (dec_ms * 1e-3), 1) if dec_ms > 0 else None
     return out
+
+
+def confine_rank_to_cpu_share(local, world):
+    """Under --gpus N every rank confines itself to its share of the CPUs the container's quota is worth (cgroup cpu.max;
+    lyra_amd/host/plugin_mt_demo.cc LimitAffinityToCpuQuota has the reasoning: CFS hands a quota out in per-CPU slices, and
+    threads spread over many more CPUs than the quota is worth get throttled long before the quota is used).  At least two
+    CPUs per rank (the enqueueing thread + the runtime's helpers).  Returns (original mask, this rank's CPUs) or None."""
+    if not hasattr(os, "sched_getaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    per = max(2, usable_cores() // max(1, world))
+    if per * world > len(allowed):
+        return None
+    mine = allowed[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return allowed, mine
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -933,6 +963,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     use_pg = world > 1 or args.force_dist
+    confined = confine_rank_to_cpu_share(local, world) if (world > 1 and not args.no_cpu_confine) else None
     if use_pg:
         import torch.distributed as dist
         if world == 1 and "MASTER_ADDR" not in os.environ:   # --force-dist typed without a launcher: a one-rank rendezvous
@@ -961,12 +992,17 @@ def main(argv=None):
     if wl["mode"] == "decode":
         res["secondary_seconds"], _ = reduce_job(res["secondary_seconds"], 0, world, dev)
     per_rank = gather_ranks(rank_summary(res, args, wl), world)
+    out = None
     if rank == 0:
         backend = "gloo (stub)" if stub else "RCCL"
-        out = result_line(args, wl, world, secs, frames, res,
-                          f"one process per GPU, torch.distributed/{backend}: {world} rank(s), process group used for the "
-                          "timing barrier and the result reduction only"
-                          + (", self-spawned from `python bench.py --gpus N`" if os.environ.get("LYRA_BENCH_RESPAWNED") else ""))
+        if use_pg:
+            how = (f"one process per GPU, torch.distributed/{backend}: {world} rank(s), process group used for the "
+                   "timing barrier and the result reduction only")
+        else:
+            how = "one process, one GPU: no process group at one rank (the barrier is a no-op, nothing is reduced)"
+        if os.environ.get("LYRA_BENCH_RESPAWNED"):
+            how += ", self-spawned from `python bench.py --gpus N`"
+        out = result_line(args, wl, world, secs, frames, res, how)
         out["ranks"] = world
         if use_pg and world == 1:
             out["process_group"] = "forced at one rank (--force-dist): barrier, max / sum reduction and rank gather ran over " + backend
@@ -974,18 +1010,36 @@ def main(argv=None):
             out["per_rank_ms_per_step"] = [r["ms_per_step"] for r in per_rank]
             out["per_rank"] = per_rank
             out["verified"] = None if any(r.get("verified") is None for r in per_rank) else all(r["verified"] for r in per_rank)
+            out["cpus_per_rank"] = len(confined[1]) if confined else None
         if stub:
             out["stub"] = {"calls": sh.calls, "first_id": first_id, "weights_bytes": sh.weights_bytes}
-        if not args.no_cpu_baseline and not stub:   # rank 0's host cores, at any world size
-            try:
-                out["cpu_baseline"] = cpu_baseline(wl["bits"], wl["mode"], args.requant)
-            except Exception as e:  # the baseline leg must never take the GPU number down with it
-                out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+    # The process group goes away BEFORE the CPU legs: the other ranks have left by then (no rank spinning in a barrier
+    # on the host cores the baseline is timed on), and nothing the baseline's threads do can reach another rank's clock.
     if use_pg:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_cpu_baseline and not stub:   # rank 0's host cores, at any world size
+            if confined:   # back to the CPUs a one-rank run has
+                try:
+                    os.sched_setaffinity(0, confined[0])
+                except OSError:
+                    pass
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl["bits"], wl["mode"], args.requant)
+            except Exception as e:  # the baseline leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+            if args.requant == "xnnpack":
+                try:
+                    from oracle import lyra_oracle
+                    if lyra_oracle.xnn_engine_available():
+                        out["cpu_baseline_xnnpack"] = cpu_baseline(wl["bits"], wl["mode"], args.requant, engine="xnnpack")
+                    else:
+                        out["cpu_baseline_xnnpack"] = {"error": "oracle/_xnn/liblyra_oracle_xnn.so not built"}
+                except Exception as e:
+                    out["cpu_baseline_xnnpack"] = {"error": repr(e)}
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

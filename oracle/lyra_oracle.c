@@ -79,6 +79,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef LO_XNNPACK
+/* Second build of this file (oracle/Makefile target _xnn/liblyra_oracle_xnn.so): the SAME graph plumbing, every
+ * arithmetic operator executed by XNNPACK operator objects -- see "XNNPACK backend" below. */
+#include <xnnpack.h>
+#endif
 
 #define LRELU_ALPHA 0.30000001192092896f
 #define NUM_FEATURES 64
@@ -213,6 +218,7 @@ typedef struct {
   int cout, k, cig, groups, stride, cog;
   float* wt;      /* [g][k*cig][cog] */
   const float* b; /* [cout] */
+  const float* w0; /* [cout][k][cig], as packed (the flatbuffer's OHWI filter) */
 } conv_f;
 
 typedef struct {
@@ -223,6 +229,8 @@ typedef struct {
   float sin, sout;
   qmul* q; /* [cout] */
   float* fs; /* [cout] mode 2 */
+  const int8_t* w0; /* [cout][k][cig], as packed */
+  const float* ws;  /* [cout] filter scales */
 } conv_q;
 
 typedef struct { int c, k, dil; const float* w; const float* b; } dw_f;
@@ -234,6 +242,7 @@ typedef struct {
   float sin, sout;
   qmul* q;
   float* fs;
+  const float* ws;  /* [c] filter scales */
 } dw_q;
 
 typedef struct {
@@ -250,6 +259,7 @@ typedef struct {
   float sin, sout;
   qmul q;
   float fs;
+  float ws0;        /* per-tensor filter scale */
 } tconv_q;
 
 typedef struct { int32_t zin, zout; float sin, sout; qmul pos, neg; int32_t xmp, xmn; } lrelu_q;
@@ -264,6 +274,7 @@ static void load_conv_f(const pk_file* pk, const char* pre, int idx, conv_f* L) 
   L->cout = (int)e->shape[0]; L->k = (int)e->shape[1]; L->cig = (int)e->shape[2];
   L->stride = opt[0]; L->groups = opt[2]; L->cog = L->cout / L->groups;
   const float* w = (const float*)(pk->blob + e->offset);
+  L->w0 = w;
   L->b = PKF(pre, "conv", idx, "b");
   int K = L->k * L->cig;
   L->wt = (float*)malloc(sizeof(float) * (size_t)L->cout * K);
@@ -285,6 +296,7 @@ static void load_conv_q(const pk_file* pk, const char* pre, int idx, conv_q* L) 
   L->b = PKI(pre, "conv", idx, "b");
   const float* q = PKF(pre, "conv", idx, "q");
   const float* ws = PKF(pre, "conv", idx, "wscale");
+  L->w0 = w; L->ws = ws;
   L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
   int K = L->k * L->cig;
   L->wt = (int16_t*)malloc(sizeof(int16_t) * (size_t)L->cout * K);
@@ -323,6 +335,7 @@ static void load_dw_q(const pk_file* pk, const char* pre, int idx, dw_q* L) {
   L->b = PKI(pre, "dw", idx, "b");
   const float* q = PKF(pre, "dw", idx, "q");
   const float* ws = PKF(pre, "dw", idx, "wscale");
+  L->ws = ws;
   L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
   L->q = (qmul*)malloc(sizeof(qmul) * L->c);
   L->fs = (float*)malloc(sizeof(float) * L->c);
@@ -365,6 +378,7 @@ static void load_tconv_q(const pk_file* pk, const char* pre, int idx, tconv_q* L
   L->b = PKI(pre, "tconv", idx, "b");
   const float* q = PKF(pre, "tconv", idx, "q");
   const float* ws = PKF(pre, "tconv", idx, "wscale");
+  L->ws0 = ws[0];
   L->sin = q[0]; L->zin = (int32_t)q[1]; L->sout = q[2]; L->zout = (int32_t)q[3];
   L->q = quantize_multiplier((double)L->sin * (double)ws[0] / (double)L->sout);
   { const float sw = L->sin * ws[0]; L->fs = sw / L->sout; }
@@ -399,8 +413,157 @@ static void load_add_q(const pk_file* pk, const char* pre, int idx, add_q* L) {
     L->xbias = (int32_t)(1 << (shift - 1)) - L->xma * L->z1 - L->xmb * L->z2; }
 }
 
+/* ------------------------------------------------------------------------ */
+/* XNNPACK backend (-DLO_XNNPACK; target _xnn/liblyra_oracle_xnn.so)          */
+/* ------------------------------------------------------------------------ */
+/* What the reference's TfLiteModelWrapper does with use_xnn = true (tflite_model_wrapper.cc:63-85) is hand each graph to
+ * TFLite's XNNPACK delegate: one XNNPACK operator per arithmetic TFLite operator, created once, set up and run per
+ * Invoke() on one thread (num_threads = 1), with TFLite's own code left for the tensor plumbing (CONCATENATION, slices,
+ * resource variables).  This build does the same with the XNNPACK that torch's libtorch_cpu.so exports in this image:
+ * every CONV_2D / DEPTHWISE_CONV_2D / TRANSPOSE_CONV / LEAKY_RELU / ADD / QUANTIZE / DEQUANTIZE of both graphs is an
+ * xnn_operator_t -- created on first use, reshaped once (the shapes are static), then setup + xnn_run_operator per frame --
+ * and the plumbing stays the C of this file.  Operators hold their packed weights and their input / output pointers, so
+ * every thread has its own set (one stream per thread, as in lo_run_batch).  It is the bench's `cpu_baseline_xnnpack`:
+ * a stand-in for the reference CPU path on the engine the reference uses, NOT the binary of record (newer XNNPACK than
+ * TF 2.11 pins, x86 micro-kernels).  Parity: tests/test_xnnpack_engine.py -- features / packets bit-equal to the scalar
+ * restatement and to the fixtures; PCM bit-equal with the canonical last layer (LOX_CANONICAL_LAST=1), within 1 LSB with
+ * the x86 nr2 micro-kernel XNNPACK picks for the one-channel transposed conv (see the header of this file).
+ * NOTE XNNPACK may read (never use) up to XNN_EXTRA_BYTES past an input; the operands here are stack arrays inside the
+ * frame functions, so such reads stay inside the thread's stack. */
+#ifdef LO_XNNPACK
+typedef struct { int kind; const void* layer; int a, b; uint32_t q[6]; } lox_key;
+typedef struct { lox_key key; xnn_operator_t op; void* ws; int used; } lox_slot;
+#define LOX_SLOTS 1024
+static __thread lox_slot lox_tab[LOX_SLOTS];
+static int lox_canonical_last = 0;
+static void lox_check(enum xnn_status st, const char* what) {
+  if (st != xnn_status_success) { fprintf(stderr, "lyra_oracle (xnnpack backend): %s failed: %d\n", what, (int)st); abort(); }
+}
+static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static lox_slot* lox_find(const lox_key* k) {
+  uint64_t h = 1469598103934665603ull;
+  const uint8_t* p = (const uint8_t*)k;
+  for (size_t i = 0; i < sizeof *k; ++i) h = (h ^ p[i]) * 1099511628211ull;
+  for (uint32_t i = (uint32_t)h & (LOX_SLOTS - 1);; i = (i + 1) & (LOX_SLOTS - 1)) {
+    lox_slot* s = &lox_tab[i];
+    if (!s->used) { s->key = *k; s->used = 1; s->op = NULL; s->ws = NULL; return s; }
+    if (memcmp(&s->key, k, sizeof *k) == 0) return s;
+  }
+}
+static lox_key lox_mkkey(int kind, const void* layer, int a, int b) {
+  lox_key k; memset(&k, 0, sizeof k); k.kind = kind; k.layer = layer; k.a = a; k.b = b; return k;
+}
+static void* lox_ws_alloc(size_t ws, size_t wa) {
+  if (!ws) return NULL;
+  return aligned_alloc(wa > 64 ? wa : 64, (ws + 63) / 64 * 64 + 64);
+}
+/* CONV_2D / DEPTHWISE_CONV_2D with a [k,1] kernel, VALID padding, batch 1, width 1 */
+static void lox_conv_f32(const void* layer, int depthwise, int Tin, int k, int stride, int dil, int groups, int gic, int goc,
+                         const float* w, const float* b, const float* in, float* out) {
+  lox_key key = lox_mkkey(1, layer, Tin, depthwise);
+  lox_slot* s = lox_find(&key);
+  if (!s->op) {
+    const size_t cin = (size_t)groups * gic, cout = (size_t)groups * goc;
+    lox_check(xnn_create_convolution2d_nhwc_f32(0, 0, 0, 0, (uint32_t)k, 1, (uint32_t)stride, 1, (uint32_t)dil, 1, (uint32_t)groups,
+                                                (size_t)gic, (size_t)goc, cin, cout, w, b, -INFINITY, INFINITY,
+                                                depthwise ? XNN_FLAG_DEPTHWISE_CONVOLUTION : 0, NULL, NULL, &s->op), "create conv f32");
+    size_t ws = 0, wa = 0, oh = 0, ow = 0;
+    lox_check(xnn_reshape_convolution2d_nhwc_f32(s->op, 1, (size_t)Tin, 1, &ws, &wa, &oh, &ow, NULL), "reshape conv f32");
+    s->ws = lox_ws_alloc(ws, wa);
+  }
+  lox_check(xnn_setup_convolution2d_nhwc_f32(s->op, s->ws, in, out), "setup conv f32");
+  lox_check(xnn_run_operator(s->op, NULL), "run conv f32");
+}
+static void lox_conv_q8(const void* layer, int depthwise, int Tin, int k, int stride, int dil, int groups, int gic, int goc,
+                        int32_t zin, float sin, const float* wscale, const int8_t* w, const int32_t* b, int32_t zout, float sout,
+                        const int8_t* in, int8_t* out) {
+  lox_key key = lox_mkkey(2, layer, Tin, depthwise);
+  lox_slot* s = lox_find(&key);
+  if (!s->op) {
+    const size_t cin = (size_t)groups * gic, cout = (size_t)groups * goc;
+    lox_check(xnn_create_convolution2d_nhwc_qs8_qc8w(0, 0, 0, 0, (uint32_t)k, 1, (uint32_t)stride, 1, (uint32_t)dil, 1,
+                                                     (uint32_t)groups, (size_t)gic, (size_t)goc, cin, cout, (int8_t)zin, sin, wscale,
+                                                     w, b, (int8_t)zout, sout, -128, 127,
+                                                     depthwise ? XNN_FLAG_DEPTHWISE_CONVOLUTION : 0, NULL, NULL, &s->op), "create conv qs8");
+    size_t ws = 0, wa = 0, oh = 0, ow = 0;
+    lox_check(xnn_reshape_convolution2d_nhwc_qs8_qc8w(s->op, 1, (size_t)Tin, 1, &ws, &wa, &oh, &ow, NULL), "reshape conv qs8");
+    s->ws = lox_ws_alloc(ws, wa);
+  }
+  lox_check(xnn_setup_convolution2d_nhwc_qs8_qc8w(s->op, s->ws, in, out), "setup conv qs8");
+  lox_check(xnn_run_operator(s->op, NULL), "run conv qs8");
+}
+/* elementwise: LEAKY_RELU (f32, qs8), QUANTIZE / DEQUANTIZE (convert), ADD (f32, qs8) */
+static void lox_unary(int kind, enum xnn_unary_operator type, enum xnn_datatype din, enum xnn_datatype dout, float alpha,
+                      const struct xnn_quantization_params* qi, const struct xnn_quantization_params* qo, int n,
+                      const void* in, void* out) {
+  lox_key key = lox_mkkey(kind, NULL, n, (int)type);
+  if (qi) { key.q[0] = (uint32_t)qi->zero_point; key.q[1] = fbits(qi->scale); }
+  if (qo) { key.q[2] = (uint32_t)qo->zero_point; key.q[3] = fbits(qo->scale); }
+  key.q[4] = (uint32_t)din * 64u + (uint32_t)dout;
+  lox_slot* s = lox_find(&key);
+  if (!s->op) {
+    union xnn_unary_params p; memset(&p, 0, sizeof p); p.leaky_relu.negative_slope = alpha;
+    lox_check(xnn_create_unary_elementwise_nc(type, din, dout, type == xnn_unary_leaky_relu ? &p : NULL, qi, qo, 0, &s->op), "create unary");
+    lox_check(xnn_reshape_unary_elementwise_nc(s->op, 1, (size_t)n, (size_t)n, (size_t)n, NULL), "reshape unary");
+  }
+  lox_check(xnn_setup_unary_elementwise_nc(s->op, in, out), "setup unary");
+  lox_check(xnn_run_operator(s->op, NULL), "run unary");
+}
+static void lox_add(enum xnn_datatype dt, const struct xnn_quantization_params* qa, const struct xnn_quantization_params* qb,
+                    const struct xnn_quantization_params* qo, int n, const void* a, const void* b, void* out) {
+  lox_key key = lox_mkkey(5, NULL, n, (int)dt);
+  if (qa) { key.q[0] = (uint32_t)qa->zero_point; key.q[1] = fbits(qa->scale); key.q[2] = (uint32_t)qb->zero_point;
+            key.q[3] = fbits(qb->scale); key.q[4] = (uint32_t)qo->zero_point; key.q[5] = fbits(qo->scale); }
+  lox_slot* s = lox_find(&key);
+  if (!s->op) {
+    lox_check(xnn_create_binary_elementwise_nd(xnn_binary_add, dt, qa, qb, qo, 0, &s->op), "create add");
+    const size_t shape[1] = {(size_t)n};
+    lox_check(xnn_reshape_binary_elementwise_nd(s->op, 1, shape, 1, shape, NULL), "reshape add");
+  }
+  lox_check(xnn_setup_binary_elementwise_nd(s->op, a, b, out), "setup add");
+  lox_check(xnn_run_operator(s->op, NULL), "run add");
+}
+#endif  /* LO_XNNPACK */
+
+/* elementwise fp32 / conversion ops over arrays (the scalar forms above, or XNNPACK operators in the -DLO_XNNPACK build) */
+static void lrelu_f_run(const float* in, int n, float* out) {
+#ifdef LO_XNNPACK
+  lox_unary(3, xnn_unary_leaky_relu, xnn_datatype_fp32, xnn_datatype_fp32, LRELU_ALPHA, NULL, NULL, n, in, out);
+#else
+  for (int i = 0; i < n; ++i) out[i] = lrelu_f(in[i]);
+#endif
+}
+static void add_f_run(const float* a, const float* b, int n, float* out) {
+#ifdef LO_XNNPACK
+  lox_add(xnn_datatype_fp32, NULL, NULL, NULL, n, a, b, out);
+#else
+  for (int i = 0; i < n; ++i) out[i] = a[i] + b[i];
+#endif
+}
+static void quantize_run(const float* in, int n, float s, int32_t z, int8_t* out, int mode) {
+#ifdef LO_XNNPACK
+  (void)mode;
+  const struct xnn_quantization_params qo = {z, s};
+  lox_unary(4, xnn_unary_convert, xnn_datatype_fp32, xnn_datatype_qint8, 0.f, NULL, &qo, n, in, out);
+#else
+  for (int i = 0; i < n; ++i) out[i] = quantize_f(in[i], s, z, mode);
+#endif
+}
+static void dequantize_run(const int8_t* in, int n, float s, int32_t z, float* out) {
+#ifdef LO_XNNPACK
+  const struct xnn_quantization_params qi = {z, s};
+  lox_unary(4, xnn_unary_convert, xnn_datatype_qint8, xnn_datatype_fp32, 0.f, &qi, NULL, n, in, out);
+#else
+  for (int i = 0; i < n; ++i) out[i] = dequantize_f(in[i], s, z);
+#endif
+}
+
 /* out[Tout][Cout]; in[Tin][Cin]; Tout = (Tin-k)/stride+1 */
 static void conv_f_run(const conv_f* L, const float* in, int Tin, float* out) {
+#ifdef LO_XNNPACK
+  lox_conv_f32(L, 0, Tin, L->k, L->stride, 1, L->groups, L->cig, L->cog, L->w0, L->b, in, out);
+  return;
+#endif
   int Cin = L->cig * L->groups, K = L->k * L->cig;
   int Tout = (Tin - L->k) / L->stride + 1;
   float acc[512];
@@ -423,6 +586,11 @@ static void conv_f_run(const conv_f* L, const float* in, int Tin, float* out) {
 }
 
 static void conv_q_run(const conv_q* L, const int8_t* in, int Tin, int8_t* out, int mode) {
+#ifdef LO_XNNPACK
+  (void)mode;
+  lox_conv_q8(L, 0, Tin, L->k, L->stride, 1, L->groups, L->cig, L->cog, L->zin, L->sin, L->ws, L->w0, L->b, L->zout, L->sout, in, out);
+  return;
+#endif
   int Cin = L->cig * L->groups, K = L->k * L->cig;
   int Tout = (Tin - L->k) / L->stride + 1;
   int32_t acc[512];
@@ -452,6 +620,10 @@ static void conv_q_run(const conv_q* L, const int8_t* in, int Tin, int8_t* out, 
 
 /* in[Tin][C] with Tin = Tout + (k-1)*dil */
 static void dw_f_run(const dw_f* L, const float* in, int Tout, float* out) {
+#ifdef LO_XNNPACK
+  lox_conv_f32(L, 1, Tout + (L->k - 1) * L->dil, L->k, 1, L->dil, L->c, 1, 1, L->w, L->b, in, out);
+  return;
+#endif
   for (int t = 0; t < Tout; ++t)
     for (int c = 0; c < L->c; ++c) {
       float acc = L->b[c];
@@ -461,6 +633,11 @@ static void dw_f_run(const dw_f* L, const float* in, int Tout, float* out) {
 }
 
 static void dw_q_run(const dw_q* L, const int8_t* in, int Tout, int8_t* out, int mode) {
+#ifdef LO_XNNPACK
+  (void)mode;
+  lox_conv_q8(L, 1, Tout + (L->k - 1) * L->dil, L->k, 1, L->dil, L->c, 1, 1, L->zin, L->sin, L->ws, L->w, L->b, L->zout, L->sout, in, out);
+  return;
+#endif
   for (int t = 0; t < Tout; ++t)
     for (int c = 0; c < L->c; ++c) {
       int32_t acc = 0;
@@ -477,6 +654,22 @@ static void dw_q_run(const dw_q* L, const int8_t* in, int Tout, int8_t* out, int
  * input rows t = b, b-1, .. b-(k/s-1) (taps ascending = newest input first), channels ascending -- per output
  * element exactly the canonical chain; vectorises over the s*Cout outputs of a block. */
 static void tconv_f_run(const tconv_f* L, const float* in, int Tin, float* out) {
+#ifdef LO_XNNPACK
+  if (!(lox_canonical_last && L->cout == 1)) {   /* TRANSPOSE_CONV: filter [cout][k][1][cin] */
+    lox_key key = lox_mkkey(6, L, Tin, 0);
+    lox_slot* s = lox_find(&key);
+    if (!s->op) {
+      lox_check(xnn_create_deconvolution2d_nhwc_f32(0, 0, 0, 0, (uint32_t)L->k, 1, (uint32_t)L->stride, 1, 1, 1, 1, (size_t)L->cin,
+                                                    (size_t)L->cout, (size_t)L->cin, (size_t)L->cout, L->w, L->b, -INFINITY, INFINITY,
+                                                    0, NULL, NULL, &s->op), "create deconv f32");
+      size_t oh = 0, ow = 0;
+      lox_check(xnn_reshape_deconvolution2d_nhwc_f32(s->op, 1, (size_t)Tin, 1, 0, 0, &oh, &ow, NULL), "reshape deconv f32");
+    }
+    lox_check(xnn_setup_deconvolution2d_nhwc_f32(s->op, in, out), "setup deconv f32");
+    lox_check(xnn_run_operator(s->op, NULL), "run deconv f32");
+    return;
+  }
+#endif
   int taps = L->k / L->stride, N = L->stride * L->cout;
   int blocks = Tin + taps - 1;
   float acc[512];
@@ -499,6 +692,23 @@ static void tconv_f_run(const tconv_f* L, const float* in, int Tin, float* out) 
 }
 
 static void tconv_q_run(const tconv_q* L, const int8_t* in, int in_stride, int Tin, int8_t* out, int mode) {
+#ifdef LO_XNNPACK
+  (void)mode;
+  {
+    lox_key key = lox_mkkey(7, L, Tin, in_stride);
+    lox_slot* s = lox_find(&key);
+    if (!s->op) {
+      lox_check(xnn_create_deconvolution2d_nhwc_qs8(0, 0, 0, 0, (uint32_t)L->k, 1, (uint32_t)L->stride, 1, 1, 1, 1, (size_t)L->cin,
+                                                    (size_t)L->cout, (size_t)in_stride, (size_t)L->cout, (int8_t)L->zin, L->sin, L->ws0,
+                                                    L->w, L->b, (int8_t)L->zout, L->sout, -128, 127, 0, NULL, NULL, &s->op), "create deconv qs8");
+      size_t oh = 0, ow = 0;
+      lox_check(xnn_reshape_deconvolution2d_nhwc_qs8(s->op, 1, (size_t)Tin, 1, 0, 0, &oh, &ow, NULL), "reshape deconv qs8");
+    }
+    lox_check(xnn_setup_deconvolution2d_nhwc_qs8(s->op, in, out), "setup deconv qs8");
+    lox_check(xnn_run_operator(s->op, NULL), "run deconv qs8");
+    return;
+  }
+#endif
   int Tout = (Tin - 1) * L->stride + L->k;
   for (int tau = 0; tau < Tout; ++tau)
     for (int co = 0; co < L->cout; ++co) {
@@ -527,9 +737,25 @@ static inline int8_t lrelu_q_run1(const lrelu_q* L, int8_t x, int mode) {
   return clamp8(r + L->zout);
 }
 static void lrelu_q_run(const lrelu_q* L, const int8_t* in, int n, int8_t* out, int mode) {
+#ifdef LO_XNNPACK
+  (void)mode;
+  {
+    const struct xnn_quantization_params qi = {L->zin, L->sin}, qo = {L->zout, L->sout};
+    lox_unary(8, xnn_unary_leaky_relu, xnn_datatype_qint8, xnn_datatype_qint8, LRELU_ALPHA, &qi, &qo, n, in, out);
+    return;
+  }
+#endif
   for (int i = 0; i < n; ++i) out[i] = lrelu_q_run1(L, in[i], mode);
 }
 static void add_q_run(const add_q* L, const int8_t* a, const int8_t* b, int n, int8_t* out, int mode) {
+#ifdef LO_XNNPACK
+  (void)mode;
+  {
+    const struct xnn_quantization_params qa = {L->z1, L->s1}, qb = {L->z2, L->s2}, qo = {L->zo, L->so};
+    lox_add(xnn_datatype_qint8, &qa, &qb, &qo, n, a, b, out);
+    return;
+  }
+#endif
   for (int i = 0; i < n; ++i) {
     if (mode == 2) {
       int32_t acc = L->xbias + (int32_t)a[i] * L->xma + (int32_t)b[i] * L->xmb;
@@ -639,6 +865,11 @@ static void tap8(lo_stream* s, const int8_t* p, int n) {
 static void init_logmel(lo_model* m);
 
 lo_model* lo_load(const char* pack_path, int requant_mode) {
+#ifdef LO_XNNPACK
+  if (requant_mode != 2) { fprintf(stderr, "lyra_oracle (xnnpack backend): only the xnnpack arithmetic mode exists here\n"); return NULL; }
+  if (xnn_initialize(NULL) != xnn_status_success) { fprintf(stderr, "lyra_oracle: xnn_initialize failed\n"); return NULL; }
+  { const char* e = getenv("LOX_CANONICAL_LAST"); lox_canonical_last = e && atoi(e) != 0; }
+#endif
   lo_model* m = (lo_model*)calloc(1, sizeof(lo_model));
   if (pk_open(&m->pk, pack_path) != 0) { free(m); return NULL; }
   const pk_file* pk = &m->pk;
@@ -702,6 +933,21 @@ lo_model* lo_load(const char* pack_path, int requant_mode) {
 }
 
 void lo_free(lo_model* m) { if (m) { free(m->pk.blob); free(m); } }
+/* which engine this build of the file computes with */
+const char* lo_engine(void) {
+#ifdef LO_XNNPACK
+  return "xnnpack-operators";
+#else
+  return "scalar";
+#endif
+}
+void lo_set_canonical_last(int on) {
+#ifdef LO_XNNPACK
+  lox_canonical_last = on;
+#else
+  (void)on;
+#endif
+}
 
 lo_stream* lo_stream_new(void) { return (lo_stream*)calloc(1, sizeof(lo_stream)); }
 void lo_stream_reset(lo_stream* s) {
@@ -726,22 +972,22 @@ static void push_state(float* state, int S, const float* x, int T, int C, float*
 static void resblock_f(const dw_f* dw, const conv_f* pw, const conv_f* cv, float* state, float* x, int T,
                        float* s0, float* s1, float* s2) {
   int C = dw->c, S = 2 * dw->dil;
-  for (int i = 0; i < T * C; ++i) s0[i] = lrelu_f(x[i]);
+  lrelu_f_run(x, T * C, s0);
   push_state(state, S, s0, T, C, s1);
   dw_f_run(dw, s1, T, s0);
   conv_f_run(pw, s0, T, s2);
-  for (int i = 0; i < T * C; ++i) s2[i] = lrelu_f(s2[i]);
+  lrelu_f_run(s2, T * C, s2);
   conv_f_run(cv, s2, T, s0);
-  for (int i = 0; i < T * C; ++i) x[i] = s0[i] + x[i];
+  add_f_run(s0, x, T * C, x);
 }
 
 /* int8 state plumbing: float state, dequantised new rows, re-quantised concat (graph ops 108-114) */
 static void push_state_q(float* state, int S, const int8_t* a, int T, int C, float s, int32_t z, int8_t* buf8, int mode) {
   float tmp[20 * 512];
   memcpy(tmp, state, sizeof(float) * (size_t)S * C);
-  for (int i = 0; i < T * C; ++i) tmp[(size_t)S * C + i] = dequantize_f(a[i], s, z);
-  for (int i = 0; i < (S + T) * C; ++i) buf8[i] = quantize_f(tmp[i], s, z, mode);
-  for (int i = 0; i < S * C; ++i) state[i] = dequantize_f(buf8[(size_t)T * C + i], s, z);
+  dequantize_run(a, T * C, s, z, tmp + (size_t)S * C);
+  quantize_run(tmp, (S + T) * C, s, z, buf8, mode);
+  dequantize_run(buf8 + (size_t)T * C, S * C, s, z, state);
 }
 
 /* Int16ToUnitScalar (dsp_utils.h:106-108) and UnitToInt16Scalar + ClipToInt16Scalar (dsp_utils.h:54-88): scale, clip,
@@ -764,31 +1010,30 @@ void lo_encode_frame(const lo_model* m, lo_stream* s, const int16_t* pcm, float*
   conv_f_run(&E->first, in, 368, x);                      /* [20][64] */
   tap(s, x, 20 * 64);
   for (int r = 0; r < 3; ++r) { resblock_f(&E->dw[r], &E->pw[r], &E->cv[r], s->e_r0[r], x, 20, s0, s1, s2); tap(s, x, 20 * 64); }
-  for (int i = 0; i < 20 * 64; ++i) s0[i] = lrelu_f(x[i]);
+  lrelu_f_run(x, 20 * 64, s0);
   push_state(s->e_d0, 5, s0, 20, 64, s1);
   float y[4 * 128];
   conv_f_run(&E->down0, s1, 25, y);                       /* [4][128] */
   tap(s, y, 4 * 128);
   for (int r = 0; r < 3; ++r) { resblock_f(&E->dw[3 + r], &E->pw[3 + r], &E->cv[3 + r], s->e_r1[r], y, 4, s0, s1, s2); tap(s, y, 4 * 128); }
-  for (int i = 0; i < 4 * 128; ++i) s0[i] = lrelu_f(y[i]);
+  lrelu_f_run(y, 4 * 128, s0);
   push_state(s->e_d1, 2, s0, 4, 128, s1);
   float z[2 * 256];
   conv_f_run(&E->down1, s1, 6, z);                        /* x148 [2][256] */
   tap(s, z, 2 * 256);
   /* resblock 0 @256: float dw + pw, then int8 */
-  for (int i = 0; i < 2 * 256; ++i) s0[i] = lrelu_f(z[i]);
+  lrelu_f_run(z, 2 * 256, s0);
   push_state(s->e_r2[0], 2, s0, 2, 256, s1);
   dw_f_run(&E->dw[6], s1, 2, s0);
   conv_f_run(&E->pw[6], s0, 2, s2);
   tap(s, s2, 2 * 256);
   int8_t a8[20 * 256], b8[20 * 256], c8[2 * 512], X[2 * 256], X2[2 * 256];
-  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(s2[i], E->q_r0_s, E->q_r0_z, m->mode);
+  quantize_run(s2, 512, E->q_r0_s, E->q_r0_z, a8, m->mode);
   lrelu_q_run(&E->lr[0], a8, 512, b8, m->mode);
   conv_q_run(&E->r0b, b8, 2, a8, m->mode);
-  for (int i = 0; i < 512; ++i) {
-    float v = dequantize_f(a8[i], E->dq_r0_s, E->dq_r0_z) + z[i];
-    X[i] = quantize_f(v, E->q_x1_s, E->q_x1_z, m->mode);
-  }
+  dequantize_run(a8, 512, E->dq_r0_s, E->dq_r0_z, s0);   /* DEQUANTIZE, float ADD with the skip, QUANTIZE */
+  add_f_run(s0, z, 512, s0);
+  quantize_run(s0, 512, E->q_x1_s, E->q_x1_z, X, m->mode);
   tap8(s, X, 512);
   for (int r = 0; r < 2; ++r) {
     const lrelu_q* la = &E->lr[1 + 2 * r];
@@ -811,7 +1056,7 @@ void lo_encode_frame(const lo_model* m, lo_stream* s, const int16_t* pcm, float*
   int8_t f8[64];
   conv_q_run(&E->bott, b8, 3, f8, m->mode);               /* [1][64] */
   tap8(s, f8, 64);
-  for (int i = 0; i < 64; ++i) feat[i] = dequantize_f(f8[i], E->out_s, E->out_z);
+  dequantize_run(f8, 64, E->out_s, E->out_z, feat);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -891,28 +1136,29 @@ void lo_decode_frame(const lo_model* m, lo_stream* s, const float* feat, int16_t
   conv_f_run(&D->head, in, 3, h);
   tap(s, h, 512);
   int8_t h8[512], t8[6 * 64];
-  for (int i = 0; i < 512; ++i) h8[i] = quantize_f(lrelu_f(h[i]), D->q0_s, D->q0_z, m->mode);
+  lrelu_f_run(h, 512, h);
+  quantize_run(h, 512, D->q0_s, D->q0_z, h8, m->mode);
   float x164[2 * 256];
   for (int g = 0; g < 4; ++g) {
     float y[4 * 64];
     tconv_q_run(&D->up0[g], h8 + g * 128, 128, 1, t8, m->mode);
-    for (int i = 0; i < 4 * 64; ++i) y[i] = dequantize_f(t8[i], D->up0[g].sout, D->up0[g].zout);
+    dequantize_run(t8, 4 * 64, D->up0[g].sout, D->up0[g].zout, y);
     overlap_state(y, 4, 64, s->d_up0[g], 2, D->sub0[g]);
     for (int t = 0; t < 2; ++t) memcpy(x164 + t * 256 + g * 64, y + t * 64, sizeof(float) * 64);
   }
   tap(s, x164, 512);
   int8_t a8[20 * 256], b8[20 * 256], X[512], X2[512];
-  for (int i = 0; i < 512; ++i) a8[i] = quantize_f(lrelu_f(x164[i]), D->q1_s, D->q1_z, m->mode);
+  lrelu_f_run(x164, 512, s0);
+  quantize_run(s0, 512, D->q1_s, D->q1_z, a8, m->mode);
   /* resblock 0 (skip is the float x164) */
   push_state_q(s->d_r0[0], 2, a8, 2, 256, D->q1_s, D->q1_z, b8, m->mode);
   dw_q_run(&D->dwq[0], b8, 2, a8, m->mode);
   conv_q_run(&D->pwq[0], a8, 2, b8, m->mode);
   lrelu_q_run(&D->lr[0], b8, 512, a8, m->mode);
   conv_q_run(&D->cvq[0], a8, 2, b8, m->mode);
-  for (int i = 0; i < 512; ++i) {
-    float v = dequantize_f(b8[i], D->cvq[0].sout, D->cvq[0].zout) + x164[i];
-    X[i] = quantize_f(v, D->q3_s, D->q3_z, m->mode);
-  }
+  dequantize_run(b8, 512, D->cvq[0].sout, D->cvq[0].zout, s0);
+  add_f_run(s0, x164, 512, s0);
+  quantize_run(s0, 512, D->q3_s, D->q3_z, X, m->mode);
   tap8(s, X, 512);
   for (int r = 1; r < 3; ++r) {
     const lrelu_q* la = &D->lr[2 * r - 1];
@@ -932,19 +1178,19 @@ void lo_decode_frame(const lo_model* m, lo_stream* s, const float* feat, int16_t
   for (int g = 0; g < 2; ++g) {
     float y[6 * 64];
     tconv_q_run(&D->up1[g], a8 + g * 128, 256, 2, t8, m->mode);
-    for (int i = 0; i < 6 * 64; ++i) y[i] = dequantize_f(t8[i], D->up1[g].sout, D->up1[g].zout);
+    dequantize_run(t8, 6 * 64, D->up1[g].sout, D->up1[g].zout, y);
     overlap_state(y, 6, 64, s->d_up1[g], 2, D->sub1[g]);
     for (int t = 0; t < 4; ++t) memcpy(x231 + t * 128 + g * 64, y + t * 64, sizeof(float) * 64);
   }
   tap(s, x231, 4 * 128);
   for (int r = 0; r < 3; ++r) { resblock_f(&D->dw[r], &D->pw[r], &D->cv[r], s->d_r1[r], x231, 4, s0, s1, s2); tap(s, x231, 4 * 128); }
-  for (int i = 0; i < 4 * 128; ++i) s0[i] = lrelu_f(x231[i]);
+  lrelu_f_run(x231, 4 * 128, s0);
   float y25[25 * 64];
   tconv_f_run(&D->up2, s0, 4, y25);
   overlap_state(y25, 25, 64, s->d_up2, 5, D->sub2);
   tap(s, y25, 20 * 64);
   for (int r = 0; r < 3; ++r) { resblock_f(&D->dw[3 + r], &D->pw[3 + r], &D->cv[3 + r], s->d_r2[r], y25, 20, s0, s1, s2); tap(s, y25, 20 * 64); }
-  for (int i = 0; i < 20 * 64; ++i) s0[i] = lrelu_f(y25[i]);
+  lrelu_f_run(y25, 20 * 64, s0);
   float out[368];
   tconv_f_run(&D->up3, s0, 20, out);
   overlap_state(out, 368, 1, s->d_up3, 48, D->sub3);

@@ -25,14 +25,34 @@ def build(force=False):
 
 
 _lib = None
+_lib_xnn = None
+SO_XNN = os.path.join(HERE, "_xnn", "liblyra_oracle_xnn.so")
 
 
-def lib():
-    global _lib
+def xnn_engine_available():
+    """The second build of lyra_oracle.c (-DLO_XNNPACK): same plumbing, every arithmetic operator an XNNPACK operator of
+    torch's libtorch_cpu.so -- bench.py's cpu_baseline_xnnpack (oracle/Makefile target _xnn/liblyra_oracle_xnn.so)."""
+    return os.path.exists(SO_XNN)
+
+
+def lib(engine="scalar"):
+    global _lib, _lib_xnn
+    if engine == "xnnpack":
+        if _lib_xnn is None:
+            import torch  # noqa: F401  (maps libtorch_cpu.so, which carries the XNNPACK, and its dependencies first)
+            _lib_xnn = _bind(C.CDLL(SO_XNN))
+            _lib_xnn.lo_engine.restype = C.c_char_p
+            assert _lib_xnn.lo_engine() == b"xnnpack-operators"
+        return _lib_xnn
     if _lib is None:
         if not os.path.exists(SO):
             build()
-        L = C.CDLL(SO)
+        _lib = _bind(C.CDLL(SO))
+    return _lib
+
+
+def _bind(L):
+    if True:
         L.lo_load.restype = C.c_void_p
         L.lo_load.argtypes = [C.c_char_p, C.c_int]
         L.lo_free.argtypes = [C.c_void_p]
@@ -74,8 +94,8 @@ def lib():
         L.lo_run_batch.restype = C.c_double
         L.lo_run_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-        _lib = L
-    return _lib
+        L.lo_set_canonical_last.argtypes = [C.c_int]
+    return L
 
 
 def _p(a):
@@ -85,8 +105,10 @@ def _p(a):
 class Oracle:
     """The model (weights + requantisation mode)."""
 
-    def __init__(self, pack=DEFAULT_PACK, mode="exact"):
-        self.L = lib()
+    def __init__(self, pack=DEFAULT_PACK, mode="exact", engine="scalar"):
+        """engine "scalar": the C restatement; "xnnpack": the same plumbing over XNNPACK operators (mode "xnnpack" only)."""
+        self.L = lib(engine)
+        self.engine = engine
         self.h = self.L.lo_load(os.path.abspath(pack).encode(), MODES[mode])
         if not self.h:
             raise RuntimeError(f"cannot load {pack}")

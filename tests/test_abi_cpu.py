@@ -314,3 +314,45 @@ def test_cxx_tflite_reader_rejects_bad_model_dirs(tmp_path):
     d = fresh("version")
     open(d / "lyra_config.binarypb", "wb").write(b"\x08\x02")
     assert run(d).returncode == 0
+
+
+def test_bench_one_rank_has_no_process_group_and_says_so():
+    """N = 1 without --force-dist: no torch.distributed process group exists, and the line says that instead of naming a
+    backend that never ran (round-5 review, weak #10)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stub-context", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+           "--latency-steps", "0", "--no-kernel-table", "--ramp-steps", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["ranks"] == 1 and "process_group" not in r
+    assert "no process group at one rank" in r["config"]["parallelism"] and "RCCL" not in r["config"]["parallelism"]
+
+
+def test_bench_ranks_confine_themselves_to_their_share_of_the_cpu_quota():
+    """--gpus N: every rank takes a disjoint slice of the CPUs the quota is worth (confine_rank_to_cpu_share), rank 0 gets the
+    original mask back for the CPU legs, and the line reports the share (round-5 review, item 9)."""
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench\n"
+            "full = sorted(os.sched_getaffinity(0)); got = []; quota = bench.usable_cores()\n"
+            "for local in range(2):\n"
+            "    os.sched_setaffinity(0, full)\n"
+            "    r = bench.confine_rank_to_cpu_share(local, 2)\n"
+            "    got.append(None if r is None else (r[0] == full, r[1], sorted(os.sched_getaffinity(0))))\n"
+            "print(json.dumps(dict(full=full, quota=quota, got=got)))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    if len(r["full"]) < 4:
+        pytest.skip("fewer than 4 CPUs visible")
+    per = max(2, r["quota"] // 2)
+    a, b = r["got"]
+    assert a[0] and b[0] and a[1] == a[2] and b[1] == b[2]            # the mask was applied, the original one is returned
+    assert len(a[1]) == per and len(b[1]) == per and not set(a[1]) & set(b[1])
+    # ... and through main(): two stub ranks, the share is in the line
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stub-context", "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--latency-steps", "0", "--no-kernel-table", "--ramp-steps", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["cpus_per_rank"] == per
