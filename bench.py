@@ -158,9 +158,9 @@ def parse(argv=None):
                     help="--gpus N in ONE process: a host thread and a context per GPU, no process group")
     ap.add_argument("--bcast-weights", action="store_true",
                     help="rank 0 reads the weight container, RCCL-broadcasts it, every rank builds from the image")
-    ap.add_argument("--requant", default="xnnpack", choices=["xnnpack", "exact", "gemmlowp_double"],
-                    help="arithmetic of the graphs' int8 regions: xnnpack = what the reference runs (default); the other "
-                         "two are TFLite's builtin kernels (include/lyra_hip.h)")
+    ap.add_argument("--requant", default="xnnpack", choices=["xnnpack", "exact", "gemmlowp_double", "builtin_mixed"],
+                    help="arithmetic of the graphs' int8 regions: xnnpack = what the reference runs (default); the others "
+                         "are TFLite's builtin kernels (builtin_mixed: per operator, include/lyra_hip.h)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the self-check: after all timing, the packets and the PCM of the run's LAST TWO steps are "
                          "compared, for the first --verify-streams streams of every rank, with the CPU oracle replaying "

@@ -100,10 +100,18 @@ extern "C" {
  *                    TFLite's builtin kernels (what the reference falls back to when the delegate cannot be applied,
  *                    tflite_model_wrapper.cc:76-78): Q31 single-rounding or gemmlowp double-rounding convolutions, gemmlowp
  *                    LeakyReLU / ADD, round-half-away QUANTIZE.
- * The fp32 layers are the same in all three: bias-first fused chains (XNNPACK's order). */
+ *   BUILTIN_MIXED    what the graphs compute if the delegate takes the fp32 operators but NOT the signed-int8 ones: the
+ *                    reference ORs in only TFLITE_XNNPACK_DELEGATE_FLAG_QU8 (tflite_model_wrapper.cc:65-67) and its graphs are
+ *                    QS8, so whether the int8 regions reach XNNPACK depends on a build-time default of TFLite 2.11's delegate
+ *                    that cannot be observed offline.  TFLite's builtin int8 kernels per operator: ungrouped
+ *                    CONV_2D single rounding, grouped CONV_2D / DEPTHWISE_CONV_2D / TRANSPOSE_CONV double rounding, builtin
+ *                    LeakyReLU / ADD / QUANTIZE.  Whichever way that default falls, a bit-exact mode exists; switching is this
+ *                    one argument.
+ * The fp32 layers are the same in all four: bias-first fused chains (XNNPACK's order). */
 #define LYRA_HIP_REQUANT_EXACT 0
 #define LYRA_HIP_REQUANT_GEMMLOWP_DOUBLE 1
 #define LYRA_HIP_REQUANT_XNNPACK 2
+#define LYRA_HIP_REQUANT_BUILTIN_MIXED 3
 #define LYRA_HIP_REQUANT_DEFAULT LYRA_HIP_REQUANT_XNNPACK
 
 typedef struct lyra_hip_ctx lyra_hip_ctx;

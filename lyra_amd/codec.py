@@ -155,7 +155,7 @@ class LyraHip:
         overlap."""
         self.L = _load(library)   # library: path of a build variant (experiments); default liblyra_hip.so
         h = C.c_void_p()
-        mode = {"exact": 0, "gemmlowp_double": 1, "xnnpack": 2}[requant]
+        mode = {"exact": 0, "gemmlowp_double": 1, "xnnpack": 2, "builtin_mixed": 3}[requant]
         saved = os.environ.get("LYRA_HIP_SUBBATCHES")
         if sub_batches is not None:
             os.environ["LYRA_HIP_SUBBATCHES"] = str(int(sub_batches))

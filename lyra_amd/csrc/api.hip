@@ -555,7 +555,7 @@ int launch_extract(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B, 
   for (int i = 0; i < before_s2.n; ++i) HIPCHK(c, hipStreamWaitEvent(st_, before_s2.e[i], 0));
   { ProfScope ps(c, K_ENC_S2, st_);
     for (int nt = cdiv(B, enc_s2_streams_per_wg()), g = cdiv(nt, c->tile_div[2]), t0 = 0; t0 < nt; t0 += g)
-      hipLaunchKernelGGL(c->mode == 2 ? enc_s2_xn_kernel : c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(std::min(g, nt - t0)), dim3(512),
+      hipLaunchKernelGGL(c->mode == 2 ? enc_s2_xn_kernel : c->mode == 3 ? enc_s2_bm_kernel : c->mode ? enc_s2_dr_kernel : enc_s2_kernel, dim3(std::min(g, nt - t0)), dim3(512),
                          enc_s2_lds_bytes() + c->lds_pad[2], st_, M.d_enc2, e1, d_ids, B, c->sm.base[st::R_E2], d_feat, codes,
                          c->cw[K_ENC_S2], t0); }
   HIPCHK(c, hipGetLastError());
@@ -622,7 +622,7 @@ int launch_generate(lyra_hip_ctx* c, int k, int lo, const int32_t* d_ids, int B,
 #endif
   { ProfScope ps(c, K_DEC_S0, st_);
     for (int nt = cdiv(B, dec_s0_streams_per_wg()), g = cdiv(nt, c->tile_div[3]), t0 = 0; t0 < nt; t0 += g)
-      hipLaunchKernelGGL(c->mode == 2 ? dec_s0_xn_kernel : c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(std::min(g, nt - t0)), dim3(512),
+      hipLaunchKernelGGL(c->mode == 2 ? dec_s0_xn_kernel : c->mode == 3 ? dec_s0_bm_kernel : c->mode ? dec_s0_dr_kernel : dec_s0_kernel, dim3(std::min(g, nt - t0)), dim3(512),
                          dec_s0_lds_bytes() + c->lds_pad[3], st_,
                          M.d_dec0, d_feat, d_ids, B, c->sm.base[st::R_D0], d0, d_pkt, num_stages, M.cb,
                          c->cw[K_DEC_S0], t0); }
@@ -718,7 +718,7 @@ int lyra_hip_create_from_image(const void* image, size_t image_bytes, int device
 
 static int create_impl(const char* model_dir, const void* image, size_t image_bytes, int device, int max_streams,
                        int requant_mode, lyra_hip_ctx** out) {
-  if (!out || max_streams <= 0 || (requant_mode < 0 || requant_mode > 2))
+  if (!out || max_streams <= 0 || (requant_mode < 0 || requant_mode > 3))
     return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create: bad argument");
   *out = nullptr;
   int ndev = 0;
@@ -847,6 +847,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
 #endif
       set_lds(dec_s0_kernel, dec_s0_lds_bytes() + c->lds_pad[3]) != hipSuccess ||
       set_lds(enc_s2_dr_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_dr_kernel, dec_s0_lds_bytes()) != hipSuccess ||
+      set_lds(enc_s2_bm_kernel, enc_s2_lds_bytes()) != hipSuccess || set_lds(dec_s0_bm_kernel, dec_s0_lds_bytes()) != hipSuccess ||
       set_lds(enc_s2_xn_kernel, enc_s2_lds_bytes() + c->lds_pad[2]) != hipSuccess || set_lds(dec_s0_xn_kernel, dec_s0_lds_bytes() + c->lds_pad[3]) != hipSuccess ||
       set_lds(dec_s1_kernel, dec_s1_lds_bytes() + c->lds_pad[4]) != hipSuccess || set_lds(dec_s2_kernel, dec_s2_lds_bytes() + c->lds_pad[5]) != hipSuccess ||
       set_lds(logmel_kernel, logmel_lds_bytes()) != hipSuccess || set_lds(cng_kernel, cng_lds_bytes()) != hipSuccess)
@@ -855,12 +856,14 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   if (c->mode == 1) {
     c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_dr_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_dr_kernel");
     c->cw[K_ENC_SIDE] = code_warm_bytes("enc_side_dr_kernel"); c->cw[K_DEC_SIDE] = code_warm_bytes("dec_side_dr_kernel");
+  } else if (c->mode == 3) {
+    c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_bm_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_bm_kernel");
   } else if (c->mode == 2) {
     c->cw[K_ENC_S2] = code_warm_bytes("enc_s2_xn_kernel"); c->cw[K_DEC_S0] = code_warm_bytes("dec_s0_xn_kernel");
     c->cw[K_ENC_SIDE] = code_warm_bytes("enc_side_xn_kernel"); c->cw[K_DEC_SIDE] = code_warm_bytes("dec_side_xn_kernel");
   }
 #ifdef LYRA_PARKED   // parked experiments: only in the `make EXTRA=-DLYRA_PARKED` variant
-  if (const char* f = getenv("LYRA_HIP_FUSED")) c->fused = atoi(f);
+  if (const char* f = getenv("LYRA_HIP_FUSED")) c->fused = c->mode == 3 ? 0 : atoi(f);   // (the parked kernels predate mode 3)
   if (const char* f = getenv("LYRA_HIP_RVQ_WIDE")) c->rvq_wide = atoi(f);
 #else
   if (getenv("LYRA_HIP_FUSED") && atoi(getenv("LYRA_HIP_FUSED")))

@@ -45,6 +45,15 @@ __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_dr_kernel(const De
   if (((int)blockIdx.x + tile0) * SD0 >= B) return;
   dec_s0_body<1>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
+// mode 3 "builtin_mixed": TFLite's builtin int8 kernels per operator (lyra_dev.h conv_flavour)
+__global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_bm_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
+                                                          const int32_t* __restrict__ ids, int B,
+                                                          uint8_t* __restrict__ state, float* __restrict__ out0,
+                                                          const uint8_t* __restrict__ packets, int num_stages,
+                                                          const float* __restrict__ cb, int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * SD0 >= B) return;
+  dec_s0_body<3>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
+}
 // mode 2 "xnnpack" (the default): XNNPACK's QS8 arithmetic
 __global__ __launch_bounds__(NTD0, LYRA_D0XN_WAVES) void dec_s0_xn_kernel(const DecS0P* __restrict__ Pp, const float* __restrict__ feats,
                                                           const int32_t* __restrict__ ids, int B,

@@ -187,7 +187,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       for (int e = 0; e < 4; ++e) {
         const int s = (q & 1) * 4 + e;
         const uint32_t stp = cx.soff(s) + (uint32_t)(st::D_UP0 + g * 512 + co * 4);
-        float y = conv_dequant<MODE>(acc[0][tap][e] + zf + bias, U.M, U.sh, U.zout, P.up0_dq[g].s);   // up0_dq.z == zout (model.hip)
+        float y = conv_dequant<conv_flavour<MODE, false>()>(acc[0][tap][e] + zf + bias, U.M, U.sh, U.zout, P.up0_dq[g].s);   // up0_dq.z == zout (model.hip)
         if (tap < 2) {
           y = y + told[tap < 2 ? tap : 0][e];
           XF[(tap * SD0 + s) * CS2 + pc] = y;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
         int acc = db[e];                                  // zero point folded into dq.b
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc += sx8(x[t][j], e) * sx8(ww[j], e);
-        o[e] = conv_code<MODE>(acc, dM[e], dsh[e], dq.zout);
+        o[e] = conv_code<conv_flavour<MODE, false>()>(acc, dM[e], dsh[e], dq.zout);
       }
       *reinterpret_cast<int*>(&QD[(t * SD0 + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
       if (cx.valid(s)) *cx.at<int>(hp + (uint32_t)(t * 256)) = a[t];
@@ -252,7 +252,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       for (int j = 0; j < 2; ++j) {
         int r8[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r8[e] = lut8(LQ, conv_code<MODE>(acc[j][e], M[j][e], sh[j][e], P.pwq[0].zout));
+        for (int e = 0; e < 4; ++e) r8[e] = lut8(LQ, conv_code<conv_flavour<MODE, true>()>(acc[j][e], M[j][e], sh[j][e], P.pwq[0].zout));   // pointwise: ungrouped
         *reinterpret_cast<int*>(&QP[row * QS + ch0 + 16 * j]) = pack8(r8[0], r8[1], r8[2], r8[3]);
       }
     }
@@ -269,7 +269,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
         int o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = conv_dequant<MODE>(acc[j][e], M[j][e], sh[j][e], P.cvq[0].zout, P.dq_r0.s) +   // dq_r0.z == zout
+          const float v = conv_dequant<conv_flavour<MODE, false>()>(acc[j][e], M[j][e], sh[j][e], P.cvq[0].zout, P.dq_r0.s) +   // dq_r0.z == zout
                           XF[row * CS2 + at16(ch0 + 16 * j + e)];
           o[e] = quantize_code<MODE>(v, P.q3);
         }
@@ -322,7 +322,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
       float y[6];
 #pragma unroll
       for (int tau = 0; tau < 6; ++tau) {
-        y[tau] = conv_dequant<MODE>(o[tau] + bias, U.M, U.sh, U.zout, P.up1_dq[g].s);   // up1_dq.z == zout (model.hip)
+        y[tau] = conv_dequant<conv_flavour<MODE, false>()>(o[tau] + bias, U.M, U.sh, U.zout, P.up1_dq[g].s);   // up1_dq.z == zout (model.hip)
       }
       y[0] = y[0] + *cx.at<const float>(stp);
       y[1] = y[1] + *cx.at<const float>(stp + 256);

@@ -39,6 +39,14 @@ __global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_dr_kernel(const Enc
   if (((int)blockIdx.x + tile0) * S2 >= B) return;
   enc_s2_body<1>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
+// mode 3 "builtin_mixed": TFLite's builtin int8 kernels per operator (lyra_dev.h conv_flavour)
+__global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_bm_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
+                                                         const int32_t* __restrict__ ids, int B,
+                                                         uint8_t* __restrict__ state, float* __restrict__ feats,
+                                                         float* __restrict__ codes_dbg, int code_bytes, int tile0) {
+  if (((int)blockIdx.x + tile0) * S2 >= B) return;
+  enc_s2_body<3>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
+}
 // mode 2 "xnnpack" (the default): XNNPACK's QS8 arithmetic
 __global__ __launch_bounds__(NT2, LYRA_E2XN_WAVES) void enc_s2_xn_kernel(const EncS2P* __restrict__ Pp, const float* __restrict__ in1,
                                                          const int32_t* __restrict__ ids, int B,

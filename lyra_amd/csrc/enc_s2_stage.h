@@ -30,7 +30,7 @@ static_assert(4 * S2 * QS + 16 * QS <= XF_BYTES && 3 * S2 * QS5 + 16 * QS5 <= XF
 
 __host__ __device__ constexpr size_t enc_s2_lds() { return (size_t)2 * XF_BYTES + 3 * QB_BYTES + 2 * S2 * 4 + NLR * 256 + NADD * 2048; }
 
-// MODE: arithmetic flavour of the int8 region (0 exact / 1 gemmlowp double rounding / 2 xnnpack), a compile-time constant:
+// MODE: arithmetic flavour of the int8 region (0 exact / 1 gemmlowp double rounding / 2 xnnpack / 3 builtin_mixed), a compile-time constant:
 // as a run-time value every requantisation carried both arithmetic paths and a (uniform) branch -- a third of this
 // kernel's instructions -- which costs issue slots and, the code being executed once per workgroup, instruction fetch.
 template <int MODE>
@@ -148,7 +148,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
       int o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = conv_dequant<MODE>(acc[j][e], M[j][e], sh[j][e], P.r0b.zout, P.dq_r0.s) +   // dq_r0.z == zout (model.hip checks)
+        const float v = conv_dequant<conv_flavour<MODE, false>()>(acc[j][e], M[j][e], sh[j][e], P.r0b.zout, P.dq_r0.s) +   // dq_r0.z == zout (model.hip checks)
                         XF[row * CS2 + at16(ch0 + 16 * j + e)];
         o[e] = quantize_code<MODE>(v, P.q_x1);
       }
@@ -206,7 +206,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = (q & 1) * 4 + e;
-      int c8 = conv_code<MODE>(dacc[0][j][e] + bias, M, sh, P.down2.zout);
+      int c8 = conv_code<conv_flavour<MODE, false>()>(dacc[0][j][e] + bias, M, sh, P.down2.zout);
       QC[(2 * S2 + s) * QS5 + n] = (int8_t)lut8(LQ + 6 * 256, c8);
     }
   }
@@ -230,7 +230,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int s = q * 4 + e;
-      int c8 = conv_code<MODE>(acc[0][0][e] + bias, M, sh, P.bott.zout);
+      int c8 = conv_code<conv_flavour<MODE, false>()>(acc[0][0][e] + bias, M, sh, P.bott.zout);
       if (s < S2 && cx.valid(s)) {
         *goff<float>(feats + (size_t)b0 * 64, (uint32_t)((s * 64 + n) * 4)) = dequantize_f(c8, P.out);
         if (codes_dbg) codes_dbg[(size_t)(b0 + s) * 64 + n] = (float)c8;

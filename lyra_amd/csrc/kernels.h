@@ -33,6 +33,8 @@ __global__ void enc_s2_dr_kernel(const EncS2P* P, const float* in1, const int32_
                                  float* feats, float* codes_dbg, int code_bytes, int tile0);   // gemmlowp double rounding
 __global__ void enc_s2_xn_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state,
                                  float* feats, float* codes_dbg, int code_bytes, int tile0);   // XNNPACK QS8 arithmetic (default)
+__global__ void enc_s2_bm_kernel(const EncS2P* P, const float* in1, const int32_t* ids, int B, uint8_t* state,
+                                 float* feats, float* codes_dbg, int code_bytes, int tile0);   // TFLite builtin kernels, per-operator mixture
 __global__ void enc_side_kernel(const EncS0P* P0, const EncS1P* P1, const EncS2P* P2, const int16_t* pcm, const int32_t* ids,
                                 int B, uint8_t* st0, uint8_t* st1, uint8_t* st2, float* e0, float* e1, float* feats,
                                 float* codes_dbg, int code_bytes);
@@ -76,6 +78,8 @@ __global__ void dec_s0_kernel(const DecS0P* P, const float* feats, const int32_t
 __global__ void dec_s0_dr_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state,
                                  float* out0, const uint8_t* packets, int num_stages, const float* cb, int code_bytes, int tile0);
 __global__ void dec_s0_xn_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state,
+                                 float* out0, const uint8_t* packets, int num_stages, const float* cb, int code_bytes, int tile0);
+__global__ void dec_s0_bm_kernel(const DecS0P* P, const float* feats, const int32_t* ids, int B, uint8_t* state,
                                  float* out0, const uint8_t* packets, int num_stages, const float* cb, int code_bytes, int tile0);
 __global__ void dec_s1_kernel(const DecS1P* P, const float* in0, const int32_t* ids, int B, uint8_t* state, float* out1,
                               int code_bytes, int tile0);

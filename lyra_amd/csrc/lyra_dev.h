@@ -187,9 +187,18 @@ __device__ __forceinline__ int32_t rne_clamped_code(float v, int32_t z) {
 __device__ __forceinline__ int32_t xnn_requant(int32_t acc, int32_t Mbits, int32_t zout) {
   return rne_clamped_code((float)acc * __int_as_float(Mbits), zout);
 }
-// the layers' requantisation in any mode -> clamped int8 code (as int)
+// Mode 3 "builtin_mixed" (round 6): what the graphs compute if TFLite's XNNPACK delegate takes the fp32 operators but NOT
+// the signed-int8 ones (the reference sets only the QU8 delegate flag, tflite_model_wrapper.cc:65-67) -- TFLite 2.11's builtin
+// int8 kernels per operator, as recalled in DESIGN.md 2: an UNGROUPED CONV_2D runs on the optimized path (single rounding =
+// flavour 0), a grouped CONV_2D, DEPTHWISE_CONV_2D and TRANSPOSE_CONV on the reference kernels (gemmlowp double rounding =
+// flavour 1); LEAKY_RELU / ADD / QUANTIZE are the builtin forms modes 0 and 1 share.  conv_flavour<MODE, UNGROUPED>() is the
+// conv_code / conv_dequant template argument of ONE layer: the kernel's mode everywhere but in mode 3.
+template <int MODE, bool UNGROUPED_CONV>
+__host__ __device__ constexpr int conv_flavour() { return MODE == 3 ? (UNGROUPED_CONV ? 0 : 1) : MODE; }
+// the layers' requantisation in flavour 0 / 1 / 2 -> clamped int8 code (as int)
 template <int MODE>
 __device__ __forceinline__ int32_t conv_code(int32_t acc, int32_t M, int sh, int32_t zout) {
+  static_assert(MODE >= 0 && MODE <= 2, "a layer's flavour (conv_flavour<>), not the kernel's mode");
   if constexpr (MODE == 2) return xnn_requant(acc, M, zout);
   else return clamp8(requant(acc, M, sh, MODE) + zout);
 }

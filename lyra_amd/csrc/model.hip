@@ -153,7 +153,7 @@ int32_t xnn_scale_bits(float s_in, float s_w, float s_out) {
 
 struct Builder {
   const Pack& pk;
-  int mode;                                      // 0 exact / 1 gemmlowp_double / 2 xnnpack
+  int mode;                                      // 0 exact / 1 gemmlowp_double / 2 xnnpack / 3 builtin_mixed (Q31 multipliers and TFLite's elementwise tables like 0 / 1)
   Arena arena;
   std::vector<std::pair<void*, size_t>> fixups;  // (address of a device-pointer field, arena offset)
   std::string nonzero_dw_bias;                   // first fp32 depthwise layer with a non-zero bias (unsupported)

@@ -88,7 +88,7 @@ __device__ __forceinline__ RbqPre resblock_q_prefetch(const TileCtx& cx, int d, 
 }
 
 // la / lm: LDS tables of the block's two LeakyReLUs; addlut: LDS table pair of its ADD.
-// MODE: arithmetic flavour (0 exact / 1 gemmlowp double rounding / 2 xnnpack), compile-time.
+// MODE: arithmetic flavour (0 exact / 1 gemmlowp double rounding / 2 xnnpack / 3 builtin_mixed), compile-time.
 template <int S, int MODE>
 __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP, const TileCtx& cx, int d, int off,
                                               const int8_t* la, const int8_t* lm, const DwQ& dq, const ConvQ& pw,
@@ -118,7 +118,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int acc = __builtin_amdgcn_sdot4(taps3(pre.h[t][0], pre.h[t][1], a, e), wq[e], pre.b[e], false);
-        o[e] = conv_code<MODE>(acc, pre.M[e], pre.sh[e], dq.zout);
+        o[e] = conv_code<conv_flavour<MODE, false>()>(acc, pre.M[e], pre.sh[e], dq.zout);             // depthwise
       }
       *reinterpret_cast<int*>(&QD[(t * S + s) * QS + w4 * 4]) = pack8(o[0], o[1], o[2], o[3]);
     }
@@ -140,7 +140,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
     for (int j = 0; j < 2; ++j) {
       int r8[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r8[e] = lut8(lm, conv_code<MODE>(acc[j][e], pM[j][e], psh[j][e], pw.zout));
+      for (int e = 0; e < 4; ++e) r8[e] = lut8(lm, conv_code<conv_flavour<MODE, true>()>(acc[j][e], pM[j][e], psh[j][e], pw.zout));   // pointwise: ungrouped
       *reinterpret_cast<int*>(&QP[row * QS + ch0 + 16 * j]) = pack8(r8[0], r8[1], r8[2], r8[3]);
     }
   }
@@ -164,7 +164,7 @@ __device__ __forceinline__ void resblock_q256(int8_t* QX, int8_t* QD, int8_t* QP
       int o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int c8 = conv_code<MODE>(acc[j][e], cM[j][e], csh[j][e], cv.zout);
+        const int c8 = conv_code<conv_flavour<MODE, false>()>(acc[j][e], cM[j][e], csh[j][e], cv.zout);   // 1x1, 4 groups
         if constexpr (MODE == 2) o[e] = xnn_add(c8, sx8(xw[j], e), add);   // two multiply-adds and a shift: no table
         else o[e] = add_q_lut(addlut, c8, sx8(xw[j], e), add);
       }

@@ -64,6 +64,11 @@ class Combiner {
   const int kFan = (int)std::max(1L, EnvLong("LYRA_HIP_COMBINER_FAN", 4));
   const long kQuietUs = EnvLong("LYRA_HIP_COMBINER_QUIET_US", 40);
   const long kGatherBaseUs = EnvLong("LYRA_HIP_COMBINER_GATHER_US", 100), kGatherPerReqUs = 2, kGatherMaxUs = 3000;
+  // a gathering leader polls (sched_yield) for this long only, then sleeps on its Waiter until the arrival that completes
+  // the batch wakes it, the quiet time passes or the budget is spent (round 6: up to five leaders used to spin for up to
+  // 3 ms each -- in a CPU-quota-limited container that is quota the arriving threads need, and under SCHED_FIFO
+  // sched_yield() does not give the core to a lower-priority arrival at all)
+  const long kSpinUs = EnvLong("LYRA_HIP_COMBINER_SPIN_US", 30);
   template <class Exec>   // exec(std::vector<Req*>&): sets every request's rc
   void Run(Req* r, Exec exec) {
     thread_local std::shared_ptr<Waiter> me = std::make_shared<Waiter>();
@@ -71,9 +76,12 @@ class Combiner {
     r->state = kPending;
     std::unique_lock<std::mutex> l(mu_);
     pending_.push_back(r);
-    npending_.store((long)pending_.size(), std::memory_order_relaxed);
+    npending_.store((long)pending_.size(), std::memory_order_release);
     if (busy_) {
+      // a leader asleep in its gathering phase is woken by the request that completes the batch it expects
+      std::shared_ptr<Waiter> sleeper = (gather_waiter_ && (long)pending_.size() >= gather_expect_) ? gather_waiter_ : nullptr;
       l.unlock();
+      if (sleeper) { { std::lock_guard<std::mutex> lw(sleeper->m); } sleeper->cv.notify_one(); }
       {
         std::unique_lock<std::mutex> lw(me->m);
         me->cv.wait(lw, [&] { return r->state != kPending; });
@@ -92,21 +100,29 @@ class Combiner {
       // gather: requests are still arriving (the callers of the previous batch are being scheduled); take them along --
       // until as many as before are pending, or nothing has arrived for kQuietUs, or the budget is spent.  Polled with
       // sched_yield(): the threads that are about to arrive get this core.
+      gather_waiter_ = me;
+      gather_expect_ = expect;
       l.unlock();
       const auto g0 = std::chrono::steady_clock::now();
       const auto deadline = g0 + std::chrono::microseconds(std::min(kGatherMaxUs, kGatherBaseUs + kGatherPerReqUs * expect));
+      const auto quiet = std::chrono::microseconds(kQuietUs), spin = std::chrono::microseconds(kSpinUs);
       auto last_arrival = g0;
-      long seen = npending_.load(std::memory_order_relaxed);
+      long seen = npending_.load(std::memory_order_acquire);
       for (;;) {
-        sched_yield();
         const auto now = std::chrono::steady_clock::now();
-        const long have = npending_.load(std::memory_order_relaxed);
+        const long have = npending_.load(std::memory_order_acquire);
         if (have != seen) { seen = have; last_arrival = now; }
-        if (have >= expect || now >= deadline || now - last_arrival >= std::chrono::microseconds(kQuietUs)) break;
+        if (have >= expect || now >= deadline || now - last_arrival >= quiet) break;
+        if (now - g0 < spin) { sched_yield(); continue; }
+        // asleep until the batch is complete (notified), the quiet time has passed without an arrival, or the deadline
+        std::unique_lock<std::mutex> lw(me->m);
+        me->cv.wait_for(lw, std::min<std::chrono::steady_clock::duration>(deadline - now, quiet - (now - last_arrival)),
+                        [&] { return npending_.load(std::memory_order_acquire) >= expect; });
       }
       stats.gather_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g0).count();
       if (seen < expect) stats.timeouts += 1;
       l.lock();
+      gather_waiter_ = nullptr;
     }
     auto batch = std::make_shared<std::vector<Req*>>();
     batch->swap(pending_);
@@ -155,6 +171,8 @@ class Combiner {
   std::atomic<long> npending_{0};       // pending_.size(), readable without mu_ by the gathering leader
   bool busy_ = false;
   long last_[2] = {1, 1};               // sizes of the two latest batches
+  std::shared_ptr<Waiter> gather_waiter_;   // the leader that is gathering right now (guarded by mu_), and what it waits for
+  long gather_expect_ = 0;
 };
 struct HopReq {   // one hop in, one vector out, of one stream
   int32_t id; const void* in; void* out; int arg; int rc;
@@ -170,8 +188,12 @@ struct HopReq {   // one hop in, one vector out, of one stream
 // decoder state of a stream are disjoint (state_layout.h: one region per kernel), so the extractor-side kinds (Extract,
 // log-mel, Quantize) run on one context and the decoder-side kinds (DecodeToLossyFeatures, AddFeatures + GenerateSamples)
 // on a second one: two device calls in flight, on streams that the small-context CU partition already keeps on
-// complementary halves of the chip.  The second context costs one more copy of the 3 MB of weights and of the (unused
-// half of the) per-stream state.
+// complementary halves of the chip.  A context costs a copy of the 3 MB of weights, the per-stream state of max_streams
+// streams and its staging buffers, so each side's context is created on demand (round 6): by the first object that can only
+// ever use that side (feature extractor / log-mel: extractor side; generative model: decoder side), or by the first call of
+// that side (a quantizer object needs the extractor side for Quantize and the decoder side for DecodeToLossyFeatures; it
+// makes sure ONE context exists when it is created, so that a bad model path still fails in the factory).  A process that
+// only encodes or only decodes holds one context.
 class SharedContext {
  public:
   static SharedContext& Get() { static SharedContext s; return s; }
@@ -179,34 +201,39 @@ class SharedContext {
   int max_streams = 1024;
   enum Side { kEncSide, kDecSide, kSides };
 
-  lyra_hip_ctx* Acquire(const std::string& model_dir, int* stream_id) {
+  // `needs`: the side this object will certainly use (kSides = either will do, as long as one exists).  -> success
+  bool Acquire(const std::string& model_dir, int* stream_id, int needs) {
     std::lock_guard<std::mutex> l(mu_);
-    if (!side_[0].ctx) {
-      for (int k = 0; k < kSides; ++k)
-        if (lyra_hip_create(model_dir.c_str(), device, max_streams, LYRA_HIP_REQUANT_DEFAULT, &side_[k].ctx) != 0) {
-          LOG(ERROR) << "lyra_hip_create failed: " << lyra_hip_last_error(nullptr);
-          side_[k].ctx = nullptr;
-          DestroyAll();
-          return nullptr;
-        }
-      for (int i = max_streams - 1; i >= 0; --i) free_.push_back(i);
+    if (users_ == 0) {
+      model_dir_ = model_dir;
+      streams_ = max_streams;
+      free_.clear();
+      for (int i = streams_ - 1; i >= 0; --i) free_.push_back(i);
     }
-    if (free_.empty()) { LOG(ERROR) << "No free stream slot (SetMaxStreams)."; return nullptr; }
+    if (needs == kSides) needs = side_[kDecSide].ctx && !side_[kEncSide].ctx ? kDecSide : kEncSide;
+    {
+      std::lock_guard<std::mutex> lc(side_[needs].call_mu);
+      if (!EnsureContext(needs)) {
+        if (users_ == 0) DestroyAll(/*locked_side=*/needs);
+        return false;
+      }
+    }
+    if (free_.empty()) { LOG(ERROR) << "No free stream slot (SetMaxStreams)."; return false; }
     const int32_t id = free_.back();
     for (int k = 0; k < kSides; ++k) {
       // The reset touches the same staging buffers and id-stamp table as the calls running on other threads' objects:
-      // take the context's call mutex.
+      // take the context's call mutex.  A side whose context does not exist yet needs no reset: it is created fresh.
       std::lock_guard<std::mutex> lc(side_[k].call_mu);
-      if (lyra_hip_reset_streams(side_[k].ctx, &id, 1) != 0) {
+      if (side_[k].ctx && lyra_hip_reset_streams(side_[k].ctx, &id, 1) != 0) {
         LOG(ERROR) << "lyra_hip_reset_streams failed: " << lyra_hip_last_error(side_[k].ctx);
-        if (users_ == 0) DestroyAll();
-        return nullptr;   // the slot stays on the free list
+        if (users_ == 0) DestroyAll(k);
+        return false;   // the slot stays on the free list
       }
     }
     free_.pop_back();
     ++users_;
     *stream_id = id;
-    return side_[0].ctx;
+    return true;
   }
   void Release(int stream_id) {
     std::lock_guard<std::mutex> l(mu_);
@@ -218,6 +245,10 @@ class SharedContext {
   enum Kind { kExtract, kLogMel, kGenerate, kQuantize, kDequantize, kKinds };
   static Side SideOf(Kind kind) { return kind == kGenerate || kind == kDequantize ? kDecSide : kEncSide; }
   const char* LastError(Kind kind) { return lyra_hip_last_error(side_[SideOf(kind)].ctx); }
+  int contexts_alive() {
+    std::lock_guard<std::mutex> l(mu_);
+    return (side_[0].ctx ? 1 : 0) + (side_[1].ctx ? 1 : 0);
+  }
   int Call(Kind kind, int32_t id, const void* in, void* out, int arg = 0) {
     HopReq r{id, in, out, arg, -1};
     comb_[kind].Run(&r, [&](std::vector<HopReq*>& batch) { Execute(kind, batch); });
@@ -232,9 +263,20 @@ class SharedContext {
     std::vector<int32_t> ids;         // staging of a combined call (guarded by call_mu)
     std::vector<uint8_t> in, out;
   };
-  void DestroyAll() {                 // mu_ held
+  // call_mu of the side held.  The model path and stream count are those of the first Acquire since the last DestroyAll.
+  bool EnsureContext(int k) {
+    if (side_[k].ctx) return true;
+    if (lyra_hip_create(model_dir_.c_str(), device, streams_, LYRA_HIP_REQUANT_DEFAULT, &side_[k].ctx) != 0) {
+      LOG(ERROR) << "lyra_hip_create failed: " << lyra_hip_last_error(nullptr);
+      side_[k].ctx = nullptr;
+      return false;
+    }
+    return true;
+  }
+  void DestroyAll(int locked_side = -1) {   // mu_ held
     for (int k = 0; k < kSides; ++k) {
-      std::lock_guard<std::mutex> lc(side_[k].call_mu);   // no call of another thread may still be inside the context
+      std::unique_lock<std::mutex> lc(side_[k].call_mu, std::defer_lock);   // no call of another thread may still be inside
+      if (k != locked_side) lc.lock();
       if (side_[k].ctx) lyra_hip_destroy(side_[k].ctx);
       side_[k].ctx = nullptr;
     }
@@ -264,6 +306,10 @@ class SharedContext {
     int rc;
     PerSide& S = side_[SideOf(kind)];
     std::lock_guard<std::mutex> l(S.call_mu);
+    if (!EnsureContext(SideOf(kind))) {   // first call of this side (a quantizer object's other half): created fresh
+      for (HopReq* q : batch) q->rc = LYRA_HIP_EHIP;
+      return;
+    }
     if (B == 1) {   // the common uncontended case: no staging copies
       HopReq* q = batch[0];
       rc = Dispatch(kind, S.ctx, &q->id, 1, q->in, q->out, q->arg);
@@ -296,25 +342,26 @@ class SharedContext {
   std::mutex mu_;
   std::vector<int> free_;
   int users_ = 0;
+  std::string model_dir_;   // of the objects alive (the first Acquire since the last DestroyAll)
+  int streams_ = 0;
 };
 
 class StreamHandle {
  public:
-  explicit StreamHandle(const ghc::filesystem::path& model_path) {
-    ctx_ = SharedContext::Get().Acquire(model_path.string(), &id_);
+  StreamHandle(const ghc::filesystem::path& model_path, int needs_side) {
+    ok_ = SharedContext::Get().Acquire(model_path.string(), &id_, needs_side);
   }
-  ~StreamHandle() { if (ctx_) SharedContext::Get().Release(id_); }
-  bool ok() const { return ctx_ != nullptr; }
-  lyra_hip_ctx* ctx() const { return ctx_; }
+  ~StreamHandle() { if (ok_) SharedContext::Get().Release(id_); }
+  bool ok() const { return ok_; }
   int32_t id() const { return id_; }
  private:
-  lyra_hip_ctx* ctx_ = nullptr;
+  bool ok_ = false;
   int id_ = -1;
 };
 
 class SoundStreamEncoderHip : public FeatureExtractorInterface {
  public:
-  explicit SoundStreamEncoderHip(const ghc::filesystem::path& p) : h_(p) {}
+  explicit SoundStreamEncoderHip(const ghc::filesystem::path& p) : h_(p, SharedContext::kEncSide) {}
   bool ok() const { return h_.ok(); }
   std::optional<std::vector<float>> Extract(const absl::Span<const int16_t> audio) override {
     if (static_cast<int>(audio.size()) != kHop) {
@@ -334,7 +381,7 @@ class SoundStreamEncoderHip : public FeatureExtractorInterface {
 
 class LogMelHip : public FeatureExtractorInterface {
  public:
-  explicit LogMelHip(const ghc::filesystem::path& p) : h_(p) {}
+  explicit LogMelHip(const ghc::filesystem::path& p) : h_(p, SharedContext::kEncSide) {}
   bool ok() const { return h_.ok(); }
   std::optional<std::vector<float>> Extract(const absl::Span<const int16_t> audio) override {
     if (static_cast<int>(audio.size()) != kHop) {
@@ -352,7 +399,7 @@ class LogMelHip : public FeatureExtractorInterface {
 
 class ResidualVectorQuantizerHip : public VectorQuantizerInterface {
  public:
-  explicit ResidualVectorQuantizerHip(const ghc::filesystem::path& p) : h_(p) {}
+  explicit ResidualVectorQuantizerHip(const ghc::filesystem::path& p) : h_(p, SharedContext::kSides) {}
   bool ok() const { return h_.ok(); }
   std::optional<std::string> Quantize(const std::vector<float>& features, int num_bits) const override {
     if (num_bits > kMaxBits) {
@@ -401,7 +448,8 @@ class ResidualVectorQuantizerHip : public VectorQuantizerInterface {
 
 class LyraGanModelHip : public GenerativeModel {
  public:
-  LyraGanModelHip(const ghc::filesystem::path& p, int num_features) : GenerativeModel(kHop, num_features), h_(p) {}
+  LyraGanModelHip(const ghc::filesystem::path& p, int num_features)
+      : GenerativeModel(kHop, num_features), h_(p, SharedContext::kDecSide) {}
   bool ok() const { return h_.ok(); }
  protected:
   bool RunConditioning(const std::vector<float>& features) override {
@@ -439,6 +487,7 @@ HipCallStats GetHipCallStats() {
   }
   return st;
 }
+int GetHipContextCount() { return SharedContext::Get().contexts_alive(); }
 void SetHipDevice(int device) { SharedContext::Get().device = device; }
 void SetMaxStreams(int n) { SharedContext::Get().max_streams = n; }
 

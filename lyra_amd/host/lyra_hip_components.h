@@ -27,6 +27,9 @@ std::unique_ptr<FeatureExtractorInterface> CreateLogMelExtractor(const ghc::file
 // the largest number of streams one device call carried.
 struct HipCallStats { long calls = 0, device_calls = 0, largest_batch = 0, gather_us = 0, exec_us = 0, gather_timeouts = 0; };
 HipCallStats GetHipCallStats();
+// GPU contexts the plugin objects of this process hold right now: 0 (no object alive), 1 (only extractor-side or only
+// decoder-side calls so far) or 2.  Each holds the weights, the state of max_streams streams and its staging buffers.
+int GetHipContextCount();
 
 // Process-wide settings of the shared context (call before the first Create*).
 void SetHipDevice(int device);

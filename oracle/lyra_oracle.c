@@ -69,6 +69,12 @@
  *     (a*ma + b*mb + bias) >> shift; QUANTIZE RNE(x * (1/s)).  Each formula equals
  *     real XNNPACK exhaustively / on 80 M random outputs (same test).  Default
  *     since round 4.
+ *   3 "builtin_mixed"    (round 6) what the graphs compute if the delegate takes the
+ *     fp32 operators but NOT the signed-int8 ones (only the QU8 delegate flag is set,
+ *     tflite_model_wrapper.cc:65-67): TFLite 2.11's builtin int8 kernels, per operator
+ *     as recalled in DESIGN.md 2 -- ungrouped CONV_2D single rounding (mode 0's
+ *     formula), grouped CONV_2D / DEPTHWISE_CONV_2D / TRANSPOSE_CONV double rounding
+ *     (mode 1's), LEAKY_RELU / ADD / QUANTIZE the builtin forms of modes 0 / 1.
  *
  * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off).
  */
@@ -611,7 +617,10 @@ static void conv_q_run(const conv_q* L, const int8_t* in, int Tin, int8_t* out, 
         int c = g * L->cog + co;
         int32_t a = acc[co] + L->b[c];
         if (mode == 2) { o[co] = xnn_requant(a, L->fs[c], L->zout); continue; }
-        int32_t r = mode ? mbqm_double(a, L->q[c]) : mbqm_exact(a, L->q[c]);
+        /* mode 3 "builtin_mixed": an ungrouped CONV_2D takes TFLite's optimized path (single rounding), a grouped one the
+         * reference kernel (double rounding) */
+        const int dbl = mode == 3 ? L->groups > 1 : mode;
+        int32_t r = dbl ? mbqm_double(a, L->q[c]) : mbqm_exact(a, L->q[c]);
         o[co] = clamp8(r + L->zout);
       }
     }

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "liblyra_oracle.so")
 DEFAULT_PACK = os.path.join(HERE, "..", "lyra_amd", "assets", "lyra_v1.lyrapack")
 
-MODES = {"exact": 0, "gemmlowp_double": 1, "xnnpack": 2}
+MODES = {"exact": 0, "gemmlowp_double": 1, "xnnpack": 2, "builtin_mixed": 3}
 
 
 def build(force=False):

@@ -242,13 +242,13 @@ def chain_deconv_c4(x, w, b, stride, fused=False):
 # ----------------------------------------------------------------------------
 class Interpreter:
     def __init__(self, path, requant="exact", acc64=False, fp32=None):
-        assert requant in ("exact", "gemmlowp_double", "xnnpack")
+        assert requant in ("exact", "gemmlowp_double", "xnnpack", "builtin_mixed")
         self.model = tr.load(path)
         self.requant = requant
         self.acc64 = acc64
         # fp32 layer evaluation: "numpy" (a @ b, or float64 accumulation with acc64=True) or "chain" (bias-first fmaf
         # chains, oracle/chain_f32.c -- XNNPACK's order).  Mode "xnnpack" implies "chain".
-        self.fp32 = fp32 if fp32 is not None else ("chain" if requant == "xnnpack" else "numpy")
+        self.fp32 = fp32 if fp32 is not None else ("chain" if requant in ("xnnpack", "builtin_mixed") else "numpy")
         assert self.fp32 in ("numpy", "chain")
         self.vars = {}
         self.called_once = set()
@@ -411,8 +411,13 @@ class Interpreter:
             return (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
         return a @ b
 
-    def _requant(self, acc, in_t, w_t, out_t, cout_axis_len):
-        """acc: int64 [..., Cout] -> int8."""
+    def _requant(self, acc, in_t, w_t, out_t, cout_axis_len, ungrouped_conv=False):
+        """acc: int64 [..., Cout] -> int8.  Mode "builtin_mixed" (round 6) is the per-operator mixture the graphs compute if
+        TFLite's XNNPACK delegate takes the fp32 operators but NOT the signed-int8 ones (the reference ORs in only the QU8
+        delegate flag, tflite_model_wrapper.cc:65-67): the builtin int8 kernels of TFLite 2.11 as recalled in DESIGN.md 2 --
+        an ungrouped CONV_2D goes through the optimized path (ruy: single rounding of the Q31 product = "exact"), a grouped
+        CONV_2D, DEPTHWISE_CONV_2D and TRANSPOSE_CONV through the reference-kernel MultiplyByQuantizedMultiplier
+        (gemmlowp double rounding); LEAKY_RELU / ADD / QUANTIZE are the builtin forms of "exact" / "gemmlowp_double"."""
         s_in = np.float64(in_t.scale[0])
         s_out = np.float64(out_t.scale[0])
         if self.requant == "xnnpack":
@@ -426,7 +431,7 @@ class Interpreter:
         Ms, Ss = zip(*[quantize_multiplier(s_in * w / s_out) for w in ws])
         Ms = np.array(Ms, np.int64)
         Ss = np.array(Ss, np.int64)
-        if self.requant == "exact":
+        if self.requant == "exact" or (self.requant == "builtin_mixed" and ungrouped_conv):
             y = mbqm_exact(acc, Ms, Ss)
         else:
             y = mbqm_double(acc, Ms, Ss)
@@ -461,7 +466,7 @@ class Interpreter:
             out[:, gi * Cog:(gi + 1) * Cog] = (patches @ wg) if is_q else self._mm(patches, wg)
         if is_q:
             out = out + b.astype(np.int64)[None, :]
-            r = self._requant(out, in_t, w_t, out_t, Cout)
+            r = self._requant(out, in_t, w_t, out_t, Cout, ungrouped_conv=(g == 1))
         else:
             r = out + b[None, :]
         return r.reshape(1, Hout, 1, Cout)

@@ -41,6 +41,14 @@ def oracle_xnnpack():
 
 
 @pytest.fixture(scope="session")
+def oracle_mixed():
+    """Mode "builtin_mixed": TFLite's builtin int8 kernels per operator (the delegate takes only the fp32 operators)."""
+    from oracle import lyra_oracle
+    lyra_oracle.build()
+    return lyra_oracle.Oracle(mode="builtin_mixed")
+
+
+@pytest.fixture(scope="session")
 def oracle_default(oracle_xnnpack):
     """The oracle in the product's default arithmetic mode ("xnnpack": what the reference runs, use_xnn=true)."""
     return oracle_xnnpack

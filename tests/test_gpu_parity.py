@@ -31,7 +31,7 @@ def ctx():
 def ctx_builtin():
     """The two TFLite-builtin-kernel flavours."""
     import lyra_amd
-    cs = {m: lyra_amd.LyraHip(max_streams=64, requant=m) for m in ("exact", "gemmlowp_double")}
+    cs = {m: lyra_amd.LyraHip(max_streams=64, requant=m) for m in ("exact", "gemmlowp_double", "builtin_mixed")}
     yield cs
     for c in cs.values():
         c.close()
@@ -73,6 +73,12 @@ def test_speech_golden_xnnpack(ctx, golden_dir):
 @pytest.mark.parametrize("mode,suf", [("exact", "exact"), ("gemmlowp_double", "double")])
 def test_speech_golden_builtin_modes(ctx_builtin, golden_dir, mode, suf):
     _speech_golden(ctx_builtin[mode], _g(golden_dir, "speech_sample1.npz"), suf)
+
+
+def test_speech_golden_builtin_mixed(ctx_builtin, golden_dir):
+    """Mode "builtin_mixed" (round 6) against the flatbuffers executed in that mode (tools/make_golden.py --mixed)."""
+    from test_oracle_golden import _mixed_as_suffixed
+    _speech_golden(ctx_builtin["builtin_mixed"], _mixed_as_suffixed(golden_dir), "mixed")
 
 
 def test_known_answer_packets_fused(ctx, ctx_builtin, golden_dir):
@@ -142,11 +148,11 @@ def test_vs_oracle_bit_exact(ctx, oracle_default, B, bits):
         assert np.array_equal(out, r["pcm"][t]), f"PCM not bit-exact at step {t}"
 
 
-@pytest.mark.parametrize("mode", ["exact", "gemmlowp_double"])
-def test_builtin_modes_vs_oracle_bit_exact(ctx_builtin, oracle_exact, oracle_double, mode):
+@pytest.mark.parametrize("mode", ["exact", "gemmlowp_double", "builtin_mixed"])
+def test_builtin_modes_vs_oracle_bit_exact(ctx_builtin, oracle_exact, oracle_double, oracle_mixed, mode):
     """The two TFLite-builtin flavours stay available on CPU and GPU (what the graphs compute without the delegate)."""
     from oracle import lyra_oracle
-    o = oracle_exact if mode == "exact" else oracle_double
+    o = {"exact": oracle_exact, "gemmlowp_double": oracle_double, "builtin_mixed": oracle_mixed}[mode]
     c = ctx_builtin[mode]
     B, T, bits = 21, 6, 184
     pcm = synth(B, T, seed=777)

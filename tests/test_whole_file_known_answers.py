@@ -24,8 +24,11 @@ SHA = {  # mode -> bits -> sha256[:16] of the first 150 packets of sample1_16kHz
     # round 4, mode "xnnpack" (default): the same 150 hops through oracle/tflite_interp.py executing the flatbuffers with
     # XNNPACK's arithmetic, every op of which equals real XNNPACK (tests/test_xnnpack_witness.py)
     "xnnpack": {64: "6d4759d9ca14c62a", 120: "446e2075921b6970", 184: "6045429471825364"},
+    # round 6, mode "builtin_mixed": the same 150 hops through oracle/tflite_interp.py in that mode (per-operator mixture of
+    # TFLite's builtin int8 kernels; tools/make_golden.py run_codec(frames, "builtin_mixed"))
+    "builtin_mixed": {64: "c1fbbe3ce79e64e2", 120: "c962d6b698b26286", 184: "0ce68bd4e0120eba"},
 }
-MODES = ["xnnpack", "exact", "gemmlowp_double"]
+MODES = ["xnnpack", "exact", "gemmlowp_double", "builtin_mixed"]
 
 
 def hops_of(golden_dir, name):
@@ -52,8 +55,8 @@ def lsd_per_hop(pcm_in, pcm_out):
 # oracle (CPU)
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", MODES)
-def test_oracle_whole_file_packets(golden_dir, oracle_exact, oracle_double, oracle_xnnpack, mode):
-    o = {"exact": oracle_exact, "gemmlowp_double": oracle_double, "xnnpack": oracle_xnnpack}[mode]
+def test_oracle_whole_file_packets(golden_dir, oracle_exact, oracle_double, oracle_xnnpack, oracle_mixed, mode):
+    o = {"exact": oracle_exact, "gemmlowp_double": oracle_double, "xnnpack": oracle_xnnpack, "builtin_mixed": oracle_mixed}[mode]
     hops = hops_of(golden_dir, "sample1_16kHz")
     assert hops.shape[0] == 172
     for bits in (64, 120, 184):
@@ -108,13 +111,13 @@ def test_gpu_whole_file_packets_b1(golden_dir, ctx_by_mode, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", MODES)
-def test_gpu_whole_file_b4096_all_hops(golden_dir, ctx_by_mode, oracle_exact, oracle_double, oracle_xnnpack, mode):
+def test_gpu_whole_file_b4096_all_hops(golden_dir, ctx_by_mode, oracle_exact, oracle_double, oracle_xnnpack, oracle_mixed, mode):
     """The whole file on 4096 streams at once (device-pointer pipeline as benchmarked), every stream a replica:
     packets hash to the known answer, PCM is bit-exact versus the oracle, all replicas agree, over all 172 hops."""
     import torch
     import lyra_amd
     ctx = ctx_by_mode(mode)
-    o = {"exact": oracle_exact, "gemmlowp_double": oracle_double, "xnnpack": oracle_xnnpack}[mode]
+    o = {"exact": oracle_exact, "gemmlowp_double": oracle_double, "xnnpack": oracle_xnnpack, "builtin_mixed": oracle_mixed}[mode]
     hops = hops_of(golden_dir, "sample1_16kHz")
     B, bits = 4096, 184
     ref = lyra_oracle.run_batch(o, hops[:, None, :], bits // 4, do_decode=True)

@@ -64,7 +64,26 @@ def packets_of(idx, n):
     return np.array([[(int(r[2 * j]) << 4) | int(r[2 * j + 1]) for j in range(n // 2)] for r in idx], np.uint8)
 
 
+def make_mixed():
+    """Round 6: the fourth arithmetic mode, "builtin_mixed" (oracle/tflite_interp.py _requant), on the same 50 hops of
+    speech, in a file of its own so that the other fixtures stay byte-identical:  python tools/make_golden.py --mixed"""
+    w = wave.open(REF + "/testdata/sample1_16kHz.wav")
+    pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+    frames = pcm[:50 * 320].reshape(50, 320)
+    g = run_codec(frames, "builtin_mixed")
+    np.savez_compressed(os.path.join(OUT, "speech_sample1_mixed.npz"), pcm_in=frames, feats=g["feats"], idx=g["idx"],
+                        lossy=g["lossy"], pcm=g["pcm"], pcmf=g["pcm_f"])
+    for other in ("exact", "gemmlowp_double", "xnnpack"):
+        o = run_codec(frames[:20], other)
+        print("builtin_mixed vs", other, ": feature codes differing in 20 hops", int((o["feats"] != g["feats"][:20]).sum()), "of", 20 * 64)
+    for n in (16, 30, 46):
+        print("speech builtin_mixed", n * 4, "bits sha256[:16] of first 50 packets",
+              hashlib.sha256(packets_of(g["idx"], n).tobytes()).hexdigest()[:16])
+
+
 def main():
+    if "--mixed" in sys.argv:
+        return make_mixed()
     os.makedirs(OUT, exist_ok=True)
     # --- 1. real speech -----------------------------------------------------
     w = wave.open(REF + "/testdata/sample1_16kHz.wav")
