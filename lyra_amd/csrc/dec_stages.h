@@ -559,15 +559,23 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   const int wn = wave & 3, wm = wave >> 2;
   const int pcol = at16(wn * 16 + (lane & 15));
   // the stage input does not depend on the stream ids: requested with them, ahead of the barrier (see enc_s1_body)
-  f32x4 xr[5][1];  // residual stream in registers (MFMA C layout)
+  constexpr bool SW = LYRA_SWAP64 != 0;   // operand-swapped GEMMs: a lane holds 4 consecutive channels of ONE row (lyra_dev.h)
+  f32x4 xr[5][1];  // residual stream in registers (MFMA C layout; transposed with SW: see resblocks64r)
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 5; ++i) {
+    if constexpr (SW) {
+      const int R = (wm * 5 + i) * 16 + m, t = R / SD2, s = R & (SD2 - 1);
+      const int sb = min(s, B - 1 - b0);
+      xr[i][0] = *goff<const f32x4>(in1 + (size_t)b0 * 1280, (uint32_t)(((sb * 20 + t) * 64 + wn * 16 + q * 4) * 4));
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / SD2, s = R & (SD2 - 1);
-      int sb = min(s, B - 1 - b0);
-      xr[i][0][e] = *goff<const float>(in1 + (size_t)b0 * 1280, (uint32_t)(((sb * 20 + t) * 64 + pcol) * 4));
+      for (int e = 0; e < 4; ++e) {
+        int R = (wm * 5 + i) * 16 + q * 4 + e, t = R / SD2, s = R & (SD2 - 1);
+        int sb = min(s, B - 1 - b0);
+        xr[i][0][e] = *goff<const float>(in1 + (size_t)b0 * 1280, (uint32_t)(((sb * 20 + t) * 64 + pcol) * 4));
+      }
     }
+  }
   if (tid < SD2) sids[tid] = my_id;
   const auto warm = l2_warm<NTD2, 1>(P.warm);
   const auto warm_code = code_warm<NTD2>(code_bytes);
@@ -589,8 +597,12 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
   for (int i = 0; i < 5; ++i)
 {
     const f32x4 a4 = lrelu4(xr[i][0]);
+    if constexpr (SW) {
+      *reinterpret_cast<f32x4*>(&XB[(3 * SD2 + (wm * 5 + i) * 16 + m) * CS0 + wn * 16 + q * 4]) = a4;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = a4[e];
+      for (int e = 0; e < 4; ++e) XB[(3 * SD2 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = a4[e];
+    }
   }
   __syncthreads();
   // tconv k64/s16, polyphase: blocks b = 0..22 (+1 of padding), rows (b, s); K = 4 x 64 (newest input first: chunk
@@ -604,8 +616,42 @@ __device__ __forceinline__ void dec_s2_body(const DecS2P& P, const float* __rest
     };
     const float bias = as_global(P.up.b)[0];
     const f32x4 bias4[1] = {(f32x4){bias, bias, bias, bias}};
-    gemm_f32_init<2, 1, 16, 16>(XB, aoff, P.up.w, bias4, acc);
+    gemm_f32_init<2, 1, 16, 16, gemm_pf<2, 1>(), SW>(XB, aoff, P.up.w, bias4, acc);   // (one output channel: the splat is every phase's bias)
     const int j = lane & 15;
+    if constexpr (SW) {
+      // row (b, s) = this lane's C column; its four values are phases 4q .. 4q + 3 = four CONSECUTIVE output samples
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int R = (2 * wave + i) * 16 + m, b = R / SD2, s = R & (SD2 - 1);
+        if (b > 22) continue;
+        const int tau0 = 16 * b + 4 * q;
+        f32x4 y = acc[i][0];
+        f32x4 old = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tau0 < 48) old = *reinterpret_cast<const f32x4*>(&SB[s * 48 + tau0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = y[e] + old[e];   // (+ 0.f beyond the old tail, as the graph's ADD does)
+        if (!cx.valid(s)) continue;
+        if (tau0 < 320) {
+          // UnitToInt16Scalar (dsp_utils.h:54-88): scale, clip, C truncation
+          int v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float f = y[e] * 32768.f;
+            f = f < -32768.f ? -32768.f : f;
+            f = f > 32767.f ? 32767.f : f;
+            v[e] = (int)(int16_t)f;
+          }
+          typedef int i32x2 __attribute__((ext_vector_type(2)));
+          const i32x2 pk = (i32x2){(v[0] & 0xffff) | (v[1] << 16), (v[2] & 0xffff) | (v[3] << 16)};
+          *goff<i32x2>(pcm + (size_t)b0 * 320, (uint32_t)((s * 320 + tau0) * 2)) = pk;
+        } else {
+          f32x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = y[e] - P.up_sub;
+          *cx.at<f32x4>(cx.soff(s) + (uint32_t)(st::D_UP3 + (tau0 - 320) * 4)) = t;
+        }
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

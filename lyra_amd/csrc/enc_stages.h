@@ -103,6 +103,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   const int wn = wave & 3, wm = wave >> 2;  // GEMM wave grid for N = 64: N tile x M group of 5 tiles
   const int ncol = wn * 16 + (lane & 15);   // logical output channel of this lane's C column
   const int pcol = at16(ncol);
+  constexpr bool SW = LYRA_SWAP64 != 0;     // operand-swapped GEMMs: a lane holds 4 consecutive channels of ONE row (lyra_dev.h)
 
   // ---- B. first conv k64/s16: [20*S rows] x K=64 x N=64 ---------------------------------------
   f32x4 xr[5][1];  // the residual stream X, resident in registers (MFMA C layout) through the three blocks
@@ -111,7 +112,7 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
       int R = (wm * 5 + i) * 16 + m;
       return (R & (S0 - 1)) * PBS + (R / S0 + c) * 16 + q * 4;
     };
-    gemm_f32_bias<5, 1, 4, 4>(PB, aoff, P.first.w + wn * 4 * 64, P.first.b, wn * 16, xr);
+    gemm_f32_bias<5, 1, 4, 4, gemm_pf<5, 1>(), SW>(PB, aoff, P.first.w + wn * 4 * 64, P.first.b, wn * 16, xr);
   }
   __syncthreads();  // PCM staging area is free again
 #pragma unroll
@@ -132,8 +133,12 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
   for (int i = 0; i < 5; ++i)
 {
     const f32x4 a4 = lrelu4(xr[i][0]);
+    if constexpr (SW) {
+      *reinterpret_cast<f32x4*>(&XB[(5 * S0 + (wm * 5 + i) * 16 + m) * CS0 + wn * 16 + q * 4]) = a4;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) XB[(5 * S0 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = a4[e];
+      for (int e = 0; e < 4; ++e) XB[(5 * S0 + (wm * 5 + i) * 16 + q * 4 + e) * CS0 + pcol] = a4[e];
+    }
   }
   __syncthreads();
   for (int idx = tid; idx < 5 * S0 * 16; idx += NT0) {
@@ -153,19 +158,29 @@ __device__ __forceinline__ void enc_s0_body(const EncS0P& P, const int16_t* __re
       int R = i * 16 + m;
       return ((5 * (R / S0) + tap) * S0 + (R & (S0 - 1))) * CS0 + c16 * 16 + q * 4;
     };
-    gemm_f32_bias<MTW, NTW, 40, 40>(XB, aoff, P.down.w + (wave * NTW) * 40 * 64, P.down.b, wave * NTW * 16, acc);
+    gemm_f32_bias<MTW, NTW, 40, 40, gemm_pf<MTW, NTW>(), SW>(XB, aoff, P.down.w + (wave * NTW) * 40 * 64, P.down.b,
+                                                             wave * NTW * 16, acc);
     LYRA_TSTAMP(5);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      int n = (wave * NTW + j) * 16 + (lane & 15);
-      int pc = at16(n);
+      if constexpr (SW) {   // row (tau, s) = this lane's C column, 4 consecutive physical channels: one 16-byte store
 #pragma unroll
-      for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int R = i * 16 + q * 4 + e, tau = R / S0, s = R & (S0 - 1);
-          if (valid(s)) *goff<float>(out0 + (size_t)b0 * 512, (uint32_t)(((s * 4 + tau) * 128 + pc) * 4)) = acc[i][j][e];
+        for (int i = 0; i < MTW; ++i) {
+          const int R = i * 16 + m, tau = R / S0, s = R & (S0 - 1);
+          if (valid(s))
+            *goff<f32x4>(out0 + (size_t)b0 * 512, (uint32_t)(((s * 4 + tau) * 128 + (wave * NTW + j) * 16 + q * 4) * 4)) = acc[i][j];
         }
+      } else {
+        int n = (wave * NTW + j) * 16 + (lane & 15);
+        int pc = at16(n);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int R = i * 16 + q * 4 + e, tau = R / S0, s = R & (S0 - 1);
+            if (valid(s)) *goff<float>(out0 + (size_t)b0 * 512, (uint32_t)(((s * 4 + tau) * 128 + pc) * 4)) = acc[i][j][e];
+          }
+      }
     }
   }
   LYRA_WG_END();
@@ -259,18 +274,28 @@ __device__ __forceinline__ void enc_s1_body(const EncS1P& P, const float* __rest
       int R = i * 16 + m;
       return ((2 * (R / S1) + tap) * S1 + (R & (S1 - 1))) * CS1 + g * 64 + c16 * 16 + q * 4;
     };
-    gemm_f32_bias<MTW, NTW, 16, 16>(XB, aoff, P.down.w + nt0 * 16 * 64, P.down.b, nt0 * 16, acc);
+    constexpr bool SW = LYRA_SWAP128 != 0;   // operand-swapped (lyra_dev.h): one 16-byte store per C tile
+    gemm_f32_bias<MTW, NTW, 16, 16, gemm_pf<MTW, NTW>(), SW>(XB, aoff, P.down.w + nt0 * 16 * 64, P.down.b, nt0 * 16, acc);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      int n = (nt0 + j) * 16 + (lane & 15);
-      int pc = at16(n);
+      if constexpr (SW) {
 #pragma unroll
-      for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int R = i * 16 + q * 4 + e, tau = R / S1, s = R & (S1 - 1);
-          if (valid(s)) *goff<float>(out1 + (size_t)b0 * 512, (uint32_t)(((s * 2 + tau) * 256 + pc) * 4)) = acc[i][j][e];
+        for (int i = 0; i < MTW; ++i) {
+          const int R = i * 16 + m, tau = R / S1, s = R & (S1 - 1);
+          if (valid(s))
+            *goff<f32x4>(out1 + (size_t)b0 * 512, (uint32_t)(((s * 2 + tau) * 256 + (nt0 + j) * 16 + q * 4) * 4)) = acc[i][j];
         }
+      } else {
+        int n = (nt0 + j) * 16 + (lane & 15);
+        int pc = at16(n);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int R = i * 16 + q * 4 + e, tau = R / S1, s = R & (S1 - 1);
+            if (valid(s)) *goff<float>(out1 + (size_t)b0 * 512, (uint32_t)(((s * 2 + tau) * 256 + pc) * 4)) = acc[i][j][e];
+          }
+      }
     }
   }
   LYRA_TSTAMP(73);

@@ -316,7 +316,31 @@ __device__ __forceinline__ void wg_schedule_hint() {
 template <int NTW, int PF>
 struct WPre { f32x4 b[PF][NTW]; f32x4 init[NTW]; };
 
-template <int NTW, int KC, int KS, int PF>
+// SWAP (round 6, the 64-channel stages): the weight fragment is the MFMA's A operand and the activation fragment its B
+// operand -- both have the same per-lane shape, so the LDS reads and the packed fragments stay as they are -- which
+// transposes the C tile: lane l holds OUTPUT CHANNELS 4 * (l >> 4) + e (e = 0..3) of N tile j for activation row l & 15
+// of M tile i.  With the weight columns of a tile packed in AT16 order (model.hip: MFMA row r carries the logical channel
+// whose physical position is r) those four channels are four CONSECUTIVE floats of the row: an epilogue is one
+// ds_write_b128 / global dwordx4 store per C tile instead of four scalar stores to rows 4 apart (two of which always
+// shared an LDS bank at a row stride of 72 floats), the stage input of dec_s2 one dwordx4 load instead of four dword
+// loads.  Each output element is still bias, then fma over ascending k: the products commute, the chain does not change.
+// The bias comes as the lane's four channels (AT16-ordered array, one 16-byte load).
+#ifndef LYRA_SWAP64
+#define LYRA_SWAP64 1
+#endif
+// Measured, alternating on one box (profiles/r06_ab_swap64.txt, r06_ab_swap128.txt): the 64-channel stages swapped
+// 14.08 -> 14.13 M frames/s in the driver form and 14.43 -> 14.51 M sustained (static vector instructions of enc_s0 735 ->
+// 636, LDS instructions 180 -> 159); the 128-channel stages swapped as well LOSE 0.3 % again (their X update becomes a
+// 16-byte read-modify-write per C tile, and dec_s1 is at the register cap): -DLYRA_SWAP128=1 builds that, the default is off.
+#ifndef LYRA_SWAP128   // ... and the residual blocks + strided conv of the 128-channel stages
+#define LYRA_SWAP128 0
+#endif
+// this lane's four bias values of the N tile whose first channel is n0 (bias array in AT16 order)
+__device__ __forceinline__ f32x4 bias_quad(const float* bias, int n0) {
+  return *reinterpret_cast<const f32x4 LYRA_GLOBAL*>(as_global(bias) + n0 + (((threadIdx.x & 63) >> 4) << 2));
+}
+
+template <int NTW, int KC, int KS, int PF, bool SWAP = false>
 __device__ __forceinline__ WPre<NTW, PF> gemm_f32_wprefetch(const f32x4* bfrag_generic, const float* bias, int n0) {
   const int lane = threadIdx.x & 63;
   const f32x4 LYRA_GLOBAL* bbase = wave_uniform(bfrag_generic);
@@ -325,16 +349,21 @@ __device__ __forceinline__ WPre<NTW, PF> gemm_f32_wprefetch(const f32x4* bfrag_g
   for (int p = 0; p < PF; ++p)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) pre.b[p][j] = bbase[(j * KS + LYRA_WCHUNK(p < KC ? p : 0)) * 64 + lane];
-  const float LYRA_GLOBAL* b = as_global(bias) + n0 + (threadIdx.x & 15);
+  if constexpr (SWAP) {
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const float v = b[j * 16];
-    pre.init[j] = (f32x4){v, v, v, v};
+    for (int j = 0; j < NTW; ++j) pre.init[j] = bias_quad(bias, n0 + j * 16);
+  } else {
+    const float LYRA_GLOBAL* b = as_global(bias) + n0 + (threadIdx.x & 15);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const float v = b[j * 16];
+      pre.init[j] = (f32x4){v, v, v, v};
+    }
   }
   return pre;
 }
 
-template <int MTW, int NTW, int KC, int KS, int INIT, int PF, class AOff>
+template <int MTW, int NTW, int KC, int KS, int INIT, int PF, bool SWAP = false, class AOff>
 __device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                               f32x4 (&acc)[MTW][NTW], const f32x4 (&init)[NTW],
                                               const f32x4 (*pre_b)[NTW] = nullptr) {
@@ -376,7 +405,8 @@ __device__ __forceinline__ void gemm_f32_core(const float* lds, AOff a_off, cons
         for (int j = 0; j < NTW; ++j) {
           const bool first = c == 0 && kk == 0;
           const f32x4 cin = (first && INIT == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : (first && INIT == 2) ? acc[MTW - 1][j] : acc[i][j];
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], cin, 0, 0, 0);
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cur][j][kk], aq[cur][i][kk], cin, 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cur][i][kk], bq[cur][j][kk], cin, 0, 0, 0);
         }
     LYRA_MFMA_END();
   }
@@ -393,35 +423,40 @@ __device__ __forceinline__ void gemm_f32(const float* lds, AOff a_off, const f32
 // The chains start from the bias (logical channel order; n0 = first output channel of the wave's first N tile):
 // C layout col = lane & 15, so one value per N tile fills a lane's four rows.
 template <int MTW, int NTW, int KC, int KS = KC,
-          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), bool SWAP = false, class AOff>
 __device__ __forceinline__ void gemm_f32_bias(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                               const float* bias, int n0, f32x4 (&acc)[MTW][NTW]) {
-  const float LYRA_GLOBAL* b = as_global(bias) + n0 + (threadIdx.x & 15);
   f32x4 init[NTW];
+  if constexpr (SWAP) {
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const float v = b[j * 16];
-    init[j] = (f32x4){v, v, v, v};
+    for (int j = 0; j < NTW; ++j) init[j] = bias_quad(bias, n0 + j * 16);
+  } else {
+    const float LYRA_GLOBAL* b = as_global(bias) + n0 + (threadIdx.x & 15);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const float v = b[j * 16];
+      init[j] = (f32x4){v, v, v, v};
+    }
   }
-  gemm_f32_core<MTW, NTW, KC, KS, 2, PF>(lds, a_off, bfrag_generic, acc, init);
+  gemm_f32_core<MTW, NTW, KC, KS, 2, PF, SWAP>(lds, a_off, bfrag_generic, acc, init);
 }
 
 // ... with the first weight chunks and the bias splats requested earlier (gemm_f32_wprefetch with the same NTW, KC, KS, PF)
 template <int MTW, int NTW, int KC, int KS = KC,
-          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), bool SWAP = false, class AOff>
 __device__ __forceinline__ void gemm_f32_pre(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                              const WPre<NTW, PF>& pre, f32x4 (&acc)[MTW][NTW]) {
-  gemm_f32_core<MTW, NTW, KC, KS, 2, PF>(lds, a_off, bfrag_generic, acc, pre.init, pre.b);
+  gemm_f32_core<MTW, NTW, KC, KS, 2, PF, SWAP>(lds, a_off, bfrag_generic, acc, pre.init, pre.b);
 }
 template <int MTW, int NTW>
 constexpr int gemm_pf() { return 4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3); }
 
 // ... from splats the caller already holds
 template <int MTW, int NTW, int KC, int KS = KC,
-          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), class AOff>
+          int PF = (4 * MTW * NTW >= 16 ? 1 : (4 * MTW * NTW >= 8 ? 2 : 3)), bool SWAP = false, class AOff>
 __device__ __forceinline__ void gemm_f32_init(const float* lds, AOff a_off, const f32x4* bfrag_generic,
                                               const f32x4 (&init)[NTW], f32x4 (&acc)[MTW][NTW]) {
-  gemm_f32_core<MTW, NTW, KC, KS, 2, PF>(lds, a_off, bfrag_generic, acc, init);
+  gemm_f32_core<MTW, NTW, KC, KS, 2, PF, SWAP>(lds, a_off, bfrag_generic, acc, init);
 }
 
 template <int MTW, int NTW, int KC, class AOff>

@@ -175,7 +175,10 @@ struct Builder {
 
   // ---- fp32 conv [cout][k][cig] -> B fragments [cout/16][K/16][64 lanes][4] --------------------
   // Every loader names the shape the kernels are specialised to; Pack::get refuses anything else.
-  void conv_f(const char* pre, int idx, ConvF* out, uint32_t cout, uint32_t k, uint32_t cig) {
+  // at16_cols (the operand-swapped layers of the 64-channel stages, lyra_dev.h SWAP): column c of a 16-wide N tile carries
+  // the logical output channel at16(c), and the bias array is in AT16 order -- MFMA output row r of the transposed C tile
+  // then IS physical position r of the row, so a lane's four values are four consecutive floats.
+  void conv_f(const char* pre, int idx, ConvF* out, uint32_t cout, uint32_t k, uint32_t cig, bool at16_cols = false) {
     const float* w = pk.f32(key(pre, "conv", idx, "w"), {cout, k, cig});
     const float* b = pk.f32(key(pre, "conv", idx, "b"), {cout});
     if (!w || !b) return;
@@ -186,12 +189,15 @@ struct Builder {
         for (int lane = 0; lane < 64; ++lane)
           for (int kk = 0; kk < 4; ++kk) {
             int kidx = c * 16 + kk * 4 + (lane >> 4);
-            int n = nt * 16 + (lane & 15);
+            int n = nt * 16 + (at16_cols ? at16(lane & 15) : (lane & 15));
             int tap = kidx / cig, ci = kidx % cig;
             frag[(((size_t)nt * KC + c) * 64 + lane) * 4 + kk] = w[((size_t)n * k + tap) * cig + ci];
           }
     put(&out->w, frag);
-    put(&out->b, std::vector<float>(b, b + cout));
+    std::vector<float> bp(b, b + cout);
+    if (at16_cols)
+      for (uint32_t c = 0; c < cout; ++c) bp[at16((int)c)] = b[c];
+    put(&out->b, bp);
   }
 
   // ---- fp32 transposed conv [cout][k][cin], stride s -> polyphase B fragments ---------------------
@@ -422,22 +428,24 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   // pass over [warm.base, warm.base + warm.bytes) (l2_warm in lyra_dev.h).
   // ---- encoder (op numbering: tools/pack_weights.py) ----------------------------------
   size_t mark = B.mark();
-  B.conv_f("enc", 0, &M->enc0.first, 64, 64, 1);
+  constexpr bool SW64 = LYRA_SWAP64 != 0;   // the 64-channel stages' GEMMs run operand-swapped (lyra_dev.h)
+  constexpr bool SW128 = LYRA_SWAP128 != 0; // ... and the residual blocks / strided conv of the 128-channel stages
+  B.conv_f("enc", 0, &M->enc0.first, 64, 64, 1, SW64);
   for (int r = 0; r < 3; ++r) {
     B.dw_f("enc", r, &M->enc0.dw[r], 64);
-    B.conv_f("enc", 1 + 2 * r, &M->enc0.pw[r], 64, 1, 64);
-    B.conv_f("enc", 2 + 2 * r, &M->enc0.cv[r], 64, 1, 64);
+    B.conv_f("enc", 1 + 2 * r, &M->enc0.pw[r], 64, 1, 64, SW64);
+    B.conv_f("enc", 2 + 2 * r, &M->enc0.cv[r], 64, 1, 64, SW64);
   }
-  B.conv_f("enc", 7, &M->enc0.down, 128, 10, 64);
+  B.conv_f("enc", 7, &M->enc0.down, 128, 10, 64, SW64);
   const size_t p_enc0 = B.arena.reserve(sizeof(EncS0P));   // the kernel's parameter block rides in its warm range
   B.range(&M->enc0.warm, mark);
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
     B.dw_f("enc", 3 + r, &M->enc1.dw[r], 128);
-    B.conv_f("enc", 8 + 2 * r, &M->enc1.pw[r], 128, 1, 128);
-    B.conv_f("enc", 9 + 2 * r, &M->enc1.cv[r], 128, 1, 64);
+    B.conv_f("enc", 8 + 2 * r, &M->enc1.pw[r], 128, 1, 128, SW128);
+    B.conv_f("enc", 9 + 2 * r, &M->enc1.cv[r], 128, 1, 64, SW128);
   }
-  B.conv_f("enc", 14, &M->enc1.down, 256, 4, 64);
+  B.conv_f("enc", 14, &M->enc1.down, 256, 4, 64, SW128);
   const size_t p_enc1 = B.arena.reserve(sizeof(EncS1P));
   B.range(&M->enc1.warm, mark);
   mark = B.mark();
@@ -491,8 +499,8 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
     B.dw_f("dec", 3 + r, &M->dec1.dw[r], 128);
-    B.conv_f("dec", 7 + 2 * r, &M->dec1.pw[r], 128, 1, 128);
-    B.conv_f("dec", 8 + 2 * r, &M->dec1.cv[r], 128, 1, 64);
+    B.conv_f("dec", 7 + 2 * r, &M->dec1.pw[r], 128, 1, 128, SW128);
+    B.conv_f("dec", 8 + 2 * r, &M->dec1.cv[r], 128, 1, 64, SW128);
   }
   B.tconv_f("dec", 6, &M->dec1.up, 64, 10, 128, 5);
   {
@@ -504,8 +512,8 @@ bool build_model(const Pack& pk, int requant_mode, Model* M, std::string* err) {
   mark = B.mark();
   for (int r = 0; r < 3; ++r) {
     B.dw_f("dec", 6 + r, &M->dec2.dw[r], 64);
-    B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r], 64, 1, 64);
-    B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r], 64, 1, 64);
+    B.conv_f("dec", 13 + 2 * r, &M->dec2.pw[r], 64, 1, 64, SW64);
+    B.conv_f("dec", 14 + 2 * r, &M->dec2.cv[r], 64, 1, 64, SW64);
   }
   B.tconv_f("dec", 7, &M->dec2.up, 1, 64, 64, 16);
   {

@@ -68,10 +68,13 @@ __device__ __forceinline__ void state_touch_sink(uint32_t tok, uint8_t* state, i
 // takes < 30 KB and four workgroups fit on a CU -- the whole B = 4096 batch is resident in one wave of workgroups.
 // The depthwise conv runs on (row, channel quad) items with 16-byte LDS / history accesses; the residual add is a
 // register add.
+// LYRA_SWAP64 (round 6): the GEMMs run operand-swapped (lyra_dev.h gemm_f32_core SWAP) -- xr[i][0][e] =
+// X[row (wm*5+i)*16 + (lane&15)][physical channel wn*16 + 4q + e], and every epilogue is one 16-byte LDS store per C tile.
 template <int S, int NT>
 __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const TileCtx& cx, const DwF* dws,
                                              const ConvF* pws, const ConvF* cvs, int off0, int off1, int off2) {
   constexpr int CS = 72;
+  constexpr bool SW = LYRA_SWAP64 != 0;
   static_assert(20 * S / 16 == 5 * (NT / 256), "5 M tiles per wave");
 #pragma unroll 1
   for (int r = 0; r < 3; ++r) {
@@ -117,8 +120,12 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     for (int i = 0; i < 5; ++i)
 {
       const f32x4 a4 = lrelu4(xr[i][0]);
+      if constexpr (SW) {
+        *reinterpret_cast<f32x4*>(&A[((wm * 5 + i) * 16 + m) * CS + wn * 16 + q * 4]) = a4;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = a4[e];
+        for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = a4[e];
+      }
     }
     __syncthreads();
     LYRA_TSTAMP(10 + r * 8 + 1);
@@ -166,26 +173,30 @@ __device__ __forceinline__ void resblocks64r(f32x4 (&xr)[5][1], float* A, const 
     WPre<1, 1> cv_pre;
     {  // 4. pointwise 64 -> 64, LeakyReLU -> A
       f32x4 acc[5][1];
-      gemm_f32_bias<5, 1, 4, 4>(A, aoff, pws[r].w + wn * 4 * 64, pws[r].b, wn * 16, acc);
+      gemm_f32_bias<5, 1, 4, 4, gemm_pf<5, 1>(), SW>(A, aoff, pws[r].w + wn * 4 * 64, pws[r].b, wn * 16, acc);
       LYRA_TSTAMP(10 + r * 8 + 5);
       // the 1x1 conv's bias + first weight chunk, requested ahead of the barrier in front of it (see resblocks128; round 5:
       // +1.0 % on the whole step, +2.1 % at 1,024 streams).  The pointwise GEMM's own request stays behind its barrier: held
       // across the depthwise phase it costs spills at the 128-VGPR cap.
-      cv_pre = gemm_f32_wprefetch<1, 4, 4, 1>(cvs[r].w + wn * 4 * 64, cvs[r].b, wn * 16);
+      cv_pre = gemm_f32_wprefetch<1, 4, 4, 1, SW>(cvs[r].w + wn * 4 * 64, cvs[r].b, wn * 16);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 5; ++i)
 {
         const f32x4 a4 = lrelu4(acc[i][0]);
+        if constexpr (SW) {
+          *reinterpret_cast<f32x4*>(&A[((wm * 5 + i) * 16 + m) * CS + wn * 16 + q * 4]) = a4;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = a4[e];
+          for (int e = 0; e < 4; ++e) A[((wm * 5 + i) * 16 + q * 4 + e) * CS + pcol] = a4[e];
+        }
       }
       __syncthreads();
       LYRA_TSTAMP(10 + r * 8 + 6);
     }
     {  // 5. 1x1 conv 64 -> 64 + residual (registers)
       f32x4 acc[5][1];
-      gemm_f32_pre<5, 1, 4, 4>(A, aoff, cvs[r].w + wn * 4 * 64, cv_pre, acc);
+      gemm_f32_pre<5, 1, 4, 4, gemm_pf<5, 1>(), SW>(A, aoff, cvs[r].w + wn * 4 * 64, cv_pre, acc);
 #pragma unroll
       for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -239,6 +250,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
                                              Hist128<1024 / NT> H) {
   static_assert(S == 8 && (NT == 256 || NT == 512), "thread <-> (stream, channel quad, row half) mapping");
   constexpr int CS = 136, NTW = 8 / (NT / 64), MT = 2, RPT = 1024 / NT;
+  constexpr bool SW = LYRA_SWAP128 != 0;   // operand-swapped GEMMs (lyra_dev.h): 16-byte epilogue accesses
 #pragma unroll 1
   for (int r = 0; r < 3; ++r) {
     int tid = threadIdx.x;
@@ -289,15 +301,15 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
     // The first weight chunks + bias of each GEMM are requested ahead of the barrier / elementwise phase in front of it
     // (gemm_f32_wprefetch): the L2 round trip no longer stands between the barrier and the first MFMA.  Round 5: +1.2 % on
     // the whole step at 4,096 streams (enc_s1 -1.1 us, dec_s1 -2.2 us); the same in the 64-channel blocks costs spills.
-    const auto pw_pre = gemm_f32_wprefetch<NTW, 8, 8, gemm_pf<MT, NTW>()>(pws[r].w + (wave * NTW) * 8 * 64, pws[r].b, wave * NTW * 16);
+    const auto pw_pre = gemm_f32_wprefetch<NTW, 8, 8, gemm_pf<MT, NTW>(), SW>(pws[r].w + (wave * NTW) * 8 * 64, pws[r].b, wave * NTW * 16);
     WPre<NTW, gemm_pf<MT, NTW>()> cv_pre;
     __syncthreads();
     LYRA_TSTAMP(40 + r * 8 + 2);
     {  // pointwise 128 -> 128, LeakyReLU
       f32x4 acc[MT][NTW];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + c * 16 + q * 4; };
-      gemm_f32_pre<MT, NTW, 8, 8>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, pw_pre, acc);
-      cv_pre = gemm_f32_wprefetch<NTW, 4, 4, gemm_pf<MT, NTW>()>(cvs[r].w + (wave * NTW) * 4 * 64, cvs[r].b, wave * NTW * 16);
+      gemm_f32_pre<MT, NTW, 8, 8, gemm_pf<MT, NTW>(), SW>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, pw_pre, acc);
+      cv_pre = gemm_f32_wprefetch<NTW, 4, 4, gemm_pf<MT, NTW>(), SW>(cvs[r].w + (wave * NTW) * 4 * 64, cvs[r].b, wave * NTW * 16);
       LYRA_TSTAMP(40 + r * 8 + 3);
       // The next block's history rows.  vmcnt retires in order, so these loads would stall the first weight
       // fetch of a GEMM issued right after them; here they have the two barriers and the LDS-only P write
@@ -311,8 +323,12 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
         for (int i = 0; i < MT; ++i)
 {
           const f32x4 a4 = lrelu4(acc[i][j]);
+          if constexpr (SW) {
+            *reinterpret_cast<f32x4*>(&P[(i * 16 + m) * CS + (wave * NTW + j) * 16 + q * 4]) = a4;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) P[(i * 16 + q * 4 + e) * CS + pcol] = a4[e];
+            for (int e = 0; e < 4; ++e) P[(i * 16 + q * 4 + e) * CS + pcol] = a4[e];
+          }
         }
       }
       __syncthreads();
@@ -322,19 +338,29 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
       f32x4 acc[MT][NTW];
       const int g = (wave * NTW) >> 2;
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + g * 64 + c * 16 + q * 4; };
-      gemm_f32_pre<MT, NTW, 4, 4>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, cv_pre, acc);
+      gemm_f32_pre<MT, NTW, 4, 4, gemm_pf<MT, NTW>(), SW>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, cv_pre, acc);
       LYRA_TSTAMP(40 + r * 8 + 5);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int ncol = (wave * NTW + j) * 16 + (lane & 15);
         const int pcol = at16(ncol);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
+          if constexpr (SW) {
+            f32x4* x = reinterpret_cast<f32x4*>(&X[(i * 16 + m) * CS + (wave * NTW + j) * 16 + q * 4]);
+            const f32x4 old = *x;
+            f32x4 sum;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float* x = &X[(i * 16 + q * 4 + e) * CS + pcol];
-            *x = acc[i][j][e] + *x;
+            for (int e = 0; e < 4; ++e) sum[e] = acc[i][j][e] + old[e];
+            *x = sum;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float* x = &X[(i * 16 + q * 4 + e) * CS + pcol];
+              *x = acc[i][j][e] + *x;
+            }
           }
+        }
       }
     }
     __syncthreads();
