@@ -329,6 +329,29 @@ int lyra_hip_twin_noise(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B);
  * out [num_streams][num_internal_samples * out_rate / 16000]; synchronises.  num_internal_samples == 0 just synchronises. */
 int lyra_hip_twin_fetch(lyra_hip_ctx* ctx, int num_streams, int num_internal_samples, int out_rate, int16_t* out);
 
+/* ---- Pipelined host-buffer calls (round 6) ----------------------------------------------------------------------------
+ * Two-deep pipelined forms of the blocking host-buffer calls above, for a caller that feeds hop after hop: begin() stages
+ * the caller's data in pinned memory, uploads it on a copy stream of its own, enqueues the kernels and the download and
+ * returns; end() waits for the OLDEST begun call and copies its result out.  At most two calls may be in flight; with
+ * begin(n + 1) issued before end(n) the upload of hop n + 1 and the download of hop n run under the kernels (blocking
+ * calls idle the chain for both: BatchLyraEncoder + BatchLyraDecoder on two host threads 7.8-8.3 M frames/s, pipelined:
+ * DESIGN.md 5).  The caller's buffers may be reused as soon as begin() / end() returns.  Results are bit-identical to the
+ * blocking calls.  Do not mix blocking and pipelined calls of one kind on one context while calls are in flight.
+ *
+ * lyra_hip_encode_begin: LyraEncoder::Encode for B streams (lyra/lyra_encoder.cc:113-156) -- pcm [B][sample_rate_hz / 50]
+ *   at 8 / 16 / 32 / 48 kHz (the encoder's own resampler runs on the device, :119-122), dtx != 0 as lyra_hip_encode_dtx
+ *   (call lyra_hip_set_encoder_sample_rate(sample_rate_hz) first).
+ * lyra_hip_encode_end: packets [B][num_bits / 8 rounded up]; packet_bytes [B] may be NULL (required to tell DTX's empty
+ *   packets apart). */
+int lyra_hip_encode_begin(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, int sample_rate_hz,
+                          int num_bits, int dtx);
+int lyra_hip_encode_end(lyra_hip_ctx* ctx, uint8_t* packets, int32_t* packet_bytes);
+/* lyra_hip_twin_fetch in two halves ("Decoder twin" above): begin() ends the request being assembled -- its resampling and
+ * its download are enqueued, the NEXT request's twin calls may follow at once --, end() waits for the oldest begun request
+ * and copies its rows out (out may be NULL when that request had num_internal_samples == 0). */
+int lyra_hip_twin_fetch_begin(lyra_hip_ctx* ctx, int num_streams, int num_internal_samples, int out_rate);
+int lyra_hip_twin_fetch_end(lyra_hip_ctx* ctx, int16_t* out);
+
 /* The context's FOUR HIP streams (hipStream_t as void*), for event timing / ordering by the caller: encode side, decode
  * side, the quantizer stream of lyra_hip_encode_dev / lyra_hip_encode_dtx_dev, and the noise stream.
  *  - The packets of the two encode calls are written on the QUANTIZER stream: lyra_hip_stream() does not cover them (it

@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <condition_variable>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -122,6 +124,7 @@ struct lyra_hip_ctx {
   bool zc(int B) const { return h_zc && B <= ZC_MAX; }
   uint8_t* d_twin_args = nullptr;
   size_t twin_args_cap = 0, twin_args_used = 0;
+  void* pipe = nullptr;            // PipeState (pipe_api.inc): the two-deep pipelined host-buffer calls, created on first use
   size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
   int tile_div[6] = {1, 1, 1, 1, 1, 1};   // tiles per workgroup of each stage kernel (LYRA_TILE_LOOP), see tile_div()
   bool chunk_local = false;                       // see wait_encode_side
@@ -163,7 +166,9 @@ int fail(lyra_hip_ctx* c, int code, const char* fmt, ...) {
 template <class T>
 hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
 
+int pipe_sync(lyra_hip_ctx* c);   // the copy streams of the pipelined host-buffer calls (pipe_api.inc)
 int sync_all(lyra_hip_ctx* c) {
+  { int rc = pipe_sync(c); if (rc) return rc; }
   for (int k = 0; k < lyra_hip_ctx::KMAX; ++k) {
     if (c->se[k]) HIPCHK(c, hipStreamSynchronize(c->se[k]));
     if (c->sd[k]) HIPCHK(c, hipStreamSynchronize(c->sd[k]));
@@ -174,6 +179,7 @@ int sync_all(lyra_hip_ctx* c) {
 }
 
 void twin_free(lyra_hip_ctx* c);
+void pipe_free(lyra_hip_ctx* c);
 void free_scratch(lyra_hip_ctx* c) {
   void* ps[] = {c->d_ids, c->d_ids_dec, c->d_pcm_in, c->d_e0, c->d_e1, c->d_feat, c->d_feat2, c->d_codes, c->d_idx, c->d_pkt,
                 c->d_lossy, c->d_d0, c->d_d1, c->d_pcm_out, c->d_mel, c->d_mel_enc, c->d_flag_enc, c->d_flag_dec,
@@ -819,6 +825,16 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
       (c->nsub > 1 && [&] { for (int k = 0; k < c->nsub; ++k) if (hipEventCreateWithFlags(&c->ev_se_last[k], evflags) != hipSuccess) return true; return false; }()) ||
       hipEventCreateWithFlags(&c->ev_ahead_last, evflags) != hipSuccess)
     return bail(LYRA_HIP_EHIP, "hipStreamCreate failed");
+  // A process's streams share a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and a stream gets its queue
+  // when it is first used: touched here in a fixed order, the context's four streams land on four DIFFERENT queues
+  // whatever order the caller uses them in later (round 6: with the queues handed out in order of first use the pipelined
+  // encode ran at 16.8 or at 11.9 M frames/s depending on which calls the process had made before).
+  {
+    hipStream_t order[4] = {c->se[0], c->sd[0], c->sq[0], c->sn};
+    for (hipStream_t s : order)
+      if (hipEventRecord(c->ev_ahead_last, s) != hipSuccess) return bail(LYRA_HIP_EHIP, "hipEventRecord failed");
+    if (hipEventSynchronize(c->ev_ahead_last) != hipSuccess) return bail(LYRA_HIP_EHIP, "hipEventSynchronize failed");
+  }
   if (hipMalloc((void**)&c->d_state, (size_t)max_streams * st::BYTES) != hipSuccess)
     return bail(LYRA_HIP_ENOMEM, "hipMalloc(state) failed");
   if (hipMalloc((void**)&c->d_rvq_stats, 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->d_rvq_stats, 0, 4 * sizeof(unsigned)) != hipSuccess)
@@ -886,6 +902,7 @@ void lyra_hip_destroy(lyra_hip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)sync_all(c);
   twin_free(c);
+  pipe_free(c);
   if (c->h_zc) (void)hipHostFree(c->h_zc);
   c->h_zc = nullptr;
   free_scratch(c);
@@ -1788,4 +1805,5 @@ long lyra_hip_debug_read(lyra_hip_ctx* c, int which, float* host_out, long capac
 
 }  // extern "C"
 
+#include "pipe_api.inc"
 #include "twin_api.inc"

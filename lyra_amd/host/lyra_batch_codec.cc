@@ -92,7 +92,15 @@ std::unique_ptr<BatchLyraEncoder> BatchLyraEncoder::Create(int sample_rate_hz, i
 
 BatchLyraEncoder::~BatchLyraEncoder() { lyra_hip_destroy(ctx_); }
 
+// The blocking form: upload, kernels and download on the extractor's own stream, one synchronise (lyra_hip_encode).  It
+// shares no stream with anything, which matters when a BatchLyraDecoder runs beside it on another host thread: the
+// pipelined halves below use a second and a third stream of the context (quantizer, upload), and a process's streams
+// share a handful of hardware queues.
 std::optional<std::vector<uint8_t>> BatchLyraEncoder::Encode(const absl::Span<const int16_t> audio) {
+  if (!in_flight_.empty()) {
+    LOG(ERROR) << "Encode() while " << in_flight_.size() << " EncodeAsync() hops are in flight: call WaitEncoded() first.";
+    return std::nullopt;
+  }
   const int hop_external = sample_rate_hz_ / kBatchFrameRate;
   const size_t expected = static_cast<size_t>(num_streams_) * hop_external;
   if (audio.size() != expected) {
@@ -121,6 +129,47 @@ std::optional<std::vector<uint8_t>> BatchLyraEncoder::Encode(const absl::Span<co
     std::fill(lengths_.begin(), lengths_.end(), packet_size());
   }
   if (rc != 0) {
+    LOG(ERROR) << "Unable to extract and quantize features from audio: " << lyra_hip_last_error(ctx_);
+    return std::nullopt;
+  }
+  return packets;
+}
+
+bool BatchLyraEncoder::EncodeAsync(const absl::Span<const int16_t> audio) {
+  const int hop_external = sample_rate_hz_ / kBatchFrameRate;
+  const size_t expected = static_cast<size_t>(num_streams_) * hop_external;
+  if (audio.size() != expected) {
+    LOG(ERROR) << "The number of audio samples has to be exactly " << expected << " (" << num_streams_
+               << " streams x " << hop_external << "), but is " << audio.size() << ".";
+    return false;
+  }
+  if (in_flight_.size() >= 2) {
+    LOG(ERROR) << "Two hops are already in flight: call WaitEncoded() first.";
+    return false;
+  }
+  const int bits = BatchBitrateToNumQuantizedBits(bitrate_);
+  // lyra_encoder.cc:119-156 on the device: the encoder's own resampler (external rate -> 16 kHz), with DTX the noise
+  // decision (:131-141; the estimator's time constants follow the EXTERNAL rate, :82-85), extract, quantize, pack
+  int rc = enable_dtx_ ? lyra_hip_set_encoder_sample_rate(ctx_, sample_rate_hz_) : 0;
+  if (rc == 0)
+    rc = lyra_hip_encode_begin(ctx_, ids_.data(), num_streams_, audio.data(), sample_rate_hz_, bits, enable_dtx_ ? 1 : 0);
+  if (rc != 0) {
+    LOG(ERROR) << "Unable to extract and quantize features from audio: " << lyra_hip_last_error(ctx_);
+    return false;
+  }
+  in_flight_.push_back(packet_size());
+  return true;
+}
+
+std::optional<std::vector<uint8_t>> BatchLyraEncoder::WaitEncoded() {
+  if (in_flight_.empty()) {
+    LOG(ERROR) << "WaitEncoded() without a hop in flight.";
+    return std::nullopt;
+  }
+  const int ps = in_flight_.front();
+  in_flight_.erase(in_flight_.begin());
+  std::vector<uint8_t> packets(static_cast<size_t>(num_streams_) * ps);
+  if (lyra_hip_encode_end(ctx_, packets.data(), lengths_.data()) != 0) {
     LOG(ERROR) << "Unable to extract and quantize features from audio: " << lyra_hip_last_error(ctx_);
     return std::nullopt;
   }
@@ -241,6 +290,10 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
   }
   // BufferedResampler::FilterAndBuffer (buffered_resampler.cc:63-147); all streams are asked for the same number of
   // samples every time, so their leftover buffers have the same length.  At 16 kHz there is no resampler and no buffer.
+  if (!pending_.empty()) {
+    LOG(ERROR) << "DecodeSamples() while " << pending_.size() << " DecodeSamplesAsync() requests are in flight: call WaitDecoded() first.";
+    return false;
+  }
   const bool resampling = sample_rate_hz_ != kBatchInternalSampleRateHz;
   const int leftover = resampling ? static_cast<int>(leftover_[0].size()) : 0;
   const int used = std::min(leftover, num_samples);
@@ -275,6 +328,7 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
     failed_ = true;   // the request's samples are lost and the streams have moved on
     return false;
   }
+  if (resampling) leftover_count_ = leftover - used + (produced - (num_samples - used));
   if (direct) return true;
   const int to_copy = num_samples - used;
   for (int s = 0; s < num_streams_; ++s) {
@@ -285,6 +339,92 @@ bool BatchLyraDecoder::DecodeSamples(int num_samples, absl::Span<int16_t> out) {
       const int16_t* e = &external_[static_cast<size_t>(s) * produced];
       std::copy(e, e + to_copy, o + used);
       leftover_[s].insert(leftover_[s].end(), e + to_copy, e + produced);
+    }
+  }
+  return true;
+}
+
+bool BatchLyraDecoder::DecodeSamplesAsync(int num_samples) {
+  if (num_samples < 0) {
+    LOG(ERROR) << "Number of samples has to be non-negative.";
+    return false;
+  }
+  if (failed_) {
+    LOG(ERROR) << "This decoder failed in the middle of a request; its streams are out of step with the device. Create a new one.";
+    return false;
+  }
+  if (pending_.size() >= 2) {
+    LOG(ERROR) << "Two requests are already in flight: call WaitDecoded() first.";
+    return false;
+  }
+  // BufferedResampler::FilterAndBuffer (buffered_resampler.cc:63-147); all streams are asked for the same number of
+  // samples every time, so their leftover buffers have the same length -- which is all that is needed here: the COUNT of
+  // leftovers after every request begun is known before its samples exist.  At 16 kHz there is no resampler and no buffer.
+  const bool resampling = sample_rate_hz_ != kBatchInternalSampleRateHz;
+  const int leftover = resampling ? leftover_count_ : 0;
+  const int used = std::min(leftover, num_samples);
+  int internal = num_samples;
+  if (resampling) {
+    internal = 0;
+    if (num_samples > leftover) {
+      const float ratio = static_cast<float>(sample_rate_hz_) / static_cast<float>(kBatchInternalSampleRateHz);
+      internal = static_cast<int>(std::ceil(static_cast<float>(num_samples - leftover) / ratio));
+    }
+  }
+  if (!EnqueueInternal(internal)) {
+    (void)lyra_hip_twin_fetch(ctx_, num_streams_, 0, sample_rate_hz_, nullptr);   // abandon the half-assembled request
+    // EnqueueInternal does a stream's bookkeeping (packet consumed, fade / concealment progress) in the pass that gathers
+    // the device calls' arguments: after a failed round the host state of the streams handled so far has advanced while
+    // the device never ran that round.  The reference's LyraDecoder has no such window (one stream, one call); here the
+    // decoder refuses every further call instead of decoding from a state that no longer matches the device.
+    failed_ = true;
+    return false;
+  }
+  const int produced = resampling ? static_cast<int>(static_cast<long>(internal) * sample_rate_hz_ / kBatchInternalSampleRateHz)
+                                  : internal;
+  if (lyra_hip_twin_fetch_begin(ctx_, num_streams_, internal, sample_rate_hz_) != 0) {
+    LOG(ERROR) << "Could not decode samples: " << lyra_hip_last_error(ctx_);
+    failed_ = true;   // the request's samples are lost and the streams have moved on
+    return false;
+  }
+  pending_.push_back(Pending{num_samples, used, produced});
+  if (resampling) leftover_count_ = leftover - used + (produced - (num_samples - used));
+  return true;
+}
+
+bool BatchLyraDecoder::WaitDecoded(absl::Span<int16_t> out) {
+  if (pending_.empty()) {
+    LOG(ERROR) << "WaitDecoded() without a request in flight.";
+    return false;
+  }
+  const Pending rq = pending_.front();
+  if (out.size() != static_cast<size_t>(num_streams_) * rq.num_samples) {
+    LOG(ERROR) << "Output span has " << out.size() << " samples, expected " << static_cast<size_t>(num_streams_) * rq.num_samples;
+    return false;   // (the request stays in flight)
+  }
+  pending_.erase(pending_.begin());
+  // nothing to splice: the device result IS the answer
+  const bool direct = rq.used == 0 && rq.produced == rq.num_samples;
+  int16_t* dst = out.data();
+  if (!direct) {
+    external_.resize(static_cast<size_t>(num_streams_) * rq.produced);
+    dst = external_.data();
+  }
+  if (lyra_hip_twin_fetch_end(ctx_, dst) != 0) {
+    LOG(ERROR) << "Could not decode samples: " << lyra_hip_last_error(ctx_);
+    failed_ = true;
+    return false;
+  }
+  if (direct) return true;
+  const int to_copy = rq.num_samples - rq.used;
+  for (int s = 0; s < num_streams_; ++s) {
+    int16_t* o = out.data() + static_cast<size_t>(s) * rq.num_samples;
+    std::copy(leftover_[s].begin(), leftover_[s].begin() + rq.used, o);
+    leftover_[s].erase(leftover_[s].begin(), leftover_[s].begin() + rq.used);
+    if (rq.produced > 0) {
+      const int16_t* e = &external_[static_cast<size_t>(s) * rq.produced];
+      std::copy(e, e + to_copy, o + rq.used);
+      leftover_[s].insert(leftover_[s].end(), e + to_copy, e + rq.produced);
     }
   }
   return true;

@@ -55,7 +55,14 @@ class BatchLyraEncoder {
   // (lyra_encoder.cc:124-129), else nullopt.  Returns num_streams rows of packet_size() bytes; with DTX a row whose
   // stream sent an empty packet (lyra_encoder.cc:136-141) is all zero and packet_lengths()[s] == 0.
   std::optional<std::vector<uint8_t>> Encode(const absl::Span<const int16_t> audio);
-  // Bytes of each stream's packet from the last Encode: packet_size(), or 0 for a DTX empty packet.
+  // The same in two halves, for a caller that feeds hop after hop (round 6): EncodeAsync() starts a hop and returns --
+  // `audio` may be reused at once --, WaitEncoded() returns the packets of the OLDEST hop started.  Up to two hops may be
+  // in flight; with EncodeAsync(n + 1) issued before WaitEncoded(n) the upload of hop n + 1 and the download of hop n run
+  // under the kernels (include/lyra_hip.h "Pipelined host-buffer calls").  Same packets as Encode().
+  bool EncodeAsync(const absl::Span<const int16_t> audio);
+  std::optional<std::vector<uint8_t>> WaitEncoded();
+  int hops_in_flight() const { return static_cast<int>(in_flight_.size()); }
+  // Bytes of each stream's packet from the last Encode / WaitEncoded: packet_size(), or 0 for a DTX empty packet.
   const std::vector<int32_t>& packet_lengths() const { return lengths_; }
   bool set_bitrate(int bitrate);   // lyra_encoder.cc:158-166
   int sample_rate_hz() const { return sample_rate_hz_; }
@@ -75,6 +82,7 @@ class BatchLyraEncoder {
   std::vector<int32_t> ids_;          // stream slots 0 .. num_streams-1 of the context
   std::vector<int32_t> lengths_;
   std::vector<int16_t> resampled_;
+  std::vector<int> in_flight_;        // packet size of every hop begun and not yet waited for, oldest first
 };
 
 class BatchLyraDecoder {
@@ -95,6 +103,13 @@ class BatchLyraDecoder {
   // The same into caller memory (num_streams * num_samples samples; pinned memory avoids a staging copy): no allocation
   // on the steady-state path.  false + LOG(ERROR) where the other form returns nullopt.
   bool DecodeSamples(int num_samples, absl::Span<int16_t> out);
+  // The same in two halves (round 6): DecodeSamplesAsync() runs the state machine and enqueues the request -- packets for
+  // the next request may be set and the next request started at once --, WaitDecoded() delivers the OLDEST request begun
+  // (out.size() == num_streams * that request's num_samples).  Up to two requests may be in flight; the download of
+  // request n then runs under the kernels of request n + 1.  Same samples as DecodeSamples().
+  bool DecodeSamplesAsync(int num_samples);
+  bool WaitDecoded(absl::Span<int16_t> out);
+  int requests_in_flight() const { return static_cast<int>(pending_.size()); }
   int sample_rate_hz() const { return sample_rate_hz_; }
   int num_channels() const { return 1; }
   int frame_rate() const { return kBatchFrameRate; }
@@ -149,6 +164,9 @@ class BatchLyraDecoder {
   std::vector<int32_t> need_packet_[3], need_estimated_, need_cng_, need_noise_;
   std::vector<uint8_t> packets_[3];
   std::vector<lyra_hip_twin_slice> slices_;
+  struct Pending { int num_samples, used, produced; };   // a request begun: samples asked for, taken from the leftovers, fetched
+  std::vector<Pending> pending_;                 // oldest first
+  int leftover_count_ = 0;                       // leftover samples per stream once every request begun has been delivered
   std::vector<std::vector<int16_t>> leftover_;   // BufferedResampler::leftover_samples_ per stream (same length for all)
   std::vector<int16_t> external_;                // a request's resampled samples when leftovers have to be spliced in
 };

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <vector>
 
@@ -23,6 +24,10 @@ struct lyra_hip_ctx {
   int out_n = 0;                          // the request being assembled
   std::vector<int16_t> out;               // [max_streams][out_n]
   std::vector<std::vector<int16_t>> noise_rows;
+  // pipelined calls: results of begun calls, oldest first (at most two in flight)
+  struct Enc { std::vector<uint8_t> pk; std::vector<int32_t> len; };
+  std::deque<Enc> enc_q;
+  std::deque<std::vector<int16_t>> fetch_q;
 };
 
 namespace {
@@ -172,6 +177,45 @@ int lyra_hip_twin_assemble(lyra_hip_ctx* c, const lyra_hip_twin_slice* sl, int B
 int lyra_hip_twin_noise(lyra_hip_ctx* c, const int32_t* ids, int B) {
   if ((size_t)B != c->noise_rows.size()) return LYRA_HIP_EINVAL;
   for (int b = 0; b < B; ++b) c->st[ids[b]].noise_calls[LYRA_HIP_SIDE_DECODER]++;
+  return 0;
+}
+// pipelined forms: computed at begin(), handed over at end() -- the host twin must pair them in order, two deep at most
+int lyra_hip_encode_begin(lyra_hip_ctx* c, const int32_t* ids, int B, const int16_t* pcm, int rate, int num_bits, int dtx) {
+  if (c->enc_q.size() >= 2) return LYRA_HIP_EINVAL;
+  const int nbytes = (num_bits + 7) / 8, n_ext = rate / 50;
+  std::vector<int16_t> p16((size_t)B * 320);
+  if (rate == 16000) std::memcpy(p16.data(), pcm, p16.size() * 2);
+  else lyra_hip_resample(c, LYRA_HIP_SIDE_ENCODER, ids, B, pcm, n_ext, rate, 16000, p16.data());
+  lyra_hip_ctx::Enc e;
+  e.pk.resize((size_t)B * nbytes);
+  e.len.assign(B, nbytes);
+  const int rc = dtx ? lyra_hip_encode_dtx(c, ids, B, p16.data(), num_bits, e.pk.data(), e.len.data())
+                     : lyra_hip_encode(c, ids, B, p16.data(), num_bits, e.pk.data());
+  if (rc) return rc;
+  c->enc_q.push_back(std::move(e));
+  return 0;
+}
+int lyra_hip_encode_end(lyra_hip_ctx* c, uint8_t* packets, int32_t* packet_bytes) {
+  if (c->enc_q.empty()) return LYRA_HIP_EINVAL;
+  lyra_hip_ctx::Enc& e = c->enc_q.front();
+  std::memcpy(packets, e.pk.data(), e.pk.size());
+  if (packet_bytes) std::memcpy(packet_bytes, e.len.data(), e.len.size() * 4);
+  c->enc_q.pop_front();
+  return 0;
+}
+int lyra_hip_twin_fetch(lyra_hip_ctx* c, int num_streams, int n, int out_rate, int16_t* out);
+int lyra_hip_twin_fetch_begin(lyra_hip_ctx* c, int num_streams, int n, int out_rate) {
+  if (c->fetch_q.size() >= 2) return LYRA_HIP_EINVAL;
+  std::vector<int16_t> o((size_t)num_streams * (size_t)((long)n * out_rate / 16000));
+  const int rc = lyra_hip_twin_fetch(c, num_streams, n, out_rate, o.data());
+  if (rc) return rc;
+  c->fetch_q.push_back(std::move(o));
+  return 0;
+}
+int lyra_hip_twin_fetch_end(lyra_hip_ctx* c, int16_t* out) {
+  if (c->fetch_q.empty()) return LYRA_HIP_EINVAL;
+  if (!c->fetch_q.front().empty()) std::memcpy(out, c->fetch_q.front().data(), c->fetch_q.front().size() * 2);
+  c->fetch_q.pop_front();
   return 0;
 }
 int lyra_hip_twin_fetch(lyra_hip_ctx* c, int num_streams, int n, int out_rate, int16_t* out) {

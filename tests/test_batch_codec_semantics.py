@@ -37,7 +37,7 @@ def test_reference_model_decoder_state_machine(oracle_default):
     assert not dec.is_comfort_noise()
 
 
-def _run_session(tmp_path, oracle, rate, bitrate, dtx, pcm, script, demo=None):
+def _run_session(tmp_path, oracle, rate, bitrate, dtx, pcm, script, demo=None, pipelined=False):
     import lyra_amd
     if demo is None:
         demo = os.path.join(ROOT, "lyra_amd", "decoder_demo")
@@ -47,8 +47,10 @@ def _run_session(tmp_path, oracle, rate, bitrate, dtx, pcm, script, demo=None):
     pk, ln, pout = tmp_path / "pk.bin", tmp_path / "len.i32", tmp_path / "out.s16"
     pcm.tofile(pin)
     sc.write_text("\n".join(f"{mask} " + " ".join(map(str, sizes)) for mask, sizes in script) + "\n")
+    # pipelined: the session through EncodeAsync / WaitEncoded and DecodeSamplesAsync / WaitDecoded, two deep (decoder_demo.cc)
+    env = dict(os.environ, LYRA_DEMO_PIPELINED="1" if pipelined else "0")
     r = subprocess.run([demo, lyra_amd.default_model_dir(), str(sc), str(pin), str(rate), str(bitrate), str(int(dtx)),
-                        str(n), str(pk), str(ln), str(pout)], capture_output=True, text=True, timeout=600)
+                        str(n), str(pk), str(ln), str(pout)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
     ps = {3200: 8, 6000: 15, 9200: 23}[bitrate]
     packets = np.fromfile(pk, np.uint8).reshape(T, n, ps)
@@ -126,9 +128,10 @@ def _build_fake_demo(tmp_path):
     return exe
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("rate,bitrate,dtx", [(16000, 6000, False), (48000, 3200, True), (8000, 9200, False),
                                               (32000, 6000, True)])
-def test_batch_codec_host_logic_against_fake_abi(tmp_path, rate, bitrate, dtx):
+def test_batch_codec_host_logic_against_fake_abi(tmp_path, rate, bitrate, dtx, pipelined):
     """CPU: the C++ twins' host logic alone -- the C ABI underneath replaced by integer formulas with per-stream call
     counters (tests/host_stub), the reference model assembled from the same formulas (fake_kit.py).  Everything the
     twins do around the device calls is then checked EXACTLY, sample for sample: resampling bookkeeping and leftovers,
@@ -153,7 +156,8 @@ def test_batch_codec_host_logic_against_fake_abi(tmp_path, rate, bitrate, dtx):
         if t % 11 == 5:
             sizes = [0] + sizes          # DecodeSamples(0) is legal
         script.append((mask, sizes))
-    packets, lengths, out = _run_session(tmp_path, None, rate, bitrate, dtx, pcm, script, demo=_build_fake_demo(tmp_path))
+    packets, lengths, out = _run_session(tmp_path, None, rate, bitrate, dtx, pcm, script, demo=_build_fake_demo(tmp_path),
+                                         pipelined=pipelined)
 
     encs = [M.RefLyraEncoder(None, rate, bits, dtx, kit=FakeKit()) for _ in range(n)]
     decs = [M.RefLyraDecoder(None, rate, cng_seed=0, kit=FakeKit()) for _ in range(n)]

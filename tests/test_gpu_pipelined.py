@@ -1,0 +1,60 @@
+"""The two-deep pipelined host-buffer calls (include/lyra_hip.h "Pipelined host-buffer calls"; BatchLyraEncoder::EncodeAsync /
+WaitEncoded, BatchLyraDecoder::DecodeSamplesAsync / WaitDecoded) on the GPU: same kernels in the same order per stream, so
+every packet and every decoded sample must equal what the blocking calls give -- over scripted sessions with packet loss,
+DTX, odd request sizes and all four sample rates -- and the C ABI's begin / end pair must equal lyra_hip_encode."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.mark.parametrize("rate,bitrate,dtx", [(16000, 9200, False), (48000, 6000, True), (8000, 3200, False), (32000, 9200, True)])
+def test_pipelined_twins_equal_the_blocking_twins(tmp_path, golden_dir, rate, bitrate, dtx):
+    from test_batch_codec_semantics import _run_session
+    from test_reference_glue import _session
+    pcm, script = _session(golden_dir, rate, bitrate)
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    pa, la, oa = _run_session(tmp_path / "a", None, rate, bitrate, dtx, pcm, script)
+    pb, lb, ob = _run_session(tmp_path / "b", None, rate, bitrate, dtx, pcm, script, pipelined=True)
+    assert np.array_equal(la, lb) and np.array_equal(pa, pb), "packets differ between the blocking and the pipelined session"
+    assert oa.size == ob.size and np.array_equal(oa, ob), "decoded samples differ between the blocking and the pipelined session"
+
+
+def test_c_abi_encode_begin_end_equals_encode_and_enforces_two_in_flight():
+    import lyra_amd
+    from lyra_amd import codec
+    L = codec._load()
+    vp, ci = C.c_void_p, C.c_int
+    L.lyra_hip_encode_begin.argtypes = [vp, vp, ci, vp, ci, ci, ci]
+    L.lyra_hip_encode_end.argtypes = [vp, vp, vp]
+    B, T, bits = 300, 7, 184
+    rng = np.random.Generator(np.random.PCG64(31))
+    pcm = rng.integers(-20000, 20000, size=(T, B, 320)).astype(np.int16)
+    ids = np.arange(B, dtype=np.int32)[::-1].copy()
+    a = lyra_amd.LyraHip(max_streams=512)
+    b = lyra_amd.LyraHip(max_streams=512)
+    try:
+        want = [a.encode(pcm[t], bits, ids) for t in range(T)]
+        p = lambda x: x.ctypes.data_as(vp)
+        h = b.h if hasattr(b, "h") else b.ctx
+        got = []
+        out = np.empty((B, 23), np.uint8)
+        lens = np.empty(B, np.int32)
+        assert L.lyra_hip_encode_end(h, p(out), p(lens)) != 0                     # nothing in flight
+        assert L.lyra_hip_encode_begin(h, p(ids), B, p(pcm[0]), 16000, bits, 0) == 0
+        for t in range(T):
+            if t + 1 < T:
+                assert L.lyra_hip_encode_begin(h, p(ids), B, p(pcm[t + 1]), 16000, bits, 0) == 0
+                if t == 0:
+                    assert L.lyra_hip_encode_begin(h, p(ids), B, p(pcm[t + 1]), 16000, bits, 0) != 0   # a third one is refused
+            assert L.lyra_hip_encode_end(h, p(out), p(lens)) == 0
+            assert (lens == 23).all()
+            got.append(out.copy())
+        for t in range(T):
+            assert np.array_equal(got[t], want[t]), f"hop {t}"
+    finally:
+        a.close(); b.close()
