@@ -251,6 +251,10 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
   static_assert(S == 8 && (NT == 256 || NT == 512), "thread <-> (stream, channel quad, row half) mapping");
   constexpr int CS = 136, NTW = 8 / (NT / 64), MT = 2, RPT = 1024 / NT;
   constexpr bool SW = LYRA_SWAP128 != 0;   // operand-swapped GEMMs (lyra_dev.h): 16-byte epilogue accesses
+#ifndef LYRA_PF128_EXTRA
+#define LYRA_PF128_EXTRA 0   // experiment: weight / operand prefetch distance of the 128-channel blocks' GEMMs, in K chunks beyond the default
+#endif
+  constexpr int PF = gemm_pf<MT, NTW>() + LYRA_PF128_EXTRA;
 #pragma unroll 1
   for (int r = 0; r < 3; ++r) {
     int tid = threadIdx.x;
@@ -301,15 +305,15 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
     // The first weight chunks + bias of each GEMM are requested ahead of the barrier / elementwise phase in front of it
     // (gemm_f32_wprefetch): the L2 round trip no longer stands between the barrier and the first MFMA.  Round 5: +1.2 % on
     // the whole step at 4,096 streams (enc_s1 -1.1 us, dec_s1 -2.2 us); the same in the 64-channel blocks costs spills.
-    const auto pw_pre = gemm_f32_wprefetch<NTW, 8, 8, gemm_pf<MT, NTW>(), SW>(pws[r].w + (wave * NTW) * 8 * 64, pws[r].b, wave * NTW * 16);
-    WPre<NTW, gemm_pf<MT, NTW>()> cv_pre;
+    const auto pw_pre = gemm_f32_wprefetch<NTW, 8, 8, PF, SW>(pws[r].w + (wave * NTW) * 8 * 64, pws[r].b, wave * NTW * 16);
+    WPre<NTW, PF> cv_pre;
     __syncthreads();
     LYRA_TSTAMP(40 + r * 8 + 2);
     {  // pointwise 128 -> 128, LeakyReLU
       f32x4 acc[MT][NTW];
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + c * 16 + q * 4; };
-      gemm_f32_pre<MT, NTW, 8, 8, gemm_pf<MT, NTW>(), SW>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, pw_pre, acc);
-      cv_pre = gemm_f32_wprefetch<NTW, 4, 4, gemm_pf<MT, NTW>(), SW>(cvs[r].w + (wave * NTW) * 4 * 64, cvs[r].b, wave * NTW * 16);
+      gemm_f32_pre<MT, NTW, 8, 8, PF, SW>(D, aoff, pws[r].w + (wave * NTW) * 8 * 64, pw_pre, acc);
+      cv_pre = gemm_f32_wprefetch<NTW, 4, 4, PF, SW>(cvs[r].w + (wave * NTW) * 4 * 64, cvs[r].b, wave * NTW * 16);
       LYRA_TSTAMP(40 + r * 8 + 3);
       // The next block's history rows.  vmcnt retires in order, so these loads would stall the first weight
       // fetch of a GEMM issued right after them; here they have the two barriers and the LDS-only P write
@@ -338,7 +342,7 @@ __device__ __forceinline__ void resblocks128(float* X, float* D, float* P, const
       f32x4 acc[MT][NTW];
       const int g = (wave * NTW) >> 2;
       auto aoff = [&](int i, int c) { return (i * 16 + m) * CS + g * 64 + c * 16 + q * 4; };
-      gemm_f32_pre<MT, NTW, 4, 4, gemm_pf<MT, NTW>(), SW>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, cv_pre, acc);
+      gemm_f32_pre<MT, NTW, 4, 4, PF, SW>(P, aoff, cvs[r].w + (wave * NTW) * 4 * 64, cv_pre, acc);
       LYRA_TSTAMP(40 + r * 8 + 5);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
