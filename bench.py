@@ -393,7 +393,7 @@ def step_roofline(mode, legs, frames_per_s_per_gpu, traffic_table):
 def load_issue_time(names):
     """Offline SQ counters (profiles/r05_pmc_sq.txt, B = 4096): per SIMD, the time the matrix pipe is busy and the time the
     vector instructions take to issue, summed over the step's kernels.  On this part vector instructions do not hide under
-    the MFMAs (tools/archive/mfma_valu_overlap_probe.hip), so the two add up; informational, not the roofline."""
+    the MFMAs (mfma_valu_overlap_probe.hip (a probe of an earlier round, removed since: git history)), so the two add up; informational, not the roofline."""
     try:
         cur, tab = None, {}
         for line in open(os.path.join(ROOT, "profiles", "r05_pmc_sq.txt")):

@@ -789,7 +789,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     for (int i = 0; i < 3; ++i) prio[i] = v[i] >= 2 ? prio_hi : (v[i] == 1 ? (prio_lo + prio_hi) / 2 : prio_lo);
   }
   const unsigned evflags = hipEventDisableTiming | (getenv("LYRA_HIP_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
-  // CU partitioning (tools/archive/placement_probe.hip, profiles/r04_placement_probe.txt): two concurrent dispatches of <= 256
+  // CU partitioning (placement_probe.hip (a probe of an earlier round, removed since: git history), profiles/r04_placement_probe.txt): two concurrent dispatches of <= 256
   // workgroups are placed independently of each other -- of 2 x 128 workgroups 68 CUs get two and 68 none -- and a stage
   // kernel lasts as long as its slowest tile.  Streams created with complementary CU masks keep the chains apart.
   // The pattern is 32 bits repeated over the chip's CU mask; 0x00ff00ff / 0xff00ff00 give each side half of every XCD

@@ -459,7 +459,7 @@ __device__ __forceinline__ void dec_s1_body(const DecS1P& P, const float* __rest
   const int tid = threadIdx.x, wave = tid >> 6;
   const int b0 = tile * SD1;
   LYRA_TSTAMP(50);
-#ifdef LYRA_WGTRACE_D1   // per-workgroup trace of THIS kernel instead of dec_s0 (tools/archive/wg_trace_full.py)
+#ifdef LYRA_WGTRACE_D1   // per-workgroup trace of THIS kernel instead of dec_s0 (wg_trace_full.py (a probe of an earlier round, removed since: git history))
   LYRA_WG_BEGIN();
 #endif
   // the stage input does not depend on the stream ids: requested with them, ahead of the barrier (see enc_s1_body)

@@ -586,7 +586,7 @@ __device__ __forceinline__ WarmTok<MAXIT> l2_warm(const WarmRange& w) {
 // per workgroup; instruction-cache misses are served by the XCD's L2, which is cold at a kernel boundary, so each
 // line's first fetch goes to the Infinity Cache -- or, when the step's working set (265 MB of per-stream state at
 // B = 4096, more than the 256 MB cache) has pushed the code out of it, to HBM, in the middle of the dependent phase
-// chain.  Measured (tools/archive/pipeline_probe.py): inside the sustained encode+decode pipeline the two largest kernels
+// chain.  Measured (pipeline_probe.py (a probe of an earlier round, removed since: git history)): inside the sustained encode+decode pipeline the two largest kernels
 // (enc_s2 29 KB, dec_s0 42 KB of code) ran 64 / 82 us instead of 40 / 45 us on most boxes of the pool; pulling
 // the code into L2 with data loads at kernel start brings them back to 51 / 61 us.
 // `code_bytes` comes from the host: the symbol size of this kernel minus the offset of this very s_getpc_b64 inside it,

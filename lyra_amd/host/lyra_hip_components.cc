@@ -58,7 +58,7 @@ template <class Req>
 class Combiner {
  public:
   enum { kPending = 0, kDone = 1, kLead = 2 };
-  // tunables (environment, read once; tools/archive/plugin_mt_sweep.sh: 10-150 us of quiet time and fan-outs 2-16 are within
+  // tunables (environment, read once; plugin_mt_sweep.sh (a probe of an earlier round, removed since: git history): 10-150 us of quiet time and fan-outs 2-16 are within
   // run-to-run spread of each other at 256 and 1,024 threads)
   static long EnvLong(const char* name, long dflt) { const char* v = std::getenv(name); return v ? std::atol(v) : dflt; }
   const int kFan = (int)std::max(1L, EnvLong("LYRA_HIP_COMBINER_FAN", 4));
@@ -68,7 +68,9 @@ class Combiner {
   // the batch wakes it, the quiet time passes or the budget is spent (round 6: up to five leaders used to spin for up to
   // 3 ms each -- in a CPU-quota-limited container that is quota the arriving threads need, and under SCHED_FIFO
   // sched_yield() does not give the core to a lower-priority arrival at all)
-  const long kSpinUs = EnvLong("LYRA_HIP_COMBINER_SPIN_US", 30);
+  // 300 us measured as the knee (profiles/r06_plugin_mt_spin.txt, 64 / 256 / 1,024 threads): 30 us 71 / 173 / 303 k frames/s,
+  // 300 us 77 / 199 / 316 k, 3,000 us (= no sleeping, the round-5 behaviour) 78 / 197 / 308 k.
+  const long kSpinUs = EnvLong("LYRA_HIP_COMBINER_SPIN_US", 300);
   template <class Exec>   // exec(std::vector<Req*>&): sets every request's rc
   void Run(Req* r, Exec exec) {
     thread_local std::shared_ptr<Waiter> me = std::make_shared<Waiter>();
