@@ -24,7 +24,10 @@ def test_pipelined_twins_equal_the_blocking_twins(tmp_path, golden_dir, rate, bi
     assert oa.size == ob.size and np.array_equal(oa, ob), "decoded samples differ between the blocking and the pipelined session"
 
 
-def test_c_abi_encode_begin_end_equals_encode_and_enforces_two_in_flight():
+@pytest.mark.parametrize("sub_batches", [1, 2])
+def test_c_abi_encode_begin_end_equals_encode_and_enforces_two_in_flight(sub_batches):
+    """sub_batches = 2: the context splits a batch over two extractor / quantizer stream pairs (LYRA_HIP_SUBBATCHES); the
+    pipelined call orders its upload in front of, and its download behind, every chunk."""
     import lyra_amd
     from lyra_amd import codec
     L = codec._load()
@@ -36,7 +39,7 @@ def test_c_abi_encode_begin_end_equals_encode_and_enforces_two_in_flight():
     pcm = rng.integers(-20000, 20000, size=(T, B, 320)).astype(np.int16)
     ids = np.arange(B, dtype=np.int32)[::-1].copy()
     a = lyra_amd.LyraHip(max_streams=512)
-    b = lyra_amd.LyraHip(max_streams=512)
+    b = lyra_amd.LyraHip(max_streams=512, sub_batches=sub_batches)
     try:
         want = [a.encode(pcm[t], bits, ids) for t in range(T)]
         p = lambda x: x.ctypes.data_as(vp)
