@@ -33,9 +33,18 @@ __device__ __forceinline__ int taps3(int x0, int x1, int x2, int e) {
 }
 
 // ---- lookup tables (LDS) ----------------------------------------------------------------------------
+// -DLYRA_LUT_IDENTITY: TIMING-ONLY ablation (results are wrong) -- the table reads vanish; what the step gains is ALL the
+// byte-table gathers can cost (round 6, profiles/r06_ab_lut_identity.txt).
+#ifdef LYRA_LUT_IDENTITY
+__device__ __forceinline__ int lut8(const int8_t*, int c8) { return c8; }
+#else
 __device__ __forceinline__ int lut8(const int8_t* lut, int c8) { return (int)lut[c8 + 128]; }
+#endif
 // four packed codes at once
 __device__ __forceinline__ int lut8w(const int8_t* lut, int w) {
+#ifdef LYRA_LUT_IDENTITY
+  return w;
+#endif
   const uint32_t u = (uint32_t)w ^ 0x80808080u;
   return pack8(lut[u & 255], lut[(u >> 8) & 255], lut[(u >> 16) & 255], lut[u >> 24]);
 }
