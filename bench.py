@@ -391,12 +391,12 @@ def step_roofline(mode, legs, frames_per_s_per_gpu, traffic_table):
 
 
 def load_issue_time(names):
-    """Offline SQ counters (profiles/r05_pmc_sq.txt, B = 4096): per SIMD, the time the matrix pipe is busy and the time the
+    """Offline SQ counters (profiles/r06_pmc_sq.txt, B = 4096): per SIMD, the time the matrix pipe is busy and the time the
     vector instructions take to issue, summed over the step's kernels.  On this part vector instructions do not hide under
     the MFMAs (mfma_valu_overlap_probe.hip (a probe of an earlier round, removed since: git history)), so the two add up; informational, not the roofline."""
     try:
         cur, tab = None, {}
-        for line in open(os.path.join(ROOT, "profiles", "r05_pmc_sq.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r06_pmc_sq.txt")):
             if line.strip() and not line.startswith(" "):
                 cur = line.strip()
                 tab[cur] = {}
@@ -415,8 +415,8 @@ def load_issue_time(names):
             per = 2.6 if k == "rvq_encode_kernel" else 4.3   # cycles per wave instruction: fp32 chains | integer / mixed
             vector += (c["SQ_INSTS_VALU"] - c.get("SQ_INSTS_MFMA", 0.0)) * per / simds / clk
         return {"matrix_pipe_us_per_step_at_B4096": round(matrix * 1e6, 1), "vector_issue_us_per_step_at_B4096": round(vector * 1e6, 1),
-                "source": "offline: SQ counters of profiles/r05_pmc_sq.txt at 2.06 GHz; vector instructions do not hide under "
-                          "MFMAs on gfx950 (profiles/r03_mfma_valu_overlap_probe.txt), so a SIMD's time is the sum"}
+                "source": "offline: SQ counters of profiles/r06_pmc_sq.txt at 2.06 GHz; vector instructions do not hide under "
+                          "MFMAs on gfx950 (profiles/r03_mfma_valu_overlap_probe.txt), so a SIMD's time is at most the sum (round 6: vector issue overlaps the matrix pipe in part)"}
     except Exception:
         return None
 
