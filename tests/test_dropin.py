@@ -133,6 +133,39 @@ def test_gpu_reference_decoder_concealment_on_hip_plugins(oracle_default, golden
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rate,bitrate,dtx", [(8000, 3200, False), (32000, 6000, True), (48000, 9200, False)])
+def test_gpu_reference_classes_on_hip_plugins_other_rates_and_dtx(oracle_default, golden_dir, model_dir, rate, bitrate, dtx):
+    """The sample rates and the DTX mode of lyra_integration_test.cc:49-149 / lyra_encoder.cc:119-141: the reference's own
+    resampling, noise decision and empty-packet logic around the HIP plugins (four scripted streams with loss, a silent
+    stretch and odd request sizes -- tests/test_reference_glue.py _session), against the oracle-backed build of the same
+    sources, packet for packet and sample for sample."""
+    from oracle import lyra_ref as R
+    from test_reference_glue import _session
+    pcm, script = _session(golden_dir, rate, bitrate)
+    n = pcm.shape[1]
+    D.load(oracle_default).dropin_set_max_streams(64)
+    encs = [D.LyraEncoder(oracle_default, rate, bitrate, dtx, model_dir) for _ in range(n)]
+    decs = [D.LyraDecoder(oracle_default, rate, model_dir, cng_seed=0x4C797261 ^ s) for s in range(n)]
+    rencs = [R.LyraEncoder(oracle_default, rate, BITRATES[bitrate], dtx) for _ in range(n)]
+    rdecs = [R.LyraDecoder(oracle_default, rate, 0x4C797261 ^ s) for s in range(n)]
+    saw_empty = False
+    for t, (mask, sizes) in enumerate(script):
+        for s in range(n):
+            pk, want = encs[s].Encode(pcm[t, s]), rencs[s].Encode(pcm[t, s])
+            assert pk is not None and want is not None and np.array_equal(pk, want), (t, s)
+            saw_empty = saw_empty or pk.size == 0
+            if pk.size and mask[s] == "1":
+                assert decs[s].SetEncodedPacket(pk) and rdecs[s].SetEncodedPacket(want)
+        for k in sizes:
+            for s in range(n):
+                got, want = decs[s].DecodeSamples(k), rdecs[s].DecodeSamples(k)
+                assert got is not None and want is not None and np.array_equal(got, want), (t, s, k)
+    assert saw_empty == dtx
+    for o in encs + decs:
+        o.close()
+
+
+@pytest.mark.gpu
 def test_gpu_reference_lyra_benchmark_on_hip_plugins(oracle_default, model_dir, capfd):
     """The reference's own benchmark loop and report (lyra_benchmark_lib.cc:199-293, compiled with -DBENCHMARK)."""
     assert D.lyra_benchmark(oracle_default, 500, model_dir) == 0
