@@ -112,6 +112,11 @@ def _load(path=None):
     for suf in ("", "_dev"):
         getattr(L, f"lyra_hip_resample{suf}").argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
         getattr(L, f"lyra_hip_comfort_noise{suf}").argtypes = [vp, vp, ci, vp, vp]
+    if hasattr(L, "lyra_hip_encode_begin"):   # (build variants older than round 6 do not carry the pipelined calls)
+        L.lyra_hip_encode_begin.argtypes = [vp, vp, ci, vp, ci, ci, ci]
+        L.lyra_hip_encode_end.argtypes = [vp, vp, vp]
+        L.lyra_hip_twin_fetch_begin.argtypes = [vp, ci, ci, ci]
+        L.lyra_hip_twin_fetch_end.argtypes = [vp, vp]
     L.lyra_hip_set_cng_seed.argtypes = [vp, C.c_uint64]
     L.lyra_hip_set_encoder_sample_rate.argtypes = [vp, C.c_int]
     L.lyra_hip_stream.restype = vp
@@ -284,6 +289,25 @@ class LyraHip:
         out = np.empty((B, packet_size(num_bits)), np.uint8)
         self._chk(self.L.lyra_hip_encode(self.h, ids.ctypes.data, B, pcm.ctypes.data, num_bits, out.ctypes.data))
         return out
+
+    def encode_begin(self, pcm, num_bits, stream_ids=None, sample_rate_hz=16000, dtx=False):
+        """Pipelined form of encode() (include/lyra_hip.h "Pipelined host-buffer calls"): starts a hop and returns; up to
+        two hops may be in flight; pcm int16 [B][sample_rate_hz / 50] at 8 / 16 / 32 / 48 kHz.  `pcm` may be reused at once."""
+        pcm = _np(pcm, np.int16, (-1, sample_rate_hz // 50))
+        B = pcm.shape[0]
+        ids = self._ids(stream_ids, B)
+        if dtx:
+            self._chk(self.L.lyra_hip_set_encoder_sample_rate(self.h, sample_rate_hz))
+        self._chk(self.L.lyra_hip_encode_begin(self.h, ids.ctypes.data, B, pcm.ctypes.data, sample_rate_hz, num_bits, int(dtx)))
+        self._pending_encodes = getattr(self, "_pending_encodes", []) + [(B, num_bits)]
+
+    def encode_end(self):
+        """-> (packets uint8 [B][num_bits/8], packet_bytes int32 [B]) of the OLDEST hop begun."""
+        B, num_bits = self._pending_encodes.pop(0)
+        out = np.empty((B, packet_size(num_bits)), np.uint8)
+        lens = np.empty(B, np.int32)
+        self._chk(self.L.lyra_hip_encode_end(self.h, out.ctypes.data, lens.ctypes.data))
+        return out, lens
 
     def decode(self, packets, num_bits, stream_ids=None):
         """packets uint8 [B][num_bits/8] -> pcm int16 [B][320] (SetEncodedPacket + DecodeSamples(320))."""

@@ -31,9 +31,7 @@ def test_c_abi_encode_begin_end_equals_encode_and_enforces_two_in_flight(sub_bat
     import lyra_amd
     from lyra_amd import codec
     L = codec._load()
-    vp, ci = C.c_void_p, C.c_int
-    L.lyra_hip_encode_begin.argtypes = [vp, vp, ci, vp, ci, ci, ci]
-    L.lyra_hip_encode_end.argtypes = [vp, vp, vp]
+    vp = C.c_void_p
     B, T, bits = 300, 7, 184
     rng = np.random.Generator(np.random.PCG64(31))
     pcm = rng.integers(-20000, 20000, size=(T, B, 320)).astype(np.int16)
@@ -59,5 +57,18 @@ def test_c_abi_encode_begin_end_equals_encode_and_enforces_two_in_flight(sub_bat
             got.append(out.copy())
         for t in range(T):
             assert np.array_equal(got[t], want[t]), f"hop {t}"
+        # ... and the Python mirror of the pair (lyra_amd/codec.py), at 48 kHz with DTX, against the blocking calls
+        a.reset(); b.reset()
+        a.set_encoder_sample_rate(48000)
+        p48 = rng.integers(-20000, 20000, size=(4, B, 960)).astype(np.int16)
+        p48[:, :7] //= 2000          # a few streams are noise: DTX sends empty packets for them
+        b.encode_begin(p48[0], bits, ids, sample_rate_hz=48000, dtx=True)
+        for t in range(4):
+            if t + 1 < 4:
+                b.encode_begin(p48[t + 1], bits, ids, sample_rate_hz=48000, dtx=True)
+            pk, lens = b.encode_end()
+            p16 = a.resample(p48[t], 48000, 16000, ids, side="encoder")
+            want_pk, want_len = a.encode_dtx(p16, bits, ids)
+            assert np.array_equal(lens, want_len) and np.array_equal(pk, want_pk), f"48 kHz DTX hop {t}"
     finally:
         a.close(); b.close()
