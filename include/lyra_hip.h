@@ -346,6 +346,10 @@ int lyra_hip_twin_fetch(lyra_hip_ctx* ctx, int num_streams, int num_internal_sam
 int lyra_hip_encode_begin(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const int16_t* pcm, int sample_rate_hz,
                           int num_bits, int dtx);
 int lyra_hip_encode_end(lyra_hip_ctx* ctx, uint8_t* packets, int32_t* packet_bytes);
+/* lyra_hip_decode in two halves: begin() takes packets [B][num_bits / 8 rounded up], end() delivers pcm [B][320] of the
+ * oldest begun call (its download runs under a younger call's kernels). */
+int lyra_hip_decode_begin(lyra_hip_ctx* ctx, const int32_t* stream_ids, int B, const uint8_t* packets, int num_bits);
+int lyra_hip_decode_end(lyra_hip_ctx* ctx, int16_t* pcm);
 /* lyra_hip_twin_fetch in two halves ("Decoder twin" above): begin() ends the request being assembled -- its resampling and
  * its download are enqueued, the NEXT request's twin calls may follow at once --, end() waits for the oldest begun request
  * and copies its rows out (out may be NULL when that request had num_internal_samples == 0). */

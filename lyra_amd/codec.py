@@ -115,6 +115,8 @@ def _load(path=None):
     if hasattr(L, "lyra_hip_encode_begin"):   # (build variants older than round 6 do not carry the pipelined calls)
         L.lyra_hip_encode_begin.argtypes = [vp, vp, ci, vp, ci, ci, ci]
         L.lyra_hip_encode_end.argtypes = [vp, vp, vp]
+        L.lyra_hip_decode_begin.argtypes = [vp, vp, ci, vp, ci]
+        L.lyra_hip_decode_end.argtypes = [vp, vp]
         L.lyra_hip_twin_fetch_begin.argtypes = [vp, ci, ci, ci]
         L.lyra_hip_twin_fetch_end.argtypes = [vp, vp]
     L.lyra_hip_set_cng_seed.argtypes = [vp, C.c_uint64]
@@ -308,6 +310,19 @@ class LyraHip:
         lens = np.empty(B, np.int32)
         self._chk(self.L.lyra_hip_encode_end(self.h, out.ctypes.data, lens.ctypes.data))
         return out, lens
+
+    def decode_begin(self, packets, num_bits, stream_ids=None):
+        """Pipelined form of decode(): starts a call and returns (up to two in flight); decode_end() -> pcm of the oldest."""
+        packets = _np(packets, np.uint8, (-1, packet_size(num_bits)))
+        B = packets.shape[0]
+        ids = self._ids(stream_ids, B)
+        self._chk(self.L.lyra_hip_decode_begin(self.h, ids.ctypes.data, B, packets.ctypes.data, num_bits))
+        self._pending_decodes = getattr(self, "_pending_decodes", []) + [B]
+
+    def decode_end(self):
+        out = np.empty((self._pending_decodes.pop(0), HOP), np.int16)
+        self._chk(self.L.lyra_hip_decode_end(self.h, out.ctypes.data))
+        return out
 
     def decode(self, packets, num_bits, stream_ids=None):
         """packets uint8 [B][num_bits/8] -> pcm int16 [B][320] (SetEncodedPacket + DecodeSamples(320))."""

@@ -72,3 +72,35 @@ def test_c_abi_encode_begin_end_equals_encode_and_enforces_two_in_flight(sub_bat
             assert np.array_equal(lens, want_len) and np.array_equal(pk, want_pk), f"48 kHz DTX hop {t}"
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("sub_batches", [1, 2])
+def test_c_abi_decode_begin_end_equals_decode(sub_batches):
+    """lyra_hip_decode_begin / _end (through the Python mirror), two deep, against lyra_hip_decode on a second context: the
+    same PCM hop for hop, state carried; a third begin is refused, an end without a begin too."""
+    import lyra_amd
+    B, T, bits = 700, 8, 120
+    rng = np.random.Generator(np.random.PCG64(77))
+    pcm = rng.integers(-20000, 20000, size=(T, B, 320)).astype(np.int16)
+    ids = np.arange(B, dtype=np.int32)
+    enc = lyra_amd.LyraHip(max_streams=1024)
+    a = lyra_amd.LyraHip(max_streams=1024)
+    b = lyra_amd.LyraHip(max_streams=1024, sub_batches=sub_batches)
+    try:
+        packets = [enc.encode(pcm[t], bits, ids) for t in range(T)]
+        want = [a.decode(packets[t], bits, ids) for t in range(T)]
+        with pytest.raises(Exception):
+            b._pending_decodes = [B]
+            b.decode_end()
+        b._pending_decodes = []
+        b.decode_begin(packets[0], bits, ids)
+        for t in range(T):
+            if t + 1 < T:
+                b.decode_begin(packets[t + 1], bits, ids)
+                if t == 0:
+                    with pytest.raises(Exception):
+                        b.decode_begin(packets[t + 1], bits, ids)     # a third call in flight is refused
+            got = b.decode_end()
+            assert np.array_equal(got, want[t]), f"hop {t}"
+    finally:
+        enc.close(); a.close(); b.close()
