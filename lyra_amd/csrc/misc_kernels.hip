@@ -458,6 +458,12 @@ __device__ __forceinline__ void noise_update_wave(const NoiseP& P, int w, bool o
                                                   const float* mel, const NoisePre& pre, float* sh, float* avg,
                                                   int32_t* is_noise_out, int32_t* masked_ids);
 
+// -DLYRA_MEL_ABL=bits: TIMING-ONLY ablations of the estimator kernel (results are wrong): 1 no log, 2 no exp, 4 no sqrt,
+// 8 no decision / recurrence tail, 16 the kernel returns at once, 32 no radix-4 passes in LDS, 64 one bin per band
+// (round 6, profiles/r06_ab_mel_ablation.txt)
+#ifndef LYRA_MEL_ABL
+#define LYRA_MEL_ABL 0
+#endif
 size_t logmel_lds_bytes() { return (size_t)1024 * 2 * 8; }             // the FFT buffer; everything later aliases dead parts of it
 size_t cng_lds_bytes() { return (size_t)(1024 * 2 + 160) * 8; }      // (+160: the comfort-noise kernel's mel vector)
 
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * 2, b1 = b0 + 1;
   const bool two = b1 < B;
+  if constexpr ((LYRA_MEL_ABL & 16) != 0) return;
   LYRA_TSTAMP(110);
   int16_t* prev0 = reinterpret_cast<int16_t*>(state + (size_t)ids[b0] * stride + prev_off);
   int16_t* prev1 = reinterpret_cast<int16_t*>(state + (size_t)ids[two ? b1 : b0] * stride + prev_off);
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
   //   y_q = sum_r (-i)^(r q) W_4L^(r k) F_r[k].  The twiddles of pass s+1 (L2-resident table) are requested before
   // the butterflies of pass s, so their latency hides behind the LDS round trip and the barrier.
 #pragma unroll
-  for (int s = 1; s < 5; ++s) {
+  for (int s = 1; s < ((LYRA_MEL_ABL & 32) ? 1 : 5); ++s) {
     const int L = 1 << (2 * s);
     const int k = tid & (L - 1), g = tid >> (2 * s);
     f64x2* p = z + g * 4 * L + k;
@@ -573,7 +580,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
     const f64x2 zz = z[k], yy = z[nk];
     const double Ar = 0.5 * (zz.x + yy.x), Ai = 0.5 * (zz.y - yy.y);
     const double Br = 0.5 * (zz.y + yy.y), Bi = 0.5 * (yy.x - zz.x);
-    z[k] = (f64x2){__builtin_sqrt(Ar * Ar + Ai * Ai), __builtin_sqrt(Br * Br + Bi * Bi)};
+    if constexpr ((LYRA_MEL_ABL & 4) != 0) z[k] = (f64x2){Ar * Ar + Ai * Ai, Br * Br + Bi * Bi};
+    else z[k] = (f64x2){__builtin_sqrt(Ar * Ar + Ai * Ai), __builtin_sqrt(Br * Br + Bi * Bi)};
   }
   __syncthreads();
   LYRA_TSTAMP(113);
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
     const double* mag = dsm + f;          // |X_f[i]| = mag[2 * i]
     double acc = 0.0;
     double v = mag[2 * be0], wv = wl[be0];
-    for (int i = be0; i < be2; ++i) {
+    for (int i = be0; i < ((LYRA_MEL_ABL & 64) ? be0 + 1 : be2); ++i) {
       const double vn = mag[2 * i + 2], wn = wl[i + 1];
       const double w = v * wv;
       acc += i < be1 ? v - w : w;
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
     float x = (float)acc;
     x = x > 500.f ? x : 500.f;
     // log evaluated in double and rounded once: identical on host and device (oracle/lyra_oracle.c log_f)
-    const float lm = (float)log((double)x) / 10.f;
+    const float lm = (LYRA_MEL_ABL & 1) ? x * 1e-9f : (float)log((double)x) / 10.f;
     if (mel) mel[(size_t)(b0 + f) * 160 + band] = lm;
     if (noise_tail) mel_lds[f * 160 + band] = lm;
   };
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
   else if (two) band_item(1, tid - 96);
   if (tid < 64 && two) band_item(1, tid);
   LYRA_TSTAMP(115);
-  if (noise_tail) {   // (uniform)
+  if (noise_tail && !(LYRA_MEL_ABL & 8)) {   // (uniform)
     __syncthreads();
     LYRA_TSTAMP2(120);
     const int w = tw;
@@ -632,7 +640,10 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
 // float, which is what the host libm returns.  masked_ids (optional): ids[i], or -1 where the hop is noise -- the
 // stream list the DTX-enabled encoder runs on (lyra_encoder.cc:131-141).
 // =============================================================================================
-__device__ __forceinline__ float expf_via_double(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float expf_via_double(float x) {
+  if constexpr ((LYRA_MEL_ABL & 2) != 0) return x * 0.5f;
+  return (float)exp((double)x);
+}
 
 // One wavefront = one stream (slot w of the workgroup, NW slots); every thread of the workgroup calls this (two
 // workgroup barriers inside).  `mel`: the hop's 160 log-mel bins (LDS or global); `on`: the slot holds a real stream.
