@@ -104,3 +104,38 @@ def test_c_abi_decode_begin_end_equals_decode(sub_batches):
             assert np.array_equal(got, want[t]), f"hop {t}"
     finally:
         enc.close(); a.close(); b.close()
+
+
+@pytest.mark.parametrize("sub_batches", [1, 2])
+def test_pipelined_calls_with_stream_ids_that_change_every_hop(sub_batches):
+    """Every hop lists the streams in another order (and the small id / packet buffers of a slot are rewritten while the
+    previous call's kernels run): a call that read a slot's ids or packets from before its own upload would mix streams up.
+    Encode and decode, two deep, against the blocking calls given the same orders."""
+    import lyra_amd
+    B, T, bits = 700, 8, 120
+    rng = np.random.Generator(np.random.PCG64(5))
+    pcm = rng.integers(-20000, 20000, size=(T, B, 320)).astype(np.int16)
+    orders = [rng.permutation(B).astype(np.int32) for _ in range(T)]
+    a = lyra_amd.LyraHip(max_streams=1024)
+    b = lyra_amd.LyraHip(max_streams=1024, sub_batches=sub_batches)
+    try:
+        want_pk = [a.encode(pcm[t][orders[t]], bits, orders[t]) for t in range(T)]
+        want_pcm = [a.decode(want_pk[t], bits, orders[t]) for t in range(T)]
+        got_pk = []
+        b.encode_begin(pcm[0][orders[0]], bits, orders[0])
+        for t in range(T):
+            if t + 1 < T:
+                b.encode_begin(pcm[t + 1][orders[t + 1]], bits, orders[t + 1])
+            got_pk.append(b.encode_end()[0])
+        for t in range(T):
+            assert np.array_equal(got_pk[t], want_pk[t]), f"packets of hop {t}"
+        got_pcm = []
+        b.decode_begin(want_pk[0], bits, orders[0])
+        for t in range(T):
+            if t + 1 < T:
+                b.decode_begin(want_pk[t + 1], bits, orders[t + 1])
+            got_pcm.append(b.decode_end())
+        for t in range(T):
+            assert np.array_equal(got_pcm[t], want_pcm[t]), f"PCM of hop {t}"
+    finally:
+        a.close(); b.close()
