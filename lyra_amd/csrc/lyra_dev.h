@@ -81,8 +81,12 @@ __device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
 #ifndef LYRA_SCALAR_LRELU
   const f32x2 al = (f32x2){LYRA_LRELU_ALPHA, LYRA_LRELU_ALPHA};
   f32x2 lo = (f32x2){v[0], v[1]}, hi = (f32x2){v[2], v[3]}, alo, ahi;
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(alo) : "v"(lo), "v"(al));
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ahi) : "v"(hi), "v"(al));
+  // The products are COMPILER-VISIBLE vector multiplies (selected as v_pk_mul_f32): v is usually a fresh MFMA result, and
+  // this part does not interlock a vector read against an MFMA still writing its destination -- the compiler knows the
+  // wait states of its own instructions, not of an asm block (tools/hazard_probe.hip: a v_pk_mul_f32 spelled in asm right
+  // behind the MFMA reads elements 2, 3 stale).  The maxima below read v only after the product of the same registers.
+  alo = lo * al;
+  ahi = hi * al;
   asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(v[0]), "v"(alo[0]));
   asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(v[1]), "v"(alo[1]));
   asm("v_max_f32 %0, %1, %2" : "=v"(r[2]) : "v"(v[2]), "v"(ahi[0]));
