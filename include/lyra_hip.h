@@ -45,7 +45,13 @@
  *   (2) the outputs of an encode-side call are written after every earlier
  *       decode-side call EXCEPT (at most) THE MOST RECENT ONE has finished:
  *       encode of frame i+1 overlaps decode of frame i, but its packets never
- *       overtake the decode of frame i-1.
+ *       overtake the decode of frame i-1;
+ *   (3) calls of one side apply to a stream's state in call order, whatever the
+ *       order in which a call lists its streams -- also on a context that splits
+ *       batches over several stream sets (LYRA_HIP_SUBBATCHES > 1: every split
+ *       call then waits for all chunks of the previous call of its side; only
+ *       inside lyra_hip_run_steps_dev, which has one id list for all its steps,
+ *       do the chunks run as independent pipelines).
  * Two-buffer rule for `_dev` callers: alternate two packet/PCM buffer sets
  * (step i uses set i & 1).  By (2) the encode that rewrites set i & 1 at step
  * i+2 is ordered after the decode that read it at step i.  A caller that

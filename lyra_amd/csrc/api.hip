@@ -128,6 +128,7 @@ struct lyra_hip_ctx {
   size_t lds_pad[6] = {};          // experiment hook, see lds_pad()
   int tile_div[6] = {1, 1, 1, 1, 1, 1};   // tiles per workgroup of each stage kernel (LYRA_TILE_LOOP), see tile_div()
   bool chunk_local = false;                       // see wait_encode_side
+  bool ids_stable = false;                        // inside lyra_hip_run_steps_dev, after its first step: see enc_cross_begin
   unsigned* d_rvq_stats = nullptr;                // rvq_encode_kernel: [0] frame-stages on the exact chain, [1] wavefront-stages (debug_read 5)
   uint32_t cu_pat[4] = {0, 0, 0, 0};              // CU mask pattern of the e / d / q / n streams (0: none), see make_stream_kind
   int enc_noise_rate = 16000;                     // what the DTX encoder's NoiseEstimator::Create is given (lyra_hip_set_encoder_sample_rate)
@@ -347,8 +348,14 @@ struct ProfScope {
 //  * encode-side work on chunk k waits for every decode-side call except the most recent one, so a caller that
 //    alternates two buffers never has a buffer rewritten while a pending decode still reads it.
 // These edges ARE the encode -> decode dependency: every record / wait is checked, a failure fails the call.
+// Chunk k of a split call (LYRA_HIP_SUBBATCHES > 1) runs on a stream of its own.  Its streams' state was last written by
+// whichever chunk of the PREVIOUS call on this side held those streams: the same chunk only if the caller lists the same ids
+// in the same order again.  That is known inside lyra_hip_run_steps_dev (one id list for all its steps: ids_stable from the
+// second step on) -- there the chunks stay independent pipelines; every other call waits for all chunks of the call before it.
+// (Round 6: with a stream order that changed from call to call, chunk 0 of call n + 1 overtook chunk 1 of call n on the
+// streams that had moved between them -- tests/test_gpu_pipelined.py, found under a slower kernel build.)
 int enc_cross_begin(lyra_hip_ctx* c, int k, int nk_now) {
-  if (c->nsub > 1 && c->enc_last_nk && c->enc_last_nk != nk_now)
+  if (c->nsub > 1 && c->enc_last_nk && (c->enc_last_nk != nk_now || !c->ids_stable))
     for (int j = 0; j < c->nsub; ++j)
       if (c->se_last_set[j] && j != k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_se_last[j], 0));
   return 0;
@@ -455,7 +462,7 @@ int dec_side_begin(lyra_hip_ctx* c, int k, int nk_now = 1) {
   if (rc) return rc;
   if (c->nsub > 1 && c->n_dec_calls >= 1) {   // split differently from the previous decode-side call: after all of it
     const int prev = (int)((c->n_dec_calls - 1) & 1);
-    if (c->dec_nk_slot[prev] != nk_now)
+    if (c->dec_nk_slot[prev] != nk_now || !c->ids_stable)   // (or the ids may have moved between chunks: enc_cross_begin)
       for (int j = 0; j < c->nsub; ++j) HIPCHK(c, hipStreamWaitEvent(c->sd[k], c->ev_dec[prev][j], 0));
   }
   const long required = c->n_noise_calls - 1;   // all decoder-side noise calls but the most recent one
@@ -1671,12 +1678,13 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
   // the resamplers leave the codec's chains (resample_in_ahead / resample_deferred) in the default, unsplit configuration;
   // with sub-batches or strict call order they stay where the individual calls put them
   const bool rs_off_chain = rs && !c->serial && c->nsub == 1;
-  struct LocalScope { lyra_hip_ctx* c; ~LocalScope() { c->chunk_local = false; } } local_scope{c};
+  struct LocalScope { lyra_hip_ctx* c; ~LocalScope() { c->chunk_local = false; c->ids_stable = false; } } local_scope{c};
   c->chunk_local = c->nsub > 1 && !c->serial && enc && dec && !feats && !rs && !(F & (LYRA_HIP_STEP_DTX | LYRA_HIP_STEP_DECODER_NOISE)) &&
                    !getenv("LYRA_HIP_NO_CHUNK_LOCAL");
   for (int i = 0; i < S->n_steps; ++i) {
     const long step = S->first_step + i;
     const int set = (int)(step & 1);
+    c->ids_stable = i > 0;   // one id list for every step of this call
     if (enc) {
       const int16_t* in = S->d_pcm_ring + (size_t)(step % S->ring) * B * (size_t)n_ext;
       if (rs && !rs_off_chain) {   // lyra_encoder.cc:119-122: external rate -> 16 kHz, the encoder's own resampler
