@@ -122,10 +122,13 @@ def _build_fake_demo(tmp_path):
     """decoder_demo + lyra_batch_codec.cc against tests/host_stub/fake_lyra_hip_codec.cc (no GPU, no product library)."""
     host = os.path.join(ROOT, "lyra_amd", "host")
     exe = str(tmp_path / "decoder_demo_fake")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + host, "-I" + os.path.join(host, "shims"), "-I" + ROOT, "-o", exe,
-                           os.path.join(host, "decoder_demo.cc"), os.path.join(host, "lyra_batch_codec.cc"),
+    subprocess.check_call(["g++"] + _FAKE_DEMO_FLAGS + ["-std=c++17", "-I" + host, "-I" + os.path.join(host, "shims"), "-I" + ROOT,
+                           "-o", exe, os.path.join(host, "decoder_demo.cc"), os.path.join(host, "lyra_batch_codec.cc"),
                            os.path.join(ROOT, "tests", "host_stub", "fake_lyra_hip_codec.cc")])
     return exe
+
+
+_FAKE_DEMO_FLAGS = ["-O2"]
 
 
 @pytest.mark.parametrize("pipelined", [False, True])
@@ -180,6 +183,20 @@ def test_batch_codec_host_logic_against_fake_abi(tmp_path, rate, bitrate, dtx, p
                 assert np.array_equal(got[s_], want), f"tick {t}, stream {s_}, DecodeSamples({k})"
                 saw_cng = saw_cng or decs[s_].is_comfort_noise()
     assert pos == out.size and saw_cng and (saw_empty == dtx)
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_batch_codec_host_logic_under_address_and_ub_sanitizers(tmp_path, monkeypatch, pipelined):
+    """The same sessions with the twins' host code built with -fsanitize=address,undefined (CPU only): any report aborts
+    the demo, which fails the session."""
+    probe = subprocess.run(["g++", "-fsanitize=address,undefined", "-x", "c++", "-", "-o", str(tmp_path / "probe")],
+                           input="int main(){return 0;}", capture_output=True, text=True)
+    if probe.returncode != 0:
+        pytest.skip("no sanitizer runtimes for g++ here")
+    monkeypatch.setitem(globals(), "_FAKE_DEMO_FLAGS", ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"])
+    monkeypatch.setenv("ASAN_OPTIONS", "detect_leaks=1:abort_on_error=1")
+    test_batch_codec_host_logic_against_fake_abi(tmp_path, 48000, 3200, True, pipelined)
+    test_batch_codec_host_logic_against_fake_abi(tmp_path, 8000, 9200, False, pipelined)
 
 
 def test_file_transcode_host_logic_against_fake_abi(tmp_path):
