@@ -378,6 +378,8 @@ class LyraHip:
         if features is not None:
             features = _np(features, np.float32, (-1, NUM_MEL))
             B = features.shape[0]
+        elif B is None and stream_ids is not None:
+            B = len(stream_ids)
         ids = self._ids(stream_ids, B)
         out = np.empty((B, HOP), np.int16)
         self._chk(self.L.lyra_hip_comfort_noise(self.h, ids.ctypes.data, B,

@@ -1,0 +1,190 @@
+"""Differential test of the library's ordering rules (include/lyra_hip.h "Streams" (1)-(3)): random sequences of hops, each over
+a random subset of the streams in a random order, issued through a randomly chosen entry point -- blocking host calls, `_dev`
+calls on torch tensors, lyra_hip_run_steps_dev, the two-deep pipelined begin / end pairs -- and resets in between, on
+contexts that split batches over 1, 2 or 4 stream sets.  A second context runs the same hops through the plain blocking
+calls, unsplit; every packet and every sample must agree.  (Round 6: a split context let chunk 0 of a call overtake chunk 1 of
+the previous call on streams that had moved between them; nothing in the suite changed the stream order between calls.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N = 512
+
+
+@pytest.mark.parametrize("seed,sub_batches,bits", [(0, 1, 120), (1, 2, 184), (2, 2, 64), (3, 4, 120), (4, 2, 120)])
+def test_random_call_sequences_equal_the_blocking_reference(seed, sub_batches, bits):
+    import torch
+    import lyra_amd
+    from lyra_amd.codec import packet_size
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    ref = lyra_amd.LyraHip(max_streams=N)
+    x = lyra_amd.LyraHip(max_streams=N, sub_batches=sub_batches)
+    dev = torch.device("cuda", 0)
+    nb = packet_size(bits)
+
+    def subset():
+        B = int(rng.choice([3, 40, 64, 129, 130, 257, 300, 511, 512]))
+        return rng.permutation(N)[:B].astype(np.int32)
+
+    def audio(B, hops=1):
+        return rng.integers(-15000, 15000, size=(hops, B, 320)).astype(np.int16)
+
+    def ref_hop(order, pcm):
+        pk = ref.encode(pcm, bits, order)
+        return pk, ref.decode(pk, bits, order)
+
+    counts = {}
+    try:
+        for op in range(70):
+            kind = rng.choice(["host", "dev", "steps", "pipelined", "reset"], p=[0.2, 0.25, 0.2, 0.25, 0.1])
+            counts[kind] = counts.get(kind, 0) + 1
+            what = f"op {op} ({kind}, seed {seed})"
+            if kind == "reset":
+                ids = subset()
+                ref.reset(ids); x.reset(ids)
+            elif kind == "host":
+                order = subset(); pcm = audio(order.size)[0]
+                want_pk, want = ref_hop(order, pcm)
+                pk = x.encode(pcm, bits, order)
+                assert np.array_equal(pk, want_pk), what
+                assert np.array_equal(x.decode(pk, bits, order), want), what
+            elif kind == "dev":
+                order = subset(); pcm = audio(order.size)[0]
+                want_pk, want = ref_hop(order, pcm)
+                d_ids = torch.from_numpy(order).to(dev)
+                d_pcm = torch.from_numpy(pcm).to(dev)
+                d_pk = torch.zeros((order.size, nb), dtype=torch.uint8, device=dev)
+                d_out = torch.zeros((order.size, 320), dtype=torch.int16, device=dev)
+                x.encode_dev(d_ids, d_pcm, bits, d_pk)
+                x.decode_dev(d_ids, d_pk, bits, d_out)
+                assert np.array_equal(d_pk.cpu().numpy(), want_pk), what
+                assert np.array_equal(d_out.cpu().numpy(), want), what
+            elif kind == "steps":
+                order = subset(); n = int(rng.integers(1, 4)); pcm = audio(order.size, n)
+                for t in range(n):
+                    want_pk, want = ref_hop(order, pcm[t])
+                d_ids = torch.from_numpy(order).to(dev)
+                ring = torch.from_numpy(pcm).to(dev)
+                d_pk = [torch.zeros((order.size, nb), dtype=torch.uint8, device=dev) for _ in range(2)]
+                d_out = [torch.zeros((order.size, 320), dtype=torch.int16, device=dev) for _ in range(2)]
+                x.run_steps_dev(d_ids, bits, n, first_step=0, d_pcm_ring=ring, d_packets=d_pk, d_pcm_out=d_out)
+                last = (n - 1) & 1
+                assert np.array_equal(d_pk[last].cpu().numpy(), want_pk), what
+                assert np.array_equal(d_out[last].cpu().numpy(), want), what
+            else:   # two hops in flight on each side, the second over another subset in another order
+                oa, ob = subset(), subset()
+                pa, pb = audio(oa.size)[0], audio(ob.size)[0]
+                wa_pk = ref.encode(pa, bits, oa); wb_pk = ref.encode(pb, bits, ob)
+                wa = ref.decode(wa_pk, bits, oa); wb = ref.decode(wb_pk, bits, ob)
+                x.encode_begin(pa, bits, oa); x.encode_begin(pb, bits, ob)
+                ga_pk = x.encode_end()[0]; gb_pk = x.encode_end()[0]
+                assert np.array_equal(ga_pk, wa_pk) and np.array_equal(gb_pk, wb_pk), what
+                x.decode_begin(ga_pk, bits, oa); x.decode_begin(gb_pk, bits, ob)
+                ga = x.decode_end(); gb = x.decode_end()
+                assert np.array_equal(ga, wa) and np.array_equal(gb, wb), what
+        assert len(counts) == 5, counts
+    finally:
+        ref.close(); x.close()
+
+
+@pytest.mark.parametrize("seed,sub_batches", [(0, 1), (1, 2), (2, 2), (3, 4)])
+def test_random_sequences_around_the_codec_equal_the_blocking_reference(seed, sub_batches):
+    """The same game with the stateful pieces around the two networks -- encoder-side resampler + DTX encoder (its noise
+    estimator), decoder, decoder-side noise estimator, decoder-side resampler, comfort noise -- through host calls, `_dev`
+    calls and the pipelined 48 kHz DTX encode, 48 kHz outside, quiet stretches so that DTX decisions flip."""
+    import torch
+    import lyra_amd
+    from lyra_amd.codec import packet_size
+    bits = 120
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    ref = lyra_amd.LyraHip(max_streams=N)
+    x = lyra_amd.LyraHip(max_streams=N, sub_batches=sub_batches)
+    for c in (ref, x):
+        c.set_encoder_sample_rate(48000)
+        c.set_cng_seed(7)
+    dev = torch.device("cuda", 0)
+    nb = packet_size(bits)
+    quiet = rng.permutation(N)[:N // 5]          # a fifth of the streams only ever hear room noise
+
+    def subset():
+        B = int(rng.choice([7, 64, 129, 256, 300, 512]))
+        return rng.permutation(N)[:B].astype(np.int32)
+
+    def audio48(order):
+        a = rng.integers(-15000, 15000, size=(order.size, 960)).astype(np.int16)
+        a[np.isin(order, quiet)] //= 1500
+        return a
+
+    def ref_hop(order, a48):
+        a16 = ref.resample(a48, 48000, 16000, order, side="encoder")
+        pk, lens = ref.encode_dtx(a16, bits, order)
+        got = lens > 0
+        out = np.zeros((order.size, 320), np.int16)
+        noise = np.zeros(order.size, np.int32)
+        if got.any():      # the application hands over the packets that exist (lyra_decoder.cc: SetEncodedPacket, DecodeSamples)
+            out[got] = ref.decode(pk[got], bits, order[got])
+            noise[got] = ref.noise_receive(out[got], order[got], side="decoder")
+        if (~got).any():   # ... and plays comfort noise from the decoder-side estimate for the others
+            out[~got] = ref.comfort_noise(None, order[~got])
+        return pk, lens, out, noise, ref.resample(out, 16000, 48000, order, side="decoder")
+
+    try:
+        flips = 0
+        for op in range(50):
+            kind = rng.choice(["host", "dev", "pipelined", "reset"], p=[0.3, 0.35, 0.25, 0.1])
+            what = f"op {op} ({kind}, seed {seed})"
+            if kind == "reset":
+                ids = subset()
+                ref.reset(ids); x.reset(ids)
+                continue
+            order = subset(); a48 = audio48(order)
+            w_pk, w_len, w_out, w_noise, w_out48 = ref_hop(order, a48)
+            flips += int((w_len == 0).any() and (w_len > 0).any())
+            got = w_len > 0
+            if kind == "host":
+                a16 = x.resample(a48, 48000, 16000, order, side="encoder")
+                pk, lens = x.encode_dtx(a16, bits, order)
+            elif kind == "pipelined":
+                x.encode_begin(a48, bits, order, sample_rate_hz=48000, dtx=True)
+                pk, lens = x.encode_end()
+            else:
+                d_ids = torch.from_numpy(order).to(dev)
+                d16 = torch.zeros((order.size, 320), dtype=torch.int16, device=dev)
+                d_pk = torch.zeros((order.size, nb), dtype=torch.uint8, device=dev)
+                d_len = torch.zeros(order.size, dtype=torch.int32, device=dev)
+                x.resample_dev(d_ids, torch.from_numpy(a48).to(dev), 48000, 16000, d16, side="encoder")
+                x.encode_dtx_dev(d_ids, d16, bits, d_pk, d_len)
+                pk, lens = d_pk.cpu().numpy(), d_len.cpu().numpy()
+            assert np.array_equal(lens, w_len), what
+            assert np.array_equal(pk[got], w_pk[got]), what
+            out = np.zeros((order.size, 320), np.int16)
+            noise = np.zeros(order.size, np.int32)
+            if kind == "dev" and got.any():
+                g_ids = torch.from_numpy(order[got]).to(dev)
+                g_out = torch.zeros((int(got.sum()), 320), dtype=torch.int16, device=dev)
+                g_noise = torch.zeros(int(got.sum()), dtype=torch.int32, device=dev)
+                x.decode_dev(g_ids, torch.from_numpy(pk[got]).to(dev), bits, g_out)
+                x.noise_receive_dev(g_ids, g_out, g_noise, side="decoder")
+                out[got], noise[got] = g_out.cpu().numpy(), g_noise.cpu().numpy()
+            elif got.any():
+                out[got] = x.decode(pk[got], bits, order[got])
+                noise[got] = x.noise_receive(out[got], order[got], side="decoder")
+            if (~got).any():
+                if kind == "dev":
+                    c_out = torch.zeros((int((~got).sum()), 320), dtype=torch.int16, device=dev)
+                    x.comfort_noise_dev(torch.from_numpy(order[~got]).to(dev), None, c_out)
+                    out[~got] = c_out.cpu().numpy()
+                else:
+                    out[~got] = x.comfort_noise(None, order[~got])
+            assert np.array_equal(out, w_out), what
+            assert np.array_equal(noise, w_noise), what
+            if kind == "dev":
+                d48 = torch.zeros((order.size, 960), dtype=torch.int16, device=dev)
+                x.resample_dev(torch.from_numpy(order).to(dev), torch.from_numpy(out).to(dev), 16000, 48000, d48, side="decoder")
+                out48 = d48.cpu().numpy()
+            else:
+                out48 = x.resample(out, 16000, 48000, order, side="decoder")
+            assert np.array_equal(out48, w_out48), what
+        assert flips > 5, "the session never mixed empty and full packets"
+    finally:
+        ref.close(); x.close()
