@@ -11,8 +11,10 @@ pytestmark = pytest.mark.gpu
 N = 512
 
 
-@pytest.mark.parametrize("seed,sub_batches,bits", [(0, 1, 120), (1, 2, 184), (2, 2, 64), (3, 4, 120), (4, 2, 120)])
-def test_random_call_sequences_equal_the_blocking_reference(seed, sub_batches, bits):
+@pytest.mark.parametrize("seed,sub_batches,bits,N", [(0, 1, 120, 512), (1, 2, 184, 512), (2, 2, 64, 512), (3, 4, 120, 512),
+                                                      (4, 2, 120, 512), (5, 2, 120, 2048), (6, 4, 184, 2048)])
+def test_random_call_sequences_equal_the_blocking_reference(seed, sub_batches, bits, N):
+    # (N <= 1024: the contexts partition the chip between the two sides with CU masks; N = 2048: they do not)
     import torch
     import lyra_amd
     from lyra_amd.codec import packet_size
@@ -23,7 +25,7 @@ def test_random_call_sequences_equal_the_blocking_reference(seed, sub_batches, b
     nb = packet_size(bits)
 
     def subset():
-        B = int(rng.choice([3, 40, 64, 129, 130, 257, 300, 511, 512]))
+        B = int(rng.choice([3, 40, 64, 129, 130, 257, 300, N - 1, N]))
         return rng.permutation(N)[:B].astype(np.int32)
 
     def audio(B, hops=1):
