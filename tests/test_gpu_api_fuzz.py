@@ -190,3 +190,73 @@ def test_random_sequences_around_the_codec_equal_the_blocking_reference(seed, su
         assert flips > 5, "the session never mixed empty and full packets"
     finally:
         ref.close(); x.close()
+
+
+@pytest.mark.parametrize("seed,sub_batches", [(0, 1), (1, 2), (2, 4), (3, 2)])
+def test_run_steps_with_random_flags_equals_the_single_calls(seed, sub_batches):
+    """lyra_hip_run_steps_dev with random combinations of DTX, decoder-side noise estimator and a 48 kHz outside, over random
+    subsets, on contexts that split batches -- against the same hops issued one `_dev` call at a time on an unsplit context
+    (lyra_hip.h: what one step is made of)."""
+    import torch
+    import lyra_amd
+    from lyra_amd.codec import packet_size
+    N, bits = 512, 120
+    rng = np.random.Generator(np.random.PCG64(3000 + seed))
+    ref = lyra_amd.LyraHip(max_streams=N)
+    x = lyra_amd.LyraHip(max_streams=N, sub_batches=sub_batches)
+    dev = torch.device("cuda", 0)
+    nb = packet_size(bits)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    try:
+        for call in range(24):
+            B = int(rng.choice([9, 64, 130, 256, 300, 512]))
+            order = rng.permutation(N)[:B].astype(np.int32)
+            dtx, dnoise, rate = bool(rng.integers(2)), bool(rng.integers(2)), int(rng.choice([16000, 48000]))
+            n = int(rng.integers(1, 5))
+            what = f"call {call}: B {B}, {n} steps, dtx {dtx}, decoder noise {dnoise}, {rate} Hz (seed {seed})"
+            n_ext = 320 * rate // 16000
+            pcm = rng.integers(-15000, 15000, size=(n, B, n_ext)).astype(np.int16)
+            pcm[:, : B // 4] //= 1500
+            for c in (ref, x):
+                c.set_encoder_sample_rate(rate)
+            d_ids = torch.from_numpy(order).to(dev)
+            ring = torch.from_numpy(pcm).to(dev)
+            bufs = {}
+            for name in ("ref", "x"):
+                bufs[name] = dict(pk=[z((B, nb), torch.uint8) for _ in range(2)], out=[z((B, 320), torch.int16) for _ in range(2)],
+                                  ln=[z((B,), torch.int32) for _ in range(2)], ext=[z((B, n_ext), torch.int16) for _ in range(2)],
+                                  noise=z((B,), torch.int32))
+            r = bufs["ref"]
+            d16 = z((B, 320), torch.int16)
+            for t in range(n):          # one step, call by call (api.hip lyra_hip_run_steps_dev)
+                s = t & 1
+                src = ring[t]
+                if rate != 16000:
+                    ref.resample_dev(d_ids, ring[t], rate, 16000, d16, side="encoder")
+                    src = d16
+                if dtx:
+                    ref.encode_dtx_dev(d_ids, src, bits, r["pk"][s], r["ln"][s])
+                else:
+                    ref.encode_dev(d_ids, src, bits, r["pk"][s])
+                ref.decode_dev(d_ids, r["pk"][s], bits, r["out"][s])
+                if dnoise:
+                    ref.noise_receive_dev(d_ids, r["out"][s], r["noise"], side="decoder")
+                if rate != 16000:
+                    ref.resample_dev(d_ids, r["out"][s], 16000, rate, r["ext"][s], side="decoder")
+                ref.synchronize()       # (one buffer for d16: the next step's resampler must not overtake this step's encoder)
+            b = bufs["x"]
+            x.run_steps_dev(d_ids, bits, n, first_step=0, d_pcm_ring=ring, d_packets=b["pk"], d_pcm_out=b["out"],
+                            d_packet_bytes=b["ln"] if dtx else None, d_is_noise=b["noise"] if dnoise else None,
+                            external_rate=rate, d_ext_out=b["ext"] if rate != 16000 else None, dtx=dtx, decoder_noise=dnoise)
+            x.synchronize()
+            for s in range(min(n, 2)):
+                assert torch.equal(b["pk"][s], r["pk"][s]), what + f": packets, set {s}"
+                assert torch.equal(b["out"][s], r["out"][s]), what + f": PCM, set {s}"
+                if dtx:
+                    assert torch.equal(b["ln"][s], r["ln"][s]), what + f": packet lengths, set {s}"
+                if rate != 16000:
+                    assert torch.equal(b["ext"][s], r["ext"][s]), what + f": external-rate PCM, set {s}"
+            if dnoise:
+                assert torch.equal(b["noise"], r["noise"]), what + ": is_noise"
+    finally:
+        ref.close(); x.close()
