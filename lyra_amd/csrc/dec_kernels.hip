@@ -34,6 +34,7 @@ __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_kernel(const DecS0
                                                        uint8_t* __restrict__ state, float* __restrict__ out0,
                                                        const uint8_t* __restrict__ packets, int num_stages,
                                                        const float* __restrict__ cb, int code_bytes, int tile0) {
+  LYRA_STRESS(4);
   if (((int)blockIdx.x + tile0) * SD0 >= B) return;
   dec_s0_body<0>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_dr_kernel(const De
                                                           uint8_t* __restrict__ state, float* __restrict__ out0,
                                                           const uint8_t* __restrict__ packets, int num_stages,
                                                           const float* __restrict__ cb, int code_bytes, int tile0) {
+  LYRA_STRESS(4);
   if (((int)blockIdx.x + tile0) * SD0 >= B) return;
   dec_s0_body<1>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(NTD0, LYRA_I8_WAVES) void dec_s0_bm_kernel(const De
                                                           uint8_t* __restrict__ state, float* __restrict__ out0,
                                                           const uint8_t* __restrict__ packets, int num_stages,
                                                           const float* __restrict__ cb, int code_bytes, int tile0) {
+  LYRA_STRESS(4);
   if (((int)blockIdx.x + tile0) * SD0 >= B) return;
   dec_s0_body<3>(Pp, feats, ids, B, state, out0, packets, num_stages, cb, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(NTD0, LYRA_D0XN_WAVES) void dec_s0_xn_kernel(const 
                                                           uint8_t* __restrict__ state, float* __restrict__ out0,
                                                           const uint8_t* __restrict__ packets, int num_stages,
                                                           const float* __restrict__ cb, int code_bytes, int tile0) {
+  LYRA_STRESS(4);
   if (((int)blockIdx.x + tile0) * SD0 >= B) return;
 #ifdef LYRA_I8_PRIO
   __builtin_amdgcn_s_setprio(LYRA_I8_PRIO);
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(NTD1, NTD1 == 512 ? 4 : 3) void dec_s1_kernel(const
                                                                           const int32_t* __restrict__ ids, int B,
                                                                           uint8_t* __restrict__ state, float* __restrict__ out1,
                                                                           int code_bytes, int tile0) {
+  LYRA_STRESS(5);
   if (((int)blockIdx.x + tile0) * SD1 >= B) return;
   dec_s1_body(*Pp, in0, ids, B, state, out1, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -94,6 +99,7 @@ __global__ __launch_bounds__(64 * SD2, LYRA_C64_WAVES) void dec_s2_kernel(const 
                                                             const int32_t* __restrict__ ids, int B,
                                                             uint8_t* __restrict__ state, int16_t* __restrict__ pcm,
                                                             int code_bytes, int tile0) {
+  LYRA_STRESS(6);
   if (((int)blockIdx.x + tile0) * SD2 >= B) return;
   dec_s2_body<SD2>(*Pp, in1, ids, B, state, pcm, code_bytes, (int)blockIdx.x + tile0);
 }

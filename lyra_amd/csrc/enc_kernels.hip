@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64 * S0, LYRA_C64_WAVES) void enc_s0_kernel(const E
                                                            const int32_t* __restrict__ ids, int B,
                                                            uint8_t* __restrict__ state, float* __restrict__ out0,
                                                            int code_bytes, int tile0) {
+  LYRA_STRESS(0);
   if (((int)blockIdx.x + tile0) * S0 >= B) return;
   enc_s0_body<S0>(*Pp, pcm, ids, B, state, out0, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(NT1, NT1 == 512 ? 4 : 3) void enc_s1_kernel(const E
                                                                         const int32_t* __restrict__ ids, int B,
                                                                         uint8_t* __restrict__ state, float* __restrict__ out1,
                                                                         int code_bytes, int tile0) {
+  LYRA_STRESS(1);
   if (((int)blockIdx.x + tile0) * S1 >= B) return;
   enc_s1_body(*Pp, in0, ids, B, state, out1, code_bytes, (int)blockIdx.x + tile0);
 }

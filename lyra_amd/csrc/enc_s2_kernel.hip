@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_kernel(const EncS2P
                                                       const int32_t* __restrict__ ids, int B,
                                                       uint8_t* __restrict__ state, float* __restrict__ feats,
                                                       float* __restrict__ codes_dbg, int code_bytes, int tile0) {
+  LYRA_STRESS(2);
   if (((int)blockIdx.x + tile0) * S2 >= B) return;
   enc_s2_body<0>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_dr_kernel(const Enc
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ feats,
                                                          float* __restrict__ codes_dbg, int code_bytes, int tile0) {
+  LYRA_STRESS(2);
   if (((int)blockIdx.x + tile0) * S2 >= B) return;
   enc_s2_body<1>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(NT2, LYRA_I8_WAVES) void enc_s2_bm_kernel(const Enc
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ feats,
                                                          float* __restrict__ codes_dbg, int code_bytes, int tile0) {
+  LYRA_STRESS(2);
   if (((int)blockIdx.x + tile0) * S2 >= B) return;
   enc_s2_body<3>(Pp, in1, ids, B, state, feats, codes_dbg, code_bytes, (int)blockIdx.x + tile0);
 }
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(NT2, LYRA_E2XN_WAVES) void enc_s2_xn_kernel(const E
                                                          const int32_t* __restrict__ ids, int B,
                                                          uint8_t* __restrict__ state, float* __restrict__ feats,
                                                          float* __restrict__ codes_dbg, int code_bytes, int tile0) {
+  LYRA_STRESS(2);
   if (((int)blockIdx.x + tile0) * S2 >= B) return;
 #ifdef LYRA_I8_PRIO   // experiment: the int8 stages are latency chains with little issue demand -- let them go first
   __builtin_amdgcn_s_setprio(LYRA_I8_PRIO);

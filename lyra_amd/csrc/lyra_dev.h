@@ -57,6 +57,16 @@ static __device__ long long g_lyra_wgtrace[2048 * 4];
 #define LYRA_TSTAMP2(i) do { } while (0)
 #endif
 
+// -DLYRA_STRESS_DELAY=mask: ORDERING STRESS build (results must not change): kernel family `bit` sleeps ~0.2 ms at its start
+// (0-2 encoder stages, 3 quantizer, 4-6 decoder stages, 7 log-mel / noise estimator, 8 resampler, 9 comfort noise, 10 twin
+// helpers, 11 rvq_decode), which moves every kernel of the family against the other streams -- a missing cross-stream
+// edge then shows in the parity / fuzz tests (profiles/r06_stress_matrix.txt).
+#ifdef LYRA_STRESS_DELAY
+#define LYRA_STRESS(bit) do { if (((LYRA_STRESS_DELAY) >> (bit)) & 1) for (int i_ = 0; i_ < 60; ++i_) __builtin_amdgcn_s_sleep(127); } while (0)
+#else
+#define LYRA_STRESS(bit) do { } while (0)
+#endif
+
 namespace lyra {
 
 __host__ __device__ constexpr int at16(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }

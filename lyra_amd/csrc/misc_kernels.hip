@@ -222,6 +222,7 @@ __global__ __launch_bounds__(64) void rvq_encode_kernel(const float* __restrict_
                                                         int32_t* __restrict__ indices, uint8_t* __restrict__ packets,
                                                         const int32_t* __restrict__ mask_ids,
                                                         int32_t* __restrict__ packet_bytes, unsigned* __restrict__ stats) {
+  LYRA_STRESS(3);
   __shared__ __attribute__((aligned(16))) float rs[16 * 68];   // residuals of the tile, [frame][64 (+4 pad)]: exact path / prologue
   __shared__ int win[16];                                       // exact path: winners by frame
 #ifdef LYRA_RVQ_PRIO   // experiment: the quantizer's lone wavefronts win the issue arbitration against the co-resident stage kernels
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const float* __restrict
                                                           const int32_t* __restrict__ indices,
                                                           const uint8_t* __restrict__ packets, int num_stages, int B,
                                                           float* __restrict__ feats) {
+  LYRA_STRESS(11);
   const int d = threadIdx.x & 63;
   const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (frame >= B) return;
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const MelP* __restrict__ Pp
                                                       float* __restrict__ mel, int noise_tail, NoiseP NP,
                                                       int32_t* __restrict__ is_noise_out,
                                                       int32_t* __restrict__ masked_ids) {
+  LYRA_STRESS(7);
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   const MelP& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
@@ -782,6 +785,7 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseP P, const int32
                                                             uint8_t* __restrict__ state, const float* __restrict__ mel,
                                                             int32_t* __restrict__ is_noise_out,
                                                             int32_t* __restrict__ masked_ids) {
+  LYRA_STRESS(7);
   const int w = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + w;
   const bool on = b < B;
@@ -817,6 +821,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleP P, const int32_
                                                         uint8_t* __restrict__ state, const int16_t* __restrict__ in,
                                                         int n_in, int in_stride, int16_t* __restrict__ out, int n_out,
                                                         int out_stride) {
+  LYRA_STRESS(8);
   extern __shared__ __attribute__((aligned(16))) float rsb_all[];   // [4][RS_TAPS - 1 + n_in, padded to 4]
   constexpr int H = st::RS_TAPS - 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -887,6 +892,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleP P, const int32_
 // dst[ids[b]][0..320) = src[b][0..320): a dense batch result into the by-id hop buffer (8 bytes per thread)
 __global__ __launch_bounds__(128) void twin_scatter_kernel(const int16_t* __restrict__ src, const int32_t* __restrict__ ids,
                                                             int B, int16_t* __restrict__ dst) {
+  LYRA_STRESS(10);
   const int b = blockIdx.x, t = threadIdx.x;
   if (t < 80) reinterpret_cast<uint2*>(dst + (size_t)ids[b] * 320)[t] = reinterpret_cast<const uint2*>(src + (size_t)b * 320)[t];
 }
@@ -902,6 +908,7 @@ __global__ __launch_bounds__(256) void twin_assemble_kernel(const TwinSlice* __r
                                                              const int16_t* __restrict__ cng,
                                                              const float* __restrict__ fade_w, int16_t* __restrict__ out,
                                                              int out_stride, int16_t* __restrict__ noise_dense) {
+  LYRA_STRESS(10);
   const TwinSlice s = slices[blockIdx.x];
   const int n = s.gen_n > s.cng_n ? s.gen_n : s.cng_n;
   const int16_t* g = gan + (size_t)s.id * 320 + s.gan_off;
@@ -943,6 +950,7 @@ __global__ __launch_bounds__(256) void cng_kernel(const MelP* __restrict__ Pp, u
                                                    const int32_t* __restrict__ ids, int B,
                                                    uint8_t* __restrict__ state, const uint8_t* __restrict__ noise_state,
                                                    const float* __restrict__ features, int16_t* __restrict__ pcm) {
+  LYRA_STRESS(9);
   const MelP& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   double* re = dsm;
