@@ -156,6 +156,8 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  *                            decoder chain first -- better for blocking decode calls beside an encoder, bimodal for the `_dev` pipeline);
  *   LYRA_HIP_TILE_DIV_<K>=k  launch stage kernel K (ENC_S0 .. DEC_S2) as k slices of its tiles,
  *   LYRA_HIP_LDS_PAD_<K>=b   give its workgroups b extra bytes of LDS (occupancy experiments). */
+/* max_streams: 1 .. 289,262 per context (per-stream state is addressed with 32-bit byte offsets; 83 KB of state per stream,
+ * so that is 24 GB of the 288 -- more streams: more contexts). */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
 /* The same from an in-memory lyra_v1.lyrapack image (e.g. read once by rank 0 and broadcast to the other GPUs' ranks
  * over RCCL); the image is copied, the caller keeps ownership. */

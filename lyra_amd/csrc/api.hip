@@ -734,6 +734,14 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   if (!out || max_streams <= 0 || (requant_mode < 0 || requant_mode > 3))
     return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create: bad argument");
   *out = nullptr;
+  {   // the kernels address a stream's state as a 32-bit byte offset into its region (lyra_dev.h goff): id * region bytes
+    int worst = 0;
+    for (int r = 0; r < st::R_COUNT; ++r) worst = std::max(worst, st::REGION_BYTES[r]);
+    const long long cap = (1ll << 32) / worst;
+    if (max_streams > cap)
+      return fail(nullptr, LYRA_HIP_EINVAL, "lyra_hip_create: max_streams %d, at most %lld streams per context (32-bit byte "
+                  "offsets into the per-stream state: use several contexts)", max_streams, cap);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
     return fail(nullptr, LYRA_HIP_ENODEV, "no HIP device %d (count %d); this library has no CPU path", device, ndev);

@@ -46,6 +46,20 @@ def test_no_cpu_fallback(lib):
         lyra_amd.LyraHip()
 
 
+def test_create_refuses_more_streams_than_32_bit_state_offsets_hold(lib):
+    """The kernels address a stream's state as id * region bytes in 32 bits: a context of more streams than that is refused at
+    creation (with or without a GPU -- the check comes first), not left to wrap around."""
+    import lyra_amd
+    h = ctypes.c_void_p()
+    lib.lyra_hip_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_void_p)]
+    lib.lyra_hip_last_error.restype = ctypes.c_char_p
+    rc = lib.lyra_hip_create(lyra_amd.default_model_dir().encode(), 0, 300000, 0, ctypes.byref(h))
+    assert rc == -1 and not h.value, rc          # LYRA_HIP_EINVAL
+    msg = lib.lyra_hip_last_error(None)
+    assert b"at most" in msg and b"289262" in msg, msg
+
+
 def test_product_does_not_touch_the_oracle():
     """The product path must not import, link or call anything under oracle/."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "lyra_amd")):
