@@ -122,7 +122,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 PEAK_I8_MFMA_TOPS = 3944.0      # same guide: v_mfma_i32_16x16x64_i8, dense
 PEAK_F32_VALU_TFLOPS = 157.3    # same guide: FP32 vector, counted as FMA (2 flops per lane-instruction)
 PEAK_F32_VALU_TOPS = 78.65      # the same issue rate for non-FMA vector work (sub / mul / add, one flop each): what the
-                                # quantizer's distance search consists of (profiles/r03_valu_probe.txt: v_pk_*_f32 do
+                                # quantizer's distance search consists of (profiles/history/r03_valu_probe.txt: v_pk_*_f32 do
                                 # not double it on this part)
 PEAK_F64_VALU_TFLOPS = 78.6     # CDNA4 FP64 vector (half the fp32 rate)
 PEAK_HBM_GBS = 8000.0
@@ -153,7 +153,7 @@ def parse(argv=None):
     ap.add_argument("--ramp-steps", type=int, default=64,
                     help="extra UNTIMED steps enqueued right before the timed region so that it starts on a chip at its "
                          "loaded clocks: after >= 20 ms of idling a 20-step region runs 14 %% slower "
-                         "(profiles/r03_idle_gap_probe.txt); 0: none")
+                         "(profiles/history/r03_idle_gap_probe.txt); 0: none")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N in ONE process: a host thread and a context per GPU, no process group")
     ap.add_argument("--bcast-weights", action="store_true",
@@ -416,7 +416,7 @@ def load_issue_time(names):
             vector += (c["SQ_INSTS_VALU"] - c.get("SQ_INSTS_MFMA", 0.0)) * per / simds / clk
         return {"matrix_pipe_us_per_step_at_B4096": round(matrix * 1e6, 1), "vector_issue_us_per_step_at_B4096": round(vector * 1e6, 1),
                 "source": "offline: SQ counters of profiles/r06_pmc_sq.txt at 2.06 GHz; vector instructions do not hide under "
-                          "MFMAs on gfx950 (profiles/r03_mfma_valu_overlap_probe.txt), so a SIMD's time is at most the sum (round 6: vector issue overlaps the matrix pipe in part)"}
+                          "MFMAs on gfx950 (profiles/history/r03_mfma_valu_overlap_probe.txt), so a SIMD's time is at most the sum (round 6: vector issue overlaps the matrix pipe in part)"}
     except Exception:
         return None
 

@@ -402,6 +402,9 @@ int encq_begin(lyra_hip_ctx* c, int k, int nk_now = 1) {
 struct EventList { hipEvent_t e[lyra_hip_ctx::KMAX]; int n = 0; };
 EventList encq_buffer_free(lyra_hip_ctx* c, int k, int nk_now) {
   EventList l;
+#ifdef LYRA_ABL_NO_FEAT_WAIT   // TIMING-ONLY ablation (a race): the extractor's last stage does not wait -- what a deeper feature ring
+  return l;                    // with one wait per several steps could return at most (profiles/r06_ab_t1_featwait.txt)
+#endif
   if (c->n_encq_calls < 2) return l;
   const int p = (int)(c->n_encq_calls & 1), nk_then = c->encq_nk[p];
   if (nk_then == nk_now) { l.e[l.n++] = c->ev_encs[p][k]; return l; }
@@ -791,7 +794,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   // vector kernel that must not run beside decoder stage 0.  With the screened quantizer (round 4: 1.5 M instructions, one
   // wavefront per 16 frames) that reason is gone, and the decoder-first schedule turned out BIMODAL -- 0.290 or 0.305 ms
   // per step at B = 4096 from run to run on one box, depending on which chain ends up waiting for the other -- while the
-  // small quantizer at the highest priority and both chains equal gives 0.290-0.292 every time (profiles/r04_prio_ab2.txt,
+  // small quantizer at the highest priority and both chains equal gives 0.290-0.292 every time (profiles/history/r04_prio_ab2.txt,
   // r04_prio_ab4.txt; the decoder chain one level up is bimodal again: r04_prio_ab5.txt).  The price: a blocking decode call
   // no longer overtakes an encode running beside it -- BatchLyraEncoder + BatchLyraDecoder on two host threads 6.4 M
   // frames/s instead of 7.2 M (LYRA_HIP_PRIO=0,2,0 restores the old schedule for such a service).
@@ -804,12 +807,12 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
     for (int i = 0; i < 3; ++i) prio[i] = v[i] >= 2 ? prio_hi : (v[i] == 1 ? (prio_lo + prio_hi) / 2 : prio_lo);
   }
   const unsigned evflags = hipEventDisableTiming | (getenv("LYRA_HIP_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
-  // CU partitioning (placement_probe.hip (a probe of an earlier round, removed since: git history), profiles/r04_placement_probe.txt): two concurrent dispatches of <= 256
+  // CU partitioning (placement_probe.hip (a probe of an earlier round, removed since: git history), profiles/history/r04_placement_probe.txt): two concurrent dispatches of <= 256
   // workgroups are placed independently of each other -- of 2 x 128 workgroups 68 CUs get two and 68 none -- and a stage
   // kernel lasts as long as its slowest tile.  Streams created with complementary CU masks keep the chains apart.
   // The pattern is 32 bits repeated over the chip's CU mask; 0x00ff00ff / 0xff00ff00 give each side half of every XCD
   // whether the runtime numbers the mask bits XCC-major or interleaved (probe: 2 x 128 workgroups on 256 distinct CUs).
-  // Measured (profiles/r04_cumask_batch_sweep.txt): +10-14 % at 256-1,024 streams, +2-5 % at 2,048 (whole tiles per CU on
+  // Measured (profiles/history/r04_cumask_batch_sweep.txt): +10-14 % at 256-1,024 streams, +2-5 % at 2,048 (whole tiles per CU on
   // both halves), -4...-17 % at 1,536 and from 2,560 up (each chain then wants the whole chip in turn).  The choice is made
   // once, from max_streams: a context for at most 1,024 streams runs the extractor + quantizer on one half of every XCD
   // and the decoder + noise estimator on the other.  A masked stream has no priority (the chains no longer compete) and,

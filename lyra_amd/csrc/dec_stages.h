@@ -140,7 +140,12 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
           *reinterpret_cast<const f32x4*>(&FB[(2 * 16 + s) * FS + p4 * 4]);
   }
   LYRA_TSTAMP(81);
-  {  // conv k3 g4: per group [16 rows] x K=48 x N=128; LeakyReLU; QUANTIZE -> H8
+#ifdef LYRA_T1_ABL   // TIMING-ONLY ablation (results are wrong): odd tiles skip the GEMM phases of the T = 1 layers -- what a
+  const bool t1_skip = (tile & 1) != 0;   // 16-stream tile (twice the streams per 16-row MFMA tile) could return at most
+#else
+  constexpr bool t1_skip = false;
+#endif
+  if (!t1_skip) {  // conv k3 g4: per group [16 rows] x K=48 x N=128; LeakyReLU; QUANTIZE -> H8
     f32x4 acc[1][4];
     const int g = wave >> 1;
     auto aoff = [&](int i, int c) { return (c * 16 + m) * FS + g * 16 + q * 4; };
@@ -156,7 +161,7 @@ __device__ __forceinline__ void dec_s0_body(const DecS0P* __restrict__ Pp, const
   }
   __syncthreads();
   LYRA_TSTAMP(82);
-  {  // 4 grouped int8 transposed convs k4/s2 (one input row -> 4 output rows), carried tail of 2 rows
+  if (!t1_skip) {  // 4 grouped int8 transposed convs k4/s2 (one input row -> 4 output rows), carried tail of 2 rows
     i32x4 acc[1][8];
     const int g = wave >> 1;
     const TconvQ U = P.up0[g];

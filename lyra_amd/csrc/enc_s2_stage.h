@@ -184,8 +184,14 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
           *reinterpret_cast<const int*>(&QB4[((2 + t) * S2 + s) * QS + w4 * 4]);
   }
   LYRA_TSTAMP(7);
+#ifdef LYRA_T1_ABL   // TIMING-ONLY ablation (results are wrong): see dec_s0_body
+  const bool t1_skip = (tile & 1) != 0;
+  i32x4 dacc[1][4] = {};
+#else
+  constexpr bool t1_skip = false;
   i32x4 dacc[1][4];
-  {  // GEMM rows = streams (rows >= S are over-read padding and discarded)
+#endif
+  if (!t1_skip) {  // GEMM rows = streams (rows >= S are over-read padding and discarded)
     const int g = wave >> 1;
     auto aoff = [&](int i, int c) { return (c * S2 + m) * QS + g * 64 + q * 16; };
     gemm_i8<1, 4, 4>(QB4, aoff, P.down2.w + (wave * 4) * 4 * 64, dacc);
@@ -200,7 +206,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   }
   fold_rows8<2>(dacc[0]);   // lanes 32-63 take over N tiles 2, 3
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < (t1_skip ? 0 : 2); ++j) {
     int n = (wave * 4 + j + 2 * (lane >> 5)) * 16 + (lane & 15);
     int bias = as_global(P.down2.b)[n], M = as_global(P.down2.M)[n], sh = as_global(P.down2.sh)[n];
 #pragma unroll
@@ -220,7 +226,7 @@ __device__ __forceinline__ void enc_s2_body(const EncS2P* __restrict__ Pp, const
   }
   LYRA_TSTAMP(8);
   // ---- bottleneck conv k3 g4: per group K = 3*128, N = 16 -> 64 int8 codes ----------------------------
-  if (wave < 4) {
+  if (wave < 4 && !t1_skip) {
     i32x4 acc[1][1];
     const int g = wave;
     auto aoff = [&](int i, int c) { return ((c >> 1) * S2 + m) * QS5 + g * 128 + (c & 1) * 64 + q * 16; };

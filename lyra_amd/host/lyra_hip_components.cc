@@ -34,7 +34,7 @@ constexpr int kMaxBits = 4 * LYRA_HIP_MAX_STAGES;
 // are batch-invariant, tests/test_gpu_parity.py).
 //
 // Round 5 (the per-object path ran at 27-33 k hops/s on 64-1,024 threads, below the 42 k of the CPU oracle on the same
-// cores: profiles/r04_plugin_mt_throughput.txt -- batches of 10-60 requests and a condition variable that woke EVERY
+// cores: profiles/history/r04_plugin_mt_throughput.txt -- batches of 10-60 requests and a condition variable that woke EVERY
 // waiter of a kind after every batch):
 //  * every thread sleeps on a Waiter of its own and is woken exactly once, when its own request is done (or when it is
 //    handed the leadership); a finished batch is woken as a tree (the leader wakes the first kFan members, member i wakes

@@ -36,7 +36,7 @@
  * Canonical fp32 order (round 4: the order XNNPACK's f32 GEMM / IGEMM / DWCONV /
  * deconvolution micro-kernels compute on an FMA target -- held against real
  * XNNPACK code, 0 differing outputs on every fp32 layer of both graphs but the
- * last, tests/test_xnnpack_witness.py, profiles/r04_xnnpack_witness.txt):
+ * last, tests/test_xnnpack_witness.py, profiles/history/r04_xnnpack_witness.txt):
  *   conv      acc = bias; for tap (outer) for in-channel (inner):
  *                 acc = fmaf(x, w, acc)
  *   depthwise acc = bias; for tap: acc = fmaf(x, w, acc)

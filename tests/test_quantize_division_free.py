@@ -2,7 +2,7 @@
 correction instead of the IEEE division TFLite's AffineQuantize / the oracle's quantize_f perform).  Bit-exactness is
 proved by sweep, on the CPU, with the same IEEE operations the GPU executes (oracle/quantize_proof.c): every QUANTIZE
 scale either graph holds, every float of either sign in the 14 binades around the 256 code boundaries; with
-LYRA_PROOF_FULL=1 all 2^32 bit patterns per scale (a round-3 run of that is logged in profiles/r03_quantize_proof.txt).
+LYRA_PROOF_FULL=1 all 2^32 bit patterns per scale (a round-3 run of that is logged in profiles/history/r03_quantize_proof.txt).
 """
 import ctypes as C
 import os

@@ -8,7 +8,7 @@ flatbuffers' own quantisation parameters, one XNNPACK operator per TFLite operat
 operator, with the formulas the oracle (and, through the golden fixtures, the GPU kernels) use in mode "xnnpack".
 
 It is a WITNESS, not the binary of record: newer than the XNNPACK commit TensorFlow 2.11 pins, x86 micro-kernels.  What it
-settles (profiles/r04_xnnpack_witness.txt has the table):
+settles (profiles/history/r04_xnnpack_witness.txt has the table):
   * QS8 convolutions requantise in fp32, RNE(float(acc) * scale) -- not the Q31 single rounding ("exact") the survey took for
     XNNPACK's, and not gemmlowp's double rounding;
   * int8 LEAKY_RELU, ADD and QUANTIZE are XNNPACK's own kernels with their own arithmetic, different from the TFLite

@@ -1,4 +1,4 @@
-"""Writes profiles/r04_xnnpack_witness.txt: real XNNPACK (torch's libtorch_cpu.so) vs the oracle's arithmetic models, per op.
+"""Writes profiles/history/r04_xnnpack_witness.txt: real XNNPACK (torch's libtorch_cpu.so) vs the oracle's arithmetic models, per op.
 CPU only, needs /root/reference (this container).  Same comparisons tests/test_xnnpack_witness.py asserts."""
 import os
 import sys
