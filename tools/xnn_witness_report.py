@@ -56,7 +56,7 @@ def main():
                 P("      (op %d, the one-channel transposed conv, compared with the x86 nr2-kernel model; vs the canonical fused chain: %d of %d "
                   "outputs differ, max abs %.2e)" % (kk[0], r["canon_differ"], r["n"], r["maxabs"]))
     txt = "\n".join(out) + "\n"
-    path = os.path.join(ROOT, "profiles", "r04_xnnpack_witness.txt")
+    path = os.path.join(ROOT, "profiles", "history", "r04_xnnpack_witness.txt")
     open(path, "w").write(txt)
     print(txt)
 
