@@ -72,8 +72,9 @@ struct lyra_hip_ctx {
   int32_t* d_ids = nullptr;      // encode-side staging of host ids
   int32_t* d_ids_dec = nullptr;  // decode-side staging of host ids
   int16_t* d_pcm_in = nullptr;
-  int16_t* d_rs16[2] = {};        // run_steps: the input resampler's 16 kHz hops, by step parity (resample_in_ahead)
-  hipEvent_t ev_rs_in[2] = {};     // ... and the end of the launch that filled each
+  static constexpr int RS_RING = 3;
+  int16_t* d_rs16[RS_RING] = {};  // run_steps: the input resampler's 16 kHz hops, by step mod 3 (resample_in_ahead: two hops ahead)
+  hipEvent_t ev_rs_in[RS_RING] = {};   // ... and the end of the launch that filled each
   hipEvent_t ev_ahead_order = nullptr, ev_ahead_last = nullptr;
   // sub-batches (nsub > 1) only: a call that is split differently from the previous call of its side joins that call's
   // streams first (cross_begin / dec_side_begin) -- e.g. an unsplit resample_dev behind a split decode_dev
@@ -225,8 +226,7 @@ int ensure_scratch(lyra_hip_ctx* c, int B) {
   HIPCHK(c, dalloc(&c->d_pkt_bytes, n));
   HIPCHK(c, dalloc(&c->d_rs_in, n * 960));
   HIPCHK(c, dalloc(&c->d_rs_out, n * 960));
-  HIPCHK(c, dalloc(&c->d_rs16[0], n * 320));
-  HIPCHK(c, dalloc(&c->d_rs16[1], n * 320));
+  for (auto& p : c->d_rs16) HIPCHK(c, dalloc(&p, n * 320));
   c->cap = B;
   return 0;
 }
@@ -837,8 +837,7 @@ static int create_impl(const char* model_dir, const void* image, size_t image_by
   if (make_stream(&c->sn, 3, prio_lo) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_noise[0], evflags) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_noise[1], evflags) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_rs_in[0], evflags) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_rs_in[1], evflags) != hipSuccess ||
+      [&] { for (auto& e : c->ev_rs_in) if (hipEventCreateWithFlags(&e, evflags) != hipSuccess) return true; return false; }() ||
       hipEventCreateWithFlags(&c->ev_ahead_order, evflags) != hipSuccess ||
       (c->nsub > 1 && [&] { for (int k = 0; k < c->nsub; ++k) if (hipEventCreateWithFlags(&c->ev_se_last[k], evflags) != hipSuccess) return true; return false; }()) ||
       hipEventCreateWithFlags(&c->ev_ahead_last, evflags) != hipSuccess)
@@ -1270,6 +1269,24 @@ static int resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const
   return rc;
 }
 
+// run_steps with BOTH decoder-side legs (NoiseEstimator on every decoded hop + output resampler): the two launches of a hop are
+// ONE noise-stream call -- one begin, one record.  The two-buffer rule counts calls ("all noise-stream calls but the most
+// recent one"): counted separately, the quantizer of step i waited for the ESTIMATOR OF STEP i-1, so the decoder chain of
+// step i could not start before the previous hop's estimator + this hop's quantizer had run behind the previous decoder chain
+// (rocprofv3 timeline: 126 us of nothing on the decoder stream per step, 0.422 ms per step; profiles/r06_modes_timelines.txt).
+static int noise_and_resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm16, int32_t* d_is_noise,
+                                       int out_rate, int16_t* d_out) {
+  DEVSCOPE(c);
+  int rc = ensure_scratch(c, B);
+  if (rc) return rc;
+  if ((rc = noise_dev_begin(c))) return rc;
+  rc = launch_noise(c, 1, c->sn, d_ids, B, d_pcm16, d_is_noise, nullptr);
+  if (!rc) rc = launch_resample(c, 1, d_ids, B, d_pcm16, 320, 16000, out_rate, d_out, nullptr, 0, 0, c->sn);
+  c->rs_sn_pending = true;
+  if (!rc) rc = noise_dev_done(c);
+  return rc;
+}
+
 // Work run_steps launches AHEAD on the quantizer stream sq[0]: the encoder's input resampler (lyra_encoder.cc:119-122)
 // only depends on the caller's input ring and on slots nothing else touches, so the hop of step i+1 is resampled in front
 // of rvq_encode(i), underneath step i's feature extractor instead of lengthening the extractor's chain, into the buffer
@@ -1277,7 +1294,7 @@ static int resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, int B, const
 // of step i-1, which rvq_encode(i-1) -- earlier on the same stream -- has waited for.  (The DTX NoiseEstimator was tried
 // there too: no gain -- +31 us per step in front of the extractor or ahead -- and not kept.)
 static int resample_in_ahead(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate, long step) {
-  const int p = (int)(step & 1);
+  const int p = (int)(step % lyra_hip_ctx::RS_RING);
   int rc = launch_resample(c, 0, d_ids, B, d_in, n_in, in_rate, 16000, c->d_rs16[p], nullptr, 0, 0, c->sq[0]);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->ev_rs_in[p], c->sq[0]));
@@ -1710,16 +1727,20 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
         }
       } else if (rs) {         // ... one step ahead, on the quantizer stream (resample_in_ahead)
         DEVSCOPE(c);
+        static const int lead = getenv("LYRA_HIP_RS_LEAD") ? std::max(1, std::min(2, atoi(getenv("LYRA_HIP_RS_LEAD")))) : 2;   // experiment hook
+        auto ahead = [&](int j) {   // the hop of step first_step + j, if this call has one
+          if (j >= S->n_steps) return 0;
+          const int16_t* src = S->d_pcm_ring + (size_t)((S->first_step + j) % S->ring) * B * (size_t)n_ext;
+          return resample_in_ahead(c, S->d_stream_ids, S->B, src, n_ext, ext, S->first_step + j);
+        };
         if (i == 0) {
           if ((rc = ahead_begin(c))) return rc;
-          if ((rc = resample_in_ahead(c, S->d_stream_ids, S->B, in, n_ext, ext, step))) return rc;
+          for (int j = 0; j < lead; ++j) if ((rc = ahead(j))) return rc;
         }
-        if (i + 1 < S->n_steps) {
-          const int16_t* nxt = S->d_pcm_ring + (size_t)((step + 1) % S->ring) * B * (size_t)n_ext;
-          if ((rc = resample_in_ahead(c, S->d_stream_ids, S->B, nxt, n_ext, ext, step + 1))) return rc;
-        }
-        for (int k = 0; k < c->nsub; ++k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_rs_in[step & 1], 0));
-        in = c->d_rs16[step & 1];
+        if ((rc = ahead(i + lead))) return rc;
+        const int slot = (int)(step % lyra_hip_ctx::RS_RING);
+        for (int k = 0; k < c->nsub; ++k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_rs_in[slot], 0));
+        in = c->d_rs16[slot];
       }
       if (F & LYRA_HIP_STEP_DTX)
         rc = lyra_hip_encode_dtx_dev(c, S->d_stream_ids, S->B, in, S->num_bits, S->d_packets[set], S->d_packet_bytes[set]);
@@ -1736,13 +1757,17 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
         rc = lyra_hip_decode_dev(c, S->d_stream_ids, S->B, pk, S->num_bits, S->d_pcm_out[set]);
       }
       if (rc) return rc;
-      if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
-        if ((rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise))) return rc;
-      if (rs)     // lyra_decoder.cc:107-113 / buffered_resampler.cc: 16 kHz -> external rate
-        if ((rc = rs_off_chain ? resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set])
-                               : lyra_hip_resample_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000,
-                                                       ext, S->d_ext_out[set])))
-          return rc;
+      if ((F & LYRA_HIP_STEP_DECODER_NOISE) && rs_off_chain && !getenv("LYRA_HIP_SPLIT_SN_CALLS")) {   // both legs: one noise-stream call
+        if ((rc = noise_and_resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise, ext, S->d_ext_out[set]))) return rc;
+      } else {
+        if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
+          if ((rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise))) return rc;
+        if (rs)     // lyra_decoder.cc:107-113 / buffered_resampler.cc: 16 kHz -> external rate
+          if ((rc = rs_off_chain ? resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set])
+                                 : lyra_hip_resample_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000,
+                                                         ext, S->d_ext_out[set])))
+            return rc;
+      }
     }
   }
   return 0;
