@@ -688,7 +688,8 @@ int launch_noise(lyra_hip_ctx* c, int side, hipStream_t st_, const int32_t* d_id
   const int rate = side == 0 ? c->enc_noise_rate : 16000;
   const MelP* melp = c->model.d_mel_rate[rate == 8000 ? 0 : rate == 32000 ? 2 : rate == 48000 ? 3 : 1];
   { ProfScope ps(c, K_NOISE, st_);
-    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes(), st_, melp, d_pcm, d_ids,
+    static const size_t pad = lds_pad("logmel_noise");   // experiment hook (fewer estimator workgroups per CU)
+    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(B, 2)), dim3(256), logmel_lds_bytes() + pad, st_, melp, d_pcm, d_ids,
                        B, region, (int)st::NOISE_BYTES, (int)st::N_PREV, (float*)nullptr, 1,
                        noise_params(rate), d_is_noise, d_masked_ids); }
   HIPCHK(c, hipGetLastError());
@@ -1216,7 +1217,8 @@ static int launch_resample(lyra_hip_ctx* c, int side, const int32_t* d_ids, int 
     c->rs_sn_pending = false;
   }
   { ProfScope ps(c, K_RESAMPLE, st_);
-    hipLaunchKernelGGL(resample_kernel, dim3(cdiv(B, resample_streams_per_wg())), dim3(256), resample_lds_bytes(n_in), st_, P, d_ids, B,
+    static const size_t pad = lds_pad("resample");   // experiment hook
+    hipLaunchKernelGGL(resample_kernel, dim3(cdiv(B, resample_streams_per_wg())), dim3(256), resample_lds_bytes(n_in) + pad, st_, P, d_ids, B,
                        c->sm.base[side == 0 ? st::R_RS_E : st::R_RS_D], d_in, n_in, in_stride > 0 ? in_stride : n_in, d_out,
                        n_out, out_stride > 0 ? out_stride : n_out); }
   HIPCHK(c, hipGetLastError());
