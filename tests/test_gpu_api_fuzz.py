@@ -260,3 +260,64 @@ def test_run_steps_with_random_flags_equals_the_single_calls(seed, sub_batches):
                 assert torch.equal(b["noise"], r["noise"]), what + ": is_noise"
     finally:
         ref.close(); x.close()
+
+
+@pytest.mark.parametrize("rate,sub_batches", [(48000, 1), (8000, 1), (48000, 2), (32000, 1)])
+def test_run_steps_all_legs_over_many_hops_and_two_calls(rate, sub_batches):
+    """Every optional leg at once (DTX encoder, decoder-side NoiseEstimator, both resamplers) over 11 + 6 hops in two
+    lyra_hip_run_steps_dev calls -- long enough for the input resampler's ring of three (it runs two hops ahead) to wrap several
+    times and for the noise stream's two-buffer rule to bite (the estimator and the output resampler of a hop are one
+    noise-stream call) -- against the same hops issued one `_dev` call at a time with a synchronise after each."""
+    import torch
+    import lyra_amd
+    from lyra_amd.codec import packet_size
+    N, B, bits = 320, 300, 184
+    rng = np.random.Generator(np.random.PCG64(4100 + rate // 1000 + sub_batches))
+    ref = lyra_amd.LyraHip(max_streams=N)
+    x = lyra_amd.LyraHip(max_streams=N, sub_batches=sub_batches)
+    dev = torch.device("cuda", 0)
+    nb = packet_size(bits)
+    n_ext = 320 * rate // 16000
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    try:
+        for c in (ref, x):
+            c.set_encoder_sample_rate(rate)
+        order = rng.permutation(N)[:B].astype(np.int32)
+        d_ids = torch.from_numpy(order).to(dev)
+        total = 17
+        pcm = rng.integers(-15000, 15000, size=(total, B, n_ext)).astype(np.int16)
+        pcm[:, : B // 3] //= 1500          # a third of the streams stay quiet: DTX and the estimators have something to decide
+        ring = torch.from_numpy(pcm).to(dev)
+        bufs = {}
+        for name in ("ref", "x"):
+            bufs[name] = dict(pk=[z((B, nb), torch.uint8) for _ in range(2)], out=[z((B, 320), torch.int16) for _ in range(2)],
+                              ln=[z((B,), torch.int32) for _ in range(2)], ext=[z((B, n_ext), torch.int16) for _ in range(2)],
+                              noise=z((B,), torch.int32))
+        r, b = bufs["ref"], bufs["x"]
+        d16 = z((B, 320), torch.int16)
+        done = 0
+        for n in (11, 6):
+            for t in range(done, done + n):
+                s = t & 1
+                ref.resample_dev(d_ids, ring[t], rate, 16000, d16, side="encoder")
+                ref.encode_dtx_dev(d_ids, d16, bits, r["pk"][s], r["ln"][s])
+                ref.decode_dev(d_ids, r["pk"][s], bits, r["out"][s])
+                ref.noise_receive_dev(d_ids, r["out"][s], r["noise"], side="decoder")
+                ref.resample_dev(d_ids, r["out"][s], 16000, rate, r["ext"][s], side="decoder")
+                ref.synchronize()
+            x.run_steps_dev(d_ids, bits, n, first_step=done, d_pcm_ring=ring, d_packets=b["pk"], d_pcm_out=b["out"],
+                            d_packet_bytes=b["ln"], d_is_noise=b["noise"], external_rate=rate, d_ext_out=b["ext"], dtx=True,
+                            decoder_noise=True)
+            x.synchronize()
+            done += n
+            what = f"{rate} Hz, split {sub_batches}, after {done} hops"
+            for s in range(2):
+                assert torch.equal(b["pk"][s], r["pk"][s]), what + f": packets, set {s}"
+                assert torch.equal(b["ln"][s], r["ln"][s]), what + f": packet lengths, set {s}"
+                assert torch.equal(b["out"][s], r["out"][s]), what + f": PCM, set {s}"
+                assert torch.equal(b["ext"][s], r["ext"][s]), what + f": external-rate PCM, set {s}"
+            assert torch.equal(b["noise"], r["noise"]), what + ": is_noise"
+        lens = b["ln"][0].cpu().numpy()
+        assert (lens == 0).any() and (lens > 0).any(), "the session never mixed empty and full packets"
+    finally:
+        ref.close(); x.close()
