@@ -22,7 +22,7 @@ def test_cpp_plugin_surface(oracle_default, golden_dir, tmp_path, bits):
     pin, bits_out, pout = tmp_path / "in.s16", tmp_path / "bits.txt", tmp_path / "out.s16"
     pcm.tofile(pin)
     r = subprocess.run([demo, lyra_amd.default_model_dir(), str(pin), str(bits), str(bits_out), str(pout)],
-                       capture_output=True, text=True, timeout=120)
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     ref = lyra_oracle.run_batch(oracle_default, pcm[:, None, :], bits // 4, do_decode=True)
     lines = open(bits_out).read().split()
@@ -86,7 +86,7 @@ def test_cpp_batch_codec_twins(oracle_default, golden_dir, tmp_path, bitrate):
     pin, pk, pout = tmp_path / "in.s16", tmp_path / "pk.bin", tmp_path / "out.s16"
     pcm.tofile(pin)
     r = subprocess.run([demo, lyra_amd.default_model_dir(), str(pin), str(n), str(bitrate), str(pk), str(pout)],
-                       capture_output=True, text=True, timeout=120)
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     bits = {3200: 64, 6000: 120, 9200: 184}[bitrate]
     ref = lyra_oracle.run_batch(oracle_default, pcm, bits // 4, do_decode=True)
@@ -137,7 +137,7 @@ def test_cpp_file_transcode_ragged_batch(oracle_default, golden_dir, tmp_path):
     out_dir = tmp_path / "out"
     out_dir.mkdir()
     r = subprocess.run([demo, lyra_amd.default_model_dir(), "6000", str(out_dir)] + wavs,
-                       capture_output=True, text=True, timeout=120)
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     for name, pcm in files.items():
         hops = len(pcm) // 320
@@ -167,7 +167,7 @@ def test_cpp_wav_io_roundtrip(tmp_path):
     spliced = spliced[:4] + struct.pack("<I", len(spliced) - 8) + spliced[8:]
     open(b, "wb").write(spliced)
     for src in (a, b):
-        r = subprocess.run([demo, "--selftest-wav", str(src), str(c)], capture_output=True, text=True, timeout=60)
+        r = subprocess.run([demo, "--selftest-wav", str(src), str(c)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.returncode, r.stderr)
         assert r.stdout.split() == ["1", "16000", "1000"]
         assert np.array_equal(_read_wav(c), pcm)

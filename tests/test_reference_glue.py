@@ -368,7 +368,7 @@ def test_gpu_file_transcode_vs_reference_file_codec(ref, oracle_default, golden_
     out_dir = tmp_path / "out"
     out_dir.mkdir()
     r = subprocess.run([demo, lyra_amd.default_model_dir(), "9200", str(out_dir)] + wavs, capture_output=True, text=True,
-                       timeout=120)
+                       timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     for name in files:
         assert ref.encode_file(oracle_default, tmp_path / f"{name}.wav", tmp_path / f"{name}.ref.lyra", 9200, model_dir)
