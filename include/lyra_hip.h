@@ -155,7 +155,12 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  *                            default 0,0,2: the two chains equal, the small quantizer first; 0,2,0 = rounds 2-3:
  *                            decoder chain first -- better for blocking decode calls beside an encoder, bimodal for the `_dev` pipeline);
  *   LYRA_HIP_TILE_DIV_<K>=k  launch stage kernel K (ENC_S0 .. DEC_S2) as k slices of its tiles,
- *   LYRA_HIP_LDS_PAD_<K>=b   give its workgroups b extra bytes of LDS (occupancy experiments). */
+ *   LYRA_HIP_LDS_PAD_<K>=b   give its workgroups b extra bytes of LDS (occupancy experiments; K also logmel_noise, resample);
+ *   read by lyra_hip_run_steps_dev (profiles/r06_modes_timelines.txt):
+ *   LYRA_HIP_RS_LEAD=1       the input resampler one hop ahead of the extractor instead of two;
+ *   LYRA_HIP_SPLIT_SN_CALLS=1  a hop's decoder-side NoiseEstimator and output resampler as two noise-stream calls
+ *                            instead of one (the form before round 6's last session: the quantizer of hop i then
+ *                            waits for the estimator of hop i - 1). */
 /* max_streams: 1 .. 289,262 per context (per-stream state is addressed with 32-bit byte offsets; 83 KB of state per stream,
  * so that is 24 GB of the 288 -- more streams: more contexts). */
 int lyra_hip_create(const char* model_dir, int device, int max_streams, int requant_mode, lyra_hip_ctx** out);
