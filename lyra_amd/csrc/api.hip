@@ -1290,11 +1290,14 @@ static int noise_and_resample_deferred(lyra_hip_ctx* c, const int32_t* d_ids, in
 }
 
 // Work run_steps launches AHEAD on the quantizer stream sq[0]: the encoder's input resampler (lyra_encoder.cc:119-122)
-// only depends on the caller's input ring and on slots nothing else touches, so the hop of step i+1 is resampled in front
-// of rvq_encode(i), underneath step i's feature extractor instead of lengthening the extractor's chain, into the buffer
-// of its parity; the extractor of step i+1 waits for its event.  The buffer it overwrites was last read by the extractor
-// of step i-1, which rvq_encode(i-1) -- earlier on the same stream -- has waited for.  (The DTX NoiseEstimator was tried
-// there too: no gain -- +31 us per step in front of the extractor or ahead -- and not kept.)
+// only depends on the caller's input ring and on slots nothing else touches, so the hop of step i+2 is resampled in front
+// of rvq_encode(i), underneath step i's feature extractor instead of lengthening the extractor's chain, into buffer
+// (i+2) mod 3; the extractor of step i+2 waits for its event.  The buffer it overwrites was last read by the extractor
+// of step i-1, which rvq_encode(i-1) -- earlier on the same stream -- has waited for.  TWO hops ahead since round 6: at an
+// external rate the decoder chain is the slower one, the quantizer runs late (it waits for the noise stream's work of two
+// hops ago) and a hop resampled only ONE step ahead, queued behind it, arrived after the extractor wanted it -- a ~90 us
+// stall every second hop (profiles/r06_modes_timelines.txt; LYRA_HIP_RS_LEAD=1 is the old form).  (The DTX NoiseEstimator
+// was tried on this stream too: no gain -- +31 us per step in front of the extractor or ahead -- and not kept.)
 static int resample_in_ahead(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_in, int n_in, int in_rate, long step) {
   const int p = (int)(step % lyra_hip_ctx::RS_RING);
   int rc = launch_resample(c, 0, d_ids, B, d_in, n_in, in_rate, 16000, c->d_rs16[p], nullptr, 0, 0, c->sq[0]);
@@ -1727,7 +1730,7 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
             for (int k = 1; k < c->nsub; ++k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_ahead_order, 0));
           }
         }
-      } else if (rs) {         // ... one step ahead, on the quantizer stream (resample_in_ahead)
+      } else if (rs) {         // ... two steps ahead, on the quantizer stream (resample_in_ahead)
         DEVSCOPE(c);
         static const int lead = getenv("LYRA_HIP_RS_LEAD") ? std::max(1, std::min(2, atoi(getenv("LYRA_HIP_RS_LEAD")))) : 2;   // experiment hook
         auto ahead = [&](int j) {   // the hop of step first_step + j, if this call has one
@@ -1759,7 +1762,8 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
         rc = lyra_hip_decode_dev(c, S->d_stream_ids, S->B, pk, S->num_bits, S->d_pcm_out[set]);
       }
       if (rc) return rc;
-      if ((F & LYRA_HIP_STEP_DECODER_NOISE) && rs_off_chain && !getenv("LYRA_HIP_SPLIT_SN_CALLS")) {   // both legs: one noise-stream call
+      static const bool split_sn = getenv("LYRA_HIP_SPLIT_SN_CALLS") != nullptr;   // experiment hook: the form before round 6
+      if ((F & LYRA_HIP_STEP_DECODER_NOISE) && rs_off_chain && !split_sn) {   // both legs: one noise-stream call
         if ((rc = noise_and_resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise, ext, S->d_ext_out[set]))) return rc;
       } else {
         if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
