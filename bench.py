@@ -171,6 +171,11 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-confine", action="store_true",
                     help="at --gpus N > 1 do not confine each rank to its share of the CPU quota (confine_rank_to_cpu_share)")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--oversubscribe-device", type=int, default=None, metavar="D",
+                    help="HARDWARE SMOKE of the N-rank path on a box with fewer GPUs than ranks: every rank drives GPU D, the "
+                         "process group is gloo (RCCL refuses two ranks on one device).  Everything else is the N-rank job: one "
+                         "process and one context per rank, CPU shares, barriers, reductions, rank gather.  NOT a scaling "
+                         "measurement -- the line says so")
     ap.add_argument("--force-dist", action="store_true",
                     help="bring the process group up (RCCL on a GPU box) even with ONE rank: the N > 1 code path -- "
                          "init, barriers around the timed region, max / sum all-reduce, rank gather -- on a 1-GPU box")
@@ -949,7 +954,7 @@ def main(argv=None):
     if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if args.single_process and not stub:
             return main_single_process(args, args.gpus)
-        if not stub and torch.cuda.device_count() < args.gpus:
+        if not stub and args.oversubscribe_device is None and torch.cuda.device_count() < args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
         rc = respawn_under_launcher(argv, args.gpus)
         if rc:
@@ -957,11 +962,13 @@ def main(argv=None):
         return
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    over = args.oversubscribe_device if not stub else None
+    gpu = local if over is None else over        # the GPU this rank drives
     if stub:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
+        torch.cuda.set_device(gpu)
+        dev = torch.device("cuda", gpu) if over is None else torch.device("cpu")   # where the collectives' tensors live
     use_pg = world > 1 or args.force_dist
     confined = confine_rank_to_cpu_share(local, world) if (world > 1 and not args.no_cpu_confine) else None
     if use_pg:
@@ -972,14 +979,14 @@ def main(argv=None):
                 so.bind(("127.0.0.1", 0))
                 port = so.getsockname()[1]
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local))
-        if stub:
+        if stub or over is not None:
             dist.init_process_group("gloo", init_method="env://")
         else:
             dist.init_process_group("nccl", init_method="env://", device_id=dev)
     wl = resolve_workload(args, world)
     first_id, _ = shard_ids(wl["total"], rank, world)
     image = broadcast_weights(rank, dev) if (args.bcast_weights and use_pg) else None
-    sh = StubShard(rank, first_id, wl, args, weights_image=image) if stub else Shard(local, first_id, wl, args,
+    sh = StubShard(rank, first_id, wl, args, weights_image=image) if stub else Shard(gpu, first_id, wl, args,
                                                                                      weights_image=image)
 
     def barrier():
@@ -994,7 +1001,7 @@ def main(argv=None):
     per_rank = gather_ranks(rank_summary(res, args, wl), world)
     out = None
     if rank == 0:
-        backend = "gloo (stub)" if stub else "RCCL"
+        backend = "gloo (stub)" if stub else "RCCL" if over is None else f"gloo, every rank on GPU {over}"
         if use_pg:
             how = (f"one process per GPU, torch.distributed/{backend}: {world} rank(s), process group used for the "
                    "timing barrier and the result reduction only")
@@ -1013,6 +1020,10 @@ def main(argv=None):
             out["cpus_per_rank"] = len(confined[1]) if confined else None
         if stub:
             out["stub"] = {"calls": sh.calls, "first_id": first_id, "weights_bytes": sh.weights_bytes}
+        if over is not None:
+            out["oversubscribed"] = (f"HARDWARE SMOKE, not a scaling measurement: all {world} rank(s) drive GPU {over} "
+                                     "(--oversubscribe-device); `value` is what ONE GPU shared by them delivered")
+            out["scaling"] = "oversubscribed"
     # The process group goes away BEFORE the CPU legs: the other ranks have left by then (no rank spinning in a barrier
     # on the host cores the baseline is timed on), and nothing the baseline's threads do can reach another rank's clock.
     if use_pg:

@@ -63,3 +63,27 @@ def test_bench_rccl_path_with_one_rank():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["ranks"] == 1 and "RCCL" in r["process_group"]
     assert r["verified"] is True and r["value"] > 1e6 and r["roofline"]["frac"] > 0.1
+
+
+def test_bench_two_ranks_sharing_the_one_gpu():
+    """The N-rank job itself on real hardware, as far as a 1-GPU box allows: two processes launched exactly as the driver
+    launches them (torch.distributed.run, 127.0.0.1), each with its own context, CPU share, barriers around its timed
+    region, the max / sum reduction, the rank gather and the weight broadcast -- both driving GPU 0
+    (`--oversubscribe-device 0`, process group gloo: RCCL refuses two ranks on one device).  Every rank must verify its own
+    run against the oracle; the line must say that it is no scaling measurement."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29532", os.path.join(root, "bench.py"), "--gpus", "2", "--oversubscribe-device", "0", "--bcast-weights",
+           "--config", "2", "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--latency-steps", "0", "--verify-streams", "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks"] == 2 and len(r["per_rank"]) == 2 and len(r["per_rank_ms_per_step"]) == 2
+    assert r["verified"] is True and all(p["verified"] is True for p in r["per_rank"])
+    assert r["scaling"] == "oversubscribed" and "not a scaling measurement" in r["oversubscribed"]
+    assert r["config"]["total_streams"] == 2 * r["config"]["streams_per_gpu"]
+    assert r["ms_per_step"] == max(r["per_rank_ms_per_step"])
