@@ -171,6 +171,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-confine", action="store_true",
                     help="at --gpus N > 1 do not confine each rank to its share of the CPU quota (confine_rank_to_cpu_share)")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--per-call-split", action="store_true",
+                    help="with --per-call at an external rate: every codec call on its own (resample, encode, decode, estimator, "
+                         "resample) instead of lyra_hip_encode_ext_dev / lyra_hip_decode_ext_dev, one call per side and hop")
     ap.add_argument("--oversubscribe-device", type=int, default=None, metavar="D",
                     help="HARDWARE SMOKE of the N-rank path on a box with fewer GPUs than ranks: every rank drives GPU D, the "
                          "process group is gloo (RCCL refuses two ranks on one device).  Everything else is the N-rank job: one "
@@ -587,6 +590,15 @@ class Shard:
 
     def _step_per_call(self, kind, i):
         ctx, bits, a, s = self.ctx, self.wl["bits"], self.args, i & 1
+        if kind == "encdec" and self.rate != 16000 and not a.per_call_split:
+            # one hop at an external rate, ONE call per side (lyra_hip_encode_ext_dev / lyra_hip_decode_ext_dev)
+            x = self.pcm_in[i % self.pcm_in.shape[0]]
+            ctx.encode_ext_dev(self.ids, x, self.rate, bits, self.packets[s], self.packet_bytes[s] if a.dtx else None, dtx=a.dtx)
+            ctx.decode_ext_dev(self.ids, self.packets[s], bits, self.rate, self.pcm_out[s], self.ext_out[s],
+                               self.is_noise if a.full_decoder else None)
+            if self.mel is not None:
+                ctx.logmel_dev(self.ids, self.pcm_out[s], self.mel)
+            return
         if kind == "encdec":
             x = self.pcm_in[i % self.pcm_in.shape[0]]
             if self.rate != 16000:

@@ -276,6 +276,25 @@ int lyra_hip_noise_receive_dev(lyra_hip_ctx* ctx, int side, const int32_t* d_str
 int lyra_hip_encode_dtx_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const int16_t* d_pcm, int num_bits,
                             uint8_t* d_packets, int32_t* d_packet_bytes);
 
+/* One hop at an EXTERNAL sample rate (8000 / 16000 / 32000 / 48000 Hz), ONE call per side -- the per-call form of what
+ * LyraEncoder::Encode and LyraDecoder::DecodeSamples do around the codec for callers whose audio arrives hop by hop:
+ *   encode_ext: the encoder's resampler (lyra_encoder.cc:119-122), with dtx != 0 the NoiseEstimator decision (:131-141; then
+ *     d_packet_bytes [B] is required and lyra_hip_set_encoder_sample_rate(rate) must have been called), feature extractor,
+ *     quantizer.  d_pcm_ext int16 [B][320 * rate / 16000].
+ *   decode_ext: decode of a received hop into d_pcm16 [B][320], with estimate_noise != 0 the decoder-side NoiseEstimator
+ *     (lyra_decoder.cc:304-311 -> d_is_noise [B]), the resampler to the external rate (:107-113 -> d_pcm_ext
+ *     [B][320 * rate / 16000]; may be NULL at 16000).  The estimator and the resampler complete on the NOISE stream
+ *     (lyra_hip_stream_noise / lyra_hip_stream_wait / lyra_hip_synchronize, as for lyra_hip_run_steps_dev).
+ * Same results as lyra_hip_resample_dev + lyra_hip_encode[_dtx]_dev and lyra_hip_decode_dev + lyra_hip_noise_receive_dev +
+ * lyra_hip_resample_dev.  The difference is what rule (2) of "Streams" counts: each of these is ONE call of its side, so
+ * the next hop's encode overlaps this hop's decode; issued one by one, a hop makes two encode-side and up to three
+ * decode-side calls and the next extractor / quantizer wait for this hop's decoder chain (4096 streams at 48 kHz: 10.4 M
+ * frames/s call by call, 13.3 M through these two -- what lyra_hip_run_steps_dev reaches; profiles/r06_per_call.txt). */
+int lyra_hip_encode_ext_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const int16_t* d_pcm_ext, int sample_rate_hz,
+                            int num_bits, int dtx, uint8_t* d_packets, int32_t* d_packet_bytes);
+int lyra_hip_decode_ext_dev(lyra_hip_ctx* ctx, const int32_t* d_stream_ids, int B, const uint8_t* d_packets, int num_bits,
+                            int sample_rate_hz, int estimate_noise, int16_t* d_pcm16, int16_t* d_pcm_ext, int32_t* d_is_noise);
+
 /* n_steps hops of B streams from ONE call (no host language in the loop): per hop what lyra_benchmark times
  * (lyra_benchmark_lib.cc:121-160) and what LyraEncoder::Encode / LyraDecoder::DecodeSamples run around it.  Step i
  * (absolute number first_step + i) reads input frame (first_step + i) % ring and uses buffer set (first_step + i) & 1

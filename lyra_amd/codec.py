@@ -119,6 +119,9 @@ def _load(path=None):
         L.lyra_hip_decode_end.argtypes = [vp, vp]
         L.lyra_hip_twin_fetch_begin.argtypes = [vp, ci, ci, ci]
         L.lyra_hip_twin_fetch_end.argtypes = [vp, vp]
+    if hasattr(L, "lyra_hip_encode_ext_dev"):   # (one hop at an external rate, one call per side: round 6)
+        L.lyra_hip_encode_ext_dev.argtypes = [vp, vp, ci, vp, ci, ci, ci, vp, vp]
+        L.lyra_hip_decode_ext_dev.argtypes = [vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     L.lyra_hip_set_cng_seed.argtypes = [vp, C.c_uint64]
     L.lyra_hip_set_encoder_sample_rate.argtypes = [vp, C.c_int]
     L.lyra_hip_stream.restype = vp
@@ -482,6 +485,29 @@ class LyraHip:
                        self._dev_ptr(d_pcm, "int16", (B, HOP), "pcm"), num_bits,
                        self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"),
                        self._dev_ptr(d_packet_bytes, "int32", (B,), "packet bytes"))
+
+    def encode_ext_dev(self, d_ids, d_pcm_ext, sample_rate_hz, num_bits, d_packets, d_packet_bytes=None, dtx=False):
+        """LyraEncoder::Encode at an external sample rate as ONE encode-side call (lyra_hip_encode_ext_dev): resampler, with
+        dtx the NoiseEstimator decision (d_packet_bytes int32 [B] required), extractor, quantizer.  d_pcm_ext int16
+        [B][320 * rate / 16000]."""
+        B = d_pcm_ext.shape[0]
+        n_ext = HOP * sample_rate_hz // 16000
+        self._dev_call(self.L.lyra_hip_encode_ext_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_pcm_ext, "int16", (B, n_ext), "pcm"), sample_rate_hz, num_bits, 1 if dtx else 0,
+                       self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"),
+                       self._dev_ptr(d_packet_bytes, "int32", (B,), "packet bytes") if d_packet_bytes is not None else None)
+
+    def decode_ext_dev(self, d_ids, d_packets, num_bits, sample_rate_hz, d_pcm16, d_pcm_ext=None, d_is_noise=None):
+        """LyraDecoder::DecodeSamples for a received hop at an external rate as ONE decode-side call
+        (lyra_hip_decode_ext_dev): decode -> d_pcm16 [B][320]; d_is_noise given: the decoder-side NoiseEstimator; rate !=
+        16000: the resampler -> d_pcm_ext [B][320 * rate / 16000].  Estimator and resampler complete on the noise stream."""
+        B = d_packets.shape[0]
+        n_ext = HOP * sample_rate_hz // 16000
+        self._dev_call(self.L.lyra_hip_decode_ext_dev, self._dev_ptr(d_ids, "int32", (B,), "stream ids"), B,
+                       self._dev_ptr(d_packets, "uint8", (B, packet_size(num_bits)), "packets"), num_bits, sample_rate_hz,
+                       1 if d_is_noise is not None else 0, self._dev_ptr(d_pcm16, "int16", (B, HOP), "pcm"),
+                       self._dev_ptr(d_pcm_ext, "int16", (B, n_ext), "external-rate pcm") if d_pcm_ext is not None else None,
+                       self._dev_ptr(d_is_noise, "int32", (B,), "is_noise") if d_is_noise is not None else None)
 
     def noise_receive_dev(self, d_ids, d_pcm, d_is_noise, side="decoder"):
         """NoiseEstimator::ReceiveSamples on device buffers: pcm int16 [B][320] -> is_noise int32 [B]."""

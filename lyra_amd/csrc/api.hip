@@ -1673,6 +1673,67 @@ int lyra_hip_decode(lyra_hip_ctx* c, const int32_t* ids, int B, const uint8_t* p
   return 0;
 }
 
+// ---- one hop at an external sample rate, one call per side -----------------------------------------------------------
+// LyraEncoder::Encode (lyra_encoder.cc:113-156: resampler :119-122, DTX decision :131-141, extractor, quantizer) and
+// LyraDecoder::DecodeSamples for a received hop (lyra_decoder.cc: generative model, NoiseEstimator :304-311, resampler
+// :107-113) each as ONE call of its side.  The results are those of the individual `_dev` calls; what differs is what the
+// ordering rules of lyra_hip.h "Streams" count: issued one by one, a hop at an external rate makes two encode-side and two or
+// three decode-side calls, and rule (2) -- "all decode-side calls but the most recent ONE" -- then orders the next hop's
+// extractor and quantizer behind this hop's decoder chain (bench.py --per-call --rate 48000: 10.4 M frames/s against 13.2 M
+// through run_steps; profiles/r06_per_call.txt).  Here the encoder's resampler runs in front of the extractor on the
+// extractor's own stream (its output never leaves the library: no cross-side edge), and the decoder's estimator and
+// resampler are one noise-stream call behind the decoder's last stage, as inside lyra_hip_run_steps_dev.
+int lyra_hip_encode_ext_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const int16_t* d_pcm_ext, int sample_rate_hz,
+                            int num_bits, int dtx, uint8_t* d_packets, int32_t* d_packet_bytes) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  if ((rc = check_bits(c, num_bits))) return rc;
+  if (!d_ids || !d_pcm_ext || !d_packets || (dtx && !d_packet_bytes)) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  const int ext = sample_rate_hz;
+  if (ext != 8000 && ext != 16000 && ext != 32000 && ext != 48000)
+    return fail(c, LYRA_HIP_EINVAL, "sample rate %d Hz is not supported by the codec (lyra_config.h:57)", ext);
+  if (dtx && c->enc_noise_rate != ext)   // as lyra_hip_run_steps_dev: the DTX estimator is created at the encoder's external rate
+    return fail(c, LYRA_HIP_EINVAL, "encode_ext: DTX at %d Hz but the encoder-side noise estimator is set up for %d Hz "
+                "(call lyra_hip_set_encoder_sample_rate(%d) first)", ext, c->enc_noise_rate, ext);
+  const int16_t* in = d_pcm_ext;
+  if (ext != 16000) {
+    DEVSCOPE(c);
+    if ((rc = ensure_scratch(c, B))) return rc;
+    // same resampler slots as lyra_hip_resample_dev(ENCODER) and run_steps' ahead launches: behind those; the 16 kHz hop
+    // goes to a library buffer that only this stream's extractor reads (the previous hop's read precedes in stream order)
+    if ((rc = wait_ahead(c))) return rc;
+    if ((rc = enc_cross_begin(c, 0, 1))) return rc;   // (split contexts: after every chunk of the encode-side call before)
+    if ((rc = launch_resample(c, 0, d_ids, B, d_pcm_ext, 320 * (ext / 1000) / 16, ext, 16000, c->d_rs16[0], nullptr))) return rc;
+    if (c->nsub > 1) {   // the chunks of a split encode run on se[1..]: they read what se[0] has just written
+      HIPCHK(c, hipEventRecord(c->ev_ahead_order, c->se[0]));
+      for (int k = 1; k < c->nsub; ++k) HIPCHK(c, hipStreamWaitEvent(c->se[k], c->ev_ahead_order, 0));
+    }
+    in = c->d_rs16[0];
+  }
+  return dtx ? lyra_hip_encode_dtx_dev(c, d_ids, B, in, num_bits, d_packets, d_packet_bytes)
+             : lyra_hip_encode_dev(c, d_ids, B, in, num_bits, d_packets);
+}
+
+int lyra_hip_decode_ext_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const uint8_t* d_packets, int num_bits,
+                            int sample_rate_hz, int estimate_noise, int16_t* d_pcm16, int16_t* d_pcm_ext,
+                            int32_t* d_is_noise) {
+  int rc = check_batch(c, B);
+  if (rc) return rc;
+  const int ext = sample_rate_hz;
+  if (ext != 8000 && ext != 16000 && ext != 32000 && ext != 48000)
+    return fail(c, LYRA_HIP_EINVAL, "sample rate %d Hz is not supported by the codec (lyra_config.h:57)", ext);
+  if (!d_pcm16 || (ext != 16000 && !d_pcm_ext) || (estimate_noise && !d_is_noise)) return fail(c, LYRA_HIP_EINVAL, "null pointer");
+  if ((rc = lyra_hip_decode_dev(c, d_ids, B, d_packets, num_bits, d_pcm16))) return rc;
+  const bool rs = ext != 16000;
+  const bool off_chain = !c->serial && c->nsub == 1;   // as in lyra_hip_run_steps_dev
+  if (estimate_noise && rs && off_chain) return noise_and_resample_deferred(c, d_ids, B, d_pcm16, d_is_noise, ext, d_pcm_ext);
+  if (estimate_noise && (rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, d_ids, B, d_pcm16, d_is_noise))) return rc;
+  if (rs)
+    rc = off_chain ? resample_deferred(c, d_ids, B, d_pcm16, 320, 16000, ext, d_pcm_ext)
+                   : lyra_hip_resample_dev(c, LYRA_HIP_SIDE_DECODER, d_ids, B, d_pcm16, 320, 16000, ext, d_pcm_ext);
+  return rc;
+}
+
 // ---- many steps from one call ---------------------------------------------------------------------------------------
 // What lyra_benchmark's loop does per hop (lyra_benchmark_lib.cc:121-160) and what LyraEncoder::Encode /
 // LyraDecoder::DecodeSamples do around it (lyra_encoder.cc:113-156, lyra_decoder.cc:284-326), for n_steps hops of B

@@ -321,3 +321,101 @@ def test_run_steps_all_legs_over_many_hops_and_two_calls(rate, sub_batches):
         assert (lens == 0).any() and (lens > 0).any(), "the session never mixed empty and full packets"
     finally:
         ref.close(); x.close()
+
+
+@pytest.mark.parametrize("rate,sub_batches,dtx,noise", [(48000, 1, True, True), (8000, 1, False, True), (32000, 2, True, False),
+                                                        (48000, 2, False, True), (16000, 1, True, True), (48000, 4, True, True)])
+def test_one_call_per_side_at_an_external_rate_equals_the_single_calls(rate, sub_batches, dtx, noise):
+    """lyra_hip_encode_ext_dev / lyra_hip_decode_ext_dev (one hop at an external rate, ONE call per side -- resampler + [DTX] +
+    encode; decode + [estimator] + resampler) hop after hop WITHOUT any synchronisation between hops, two alternating buffer
+    sets, over subsets that change -- against resample / encode[_dtx] / decode / noise_receive / resample issued one by one
+    with a synchronise after every hop on an unsplit context."""
+    import torch
+    import lyra_amd
+    from lyra_amd.codec import packet_size
+    N, bits, hops = 384, 120, 14
+    rng = np.random.Generator(np.random.PCG64(5200 + rate // 1000 + 7 * sub_batches + dtx + 2 * noise))
+    ref = lyra_amd.LyraHip(max_streams=N)
+    x = lyra_amd.LyraHip(max_streams=N, sub_batches=sub_batches)
+    dev = torch.device("cuda", 0)
+    nb = packet_size(bits)
+    n_ext = 320 * rate // 16000
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    try:
+        for c in (ref, x):
+            c.set_encoder_sample_rate(rate)
+        B = 300
+        order = rng.permutation(N)[:B].astype(np.int32)
+        d_ids = torch.from_numpy(order).to(dev)
+        pcm = rng.integers(-15000, 15000, size=(hops, B, n_ext)).astype(np.int16)
+        pcm[:, : B // 3] //= 1500
+        ring = torch.from_numpy(pcm).to(dev)
+        mk = lambda: dict(pk=[z((B, nb), torch.uint8) for _ in range(2)], out=[z((B, 320), torch.int16) for _ in range(2)],
+                          ln=[z((B,), torch.int32) for _ in range(2)], ext=[z((B, n_ext), torch.int16) for _ in range(2)],
+                          noise=[z((B,), torch.int32) for _ in range(2)])
+        r, b = mk(), mk()
+        d16 = z((B, 320), torch.int16)
+        keep = {}
+        for t in range(hops):
+            s = t & 1
+            src = ring[t]
+            if rate != 16000:
+                ref.resample_dev(d_ids, ring[t], rate, 16000, d16, side="encoder")
+                src = d16
+            if dtx:
+                ref.encode_dtx_dev(d_ids, src, bits, r["pk"][s], r["ln"][s])
+            else:
+                ref.encode_dev(d_ids, src, bits, r["pk"][s])
+            ref.decode_dev(d_ids, r["pk"][s], bits, r["out"][s])
+            if noise:
+                ref.noise_receive_dev(d_ids, r["out"][s], r["noise"][s], side="decoder")
+            if rate != 16000:
+                ref.resample_dev(d_ids, r["out"][s], 16000, rate, r["ext"][s], side="decoder")
+            ref.synchronize()
+            keep[t] = {k: r[k][s].clone() for k in r}
+            # the path under test: no synchronisation between hops (only every fifth hop, to compare what the two-buffer
+            # rule still holds: sets t and t - 1)
+            x.encode_ext_dev(d_ids, ring[t], rate, bits, b["pk"][s], b["ln"][s] if dtx else None, dtx=dtx)
+            x.decode_ext_dev(d_ids, b["pk"][s], bits, rate, b["out"][s], b["ext"][s] if rate != 16000 else None,
+                             b["noise"][s] if noise else None)
+            if t % 5 == 4 or t == hops - 1:
+                x.synchronize()
+                for tt in (t - 1, t):
+                    ss, what = tt & 1, f"{rate} Hz, split {sub_batches}, dtx {dtx}, estimator {noise}: hop {tt}"
+                    assert torch.equal(b["pk"][ss], keep[tt]["pk"]), what + ": packets"
+                    assert torch.equal(b["out"][ss], keep[tt]["out"]), what + ": 16 kHz PCM"
+                    if dtx:
+                        assert torch.equal(b["ln"][ss], keep[tt]["ln"]), what + ": packet lengths"
+                    if noise:
+                        assert torch.equal(b["noise"][ss], keep[tt]["noise"]), what + ": is_noise"
+                    if rate != 16000:
+                        assert torch.equal(b["ext"][ss], keep[tt]["ext"]), what + ": external-rate PCM"
+    finally:
+        ref.close(); x.close()
+
+
+def test_one_call_per_side_argument_checks():
+    import torch
+    import lyra_amd
+    from lyra_amd.codec import packet_size, LyraHipError
+    c = lyra_amd.LyraHip(max_streams=8)
+    dev = torch.device("cuda", 0)
+    try:
+        ids = torch.arange(4, dtype=torch.int32, device=dev)
+        pk = torch.zeros((4, packet_size(64)), dtype=torch.uint8, device=dev)
+        out16 = torch.zeros((4, 320), dtype=torch.int16, device=dev)
+        x48 = torch.zeros((4, 960), dtype=torch.int16, device=dev)
+        ln = torch.zeros((4,), dtype=torch.int32, device=dev)
+        with pytest.raises(LyraHipError):      # DTX at 48 kHz while the encoder-side estimator is set up for 16 kHz
+            c.encode_ext_dev(ids, x48, 48000, 64, pk, ln, dtx=True)
+        with pytest.raises(LyraHipError):      # an external rate needs the external-rate output buffer
+            c.decode_ext_dev(ids, pk, 64, 48000, out16, None, None)
+        x44 = torch.zeros((4, 882), dtype=torch.int16, device=dev)
+        with pytest.raises(LyraHipError):      # 44.1 kHz is not a rate of the codec
+            c.encode_ext_dev(ids, x44, 44100, 64, pk)
+        c.set_encoder_sample_rate(48000)
+        c.encode_ext_dev(ids, x48, 48000, 64, pk, ln, dtx=True)
+        c.decode_ext_dev(ids, pk, 64, 48000, out16, x48.clone(), ln.clone())
+        c.synchronize()
+    finally:
+        c.close()
