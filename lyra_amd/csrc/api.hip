@@ -1702,7 +1702,7 @@ int lyra_hip_encode_ext_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const 
     // same resampler slots as lyra_hip_resample_dev(ENCODER) and run_steps' ahead launches: behind those; the 16 kHz hop
     // goes to a library buffer that only this stream's extractor reads (the previous hop's read precedes in stream order)
     if ((rc = wait_ahead(c))) return rc;
-    if ((rc = enc_cross_begin(c, 0, 1))) return rc;   // (split contexts: after every chunk of the encode-side call before)
+    if ((rc = encq_begin(c, 0, 1))) return rc;   // (split contexts: after every chunk of the encode-side call before; serial mode: in call order)
     if ((rc = launch_resample(c, 0, d_ids, B, d_pcm_ext, 320 * (ext / 1000) / 16, ext, 16000, c->d_rs16[0], nullptr))) return rc;
     if (c->nsub > 1) {   // the chunks of a split encode run on se[1..]: they read what se[0] has just written
       HIPCHK(c, hipEventRecord(c->ev_ahead_order, c->se[0]));
