@@ -419,3 +419,46 @@ def test_one_call_per_side_argument_checks():
         c.synchronize()
     finally:
         c.close()
+
+
+def test_one_call_per_side_equals_run_steps_at_benchmark_scale():
+    """4096 streams, 48 kHz, DTX encoder and decoder-side estimator, 60 hops: lyra_hip_encode_ext_dev / lyra_hip_decode_ext_dev hop
+    after hop without synchronising against ONE lyra_hip_run_steps_dev call with the same flags (itself held against the single
+    calls above) -- every buffer of the last two hops and the estimator flags must be equal."""
+    import torch
+    import lyra_amd
+    from lyra_amd.codec import packet_size
+    B, bits, hops, rate = 4096, 184, 60, 48000
+    rng = np.random.Generator(np.random.PCG64(6001))
+    a = lyra_amd.LyraHip(max_streams=B)
+    x = lyra_amd.LyraHip(max_streams=B)
+    dev = torch.device("cuda", 0)
+    nb, n_ext = packet_size(bits), 320 * rate // 16000
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    try:
+        for c in (a, x):
+            c.set_encoder_sample_rate(rate)
+        d_ids = torch.arange(B, dtype=torch.int32, device=dev)
+        pcm = rng.integers(-15000, 15000, size=(8, B, n_ext)).astype(np.int16)     # a ring of eight input hops
+        pcm[:, : B // 3] //= 1500
+        ring = torch.from_numpy(pcm).to(dev)
+        mk = lambda: dict(pk=[z((B, nb), torch.uint8) for _ in range(2)], out=[z((B, 320), torch.int16) for _ in range(2)],
+                          ln=[z((B,), torch.int32) for _ in range(2)], ext=[z((B, n_ext), torch.int16) for _ in range(2)],
+                          noise=z((B,), torch.int32))
+        r, b = mk(), mk()
+        a.run_steps_dev(d_ids, bits, hops, first_step=0, d_pcm_ring=ring, d_packets=r["pk"], d_pcm_out=r["out"],
+                        d_packet_bytes=r["ln"], d_is_noise=r["noise"], external_rate=rate, d_ext_out=r["ext"], dtx=True,
+                        decoder_noise=True)
+        for t in range(hops):
+            s = t & 1
+            x.encode_ext_dev(d_ids, ring[t % 8], rate, bits, b["pk"][s], b["ln"][s], dtx=True)
+            x.decode_ext_dev(d_ids, b["pk"][s], bits, rate, b["out"][s], b["ext"][s], b["noise"])
+        a.synchronize(); x.synchronize()
+        for s in range(2):
+            for k in ("pk", "ln", "out", "ext"):
+                assert torch.equal(b[k][s], r[k][s]), f"{k}, set {s}"
+        assert torch.equal(b["noise"], r["noise"]), "is_noise"
+        lens = b["ln"][0].cpu().numpy()
+        assert (lens == 0).any() and (lens > 0).any(), "the run never mixed empty and full packets"
+    finally:
+        a.close(); x.close()
