@@ -158,6 +158,7 @@ typedef struct lyra_hip_ctx lyra_hip_ctx;
  *   LYRA_HIP_LDS_PAD_<K>=b   give its workgroups b extra bytes of LDS (occupancy experiments; K also logmel_noise, resample);
  *   read by lyra_hip_run_steps_dev (profiles/r06_modes_timelines.txt):
  *   LYRA_HIP_RS_LEAD=1       the input resampler one hop ahead of the extractor instead of two;
+ *   LYRA_HIP_RS_OUT_ON_CHAIN_SPLIT=1  on contexts that split batches: the output resampler on the decode streams (old form);
  *   LYRA_HIP_SPLIT_SN_CALLS=1  a hop's decoder-side NoiseEstimator and output resampler as two noise-stream calls
  *                            instead of one (the form before round 6's last session: the quantizer of hop i then
  *                            waits for the estimator of hop i - 1). */

@@ -1725,7 +1725,7 @@ int lyra_hip_decode_ext_dev(lyra_hip_ctx* c, const int32_t* d_ids, int B, const 
   if (!d_pcm16 || (ext != 16000 && !d_pcm_ext) || (estimate_noise && !d_is_noise)) return fail(c, LYRA_HIP_EINVAL, "null pointer");
   if ((rc = lyra_hip_decode_dev(c, d_ids, B, d_packets, num_bits, d_pcm16))) return rc;
   const bool rs = ext != 16000;
-  const bool off_chain = !c->serial && c->nsub == 1;   // as in lyra_hip_run_steps_dev
+  const bool off_chain = !c->serial;   // as in lyra_hip_run_steps_dev (split contexts included)
   if (estimate_noise && rs && off_chain) return noise_and_resample_deferred(c, d_ids, B, d_pcm16, d_is_noise, ext, d_pcm_ext);
   if (estimate_noise && (rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, d_ids, B, d_pcm16, d_is_noise))) return rc;
   if (rs)
@@ -1772,6 +1772,12 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
   // the resamplers leave the codec's chains (resample_in_ahead / resample_deferred) in the default, unsplit configuration;
   // with sub-batches or strict call order they stay where the individual calls put them
   const bool rs_off_chain = rs && !c->serial && c->nsub == 1;
+  // The decoder-side legs leave the chain on split contexts too (round 6): the noise stream joins every chunk's decode
+  // (noise_dev_begin) and dec_side_begin orders every chunk behind the noise stream's older work -- decode-only at 8192 streams
+  // in two sub-batches, 48 kHz: 26.1 -> 27.1 M frames/s (profiles/r06_cfg4_legs.txt).  The INPUT resampler stays on the chain
+  // there: ahead on sq[0] it would only be ordered behind chunk 0's extractor.  LYRA_HIP_RS_OUT_ON_CHAIN_SPLIT=1: the old form.
+  static const bool out_on_chain_split = getenv("LYRA_HIP_RS_OUT_ON_CHAIN_SPLIT") != nullptr;
+  const bool rs_out_off_chain = rs && !c->serial && (c->nsub == 1 || !out_on_chain_split);
   struct LocalScope { lyra_hip_ctx* c; ~LocalScope() { c->chunk_local = false; c->ids_stable = false; } } local_scope{c};
   c->chunk_local = c->nsub > 1 && !c->serial && enc && dec && !feats && !rs && !(F & (LYRA_HIP_STEP_DTX | LYRA_HIP_STEP_DECODER_NOISE)) &&
                    !getenv("LYRA_HIP_NO_CHUNK_LOCAL");
@@ -1824,13 +1830,13 @@ int lyra_hip_run_steps_dev(lyra_hip_ctx* c, const lyra_hip_steps* S) {
       }
       if (rc) return rc;
       static const bool split_sn = getenv("LYRA_HIP_SPLIT_SN_CALLS") != nullptr;   // experiment hook: the form before round 6
-      if ((F & LYRA_HIP_STEP_DECODER_NOISE) && rs_off_chain && !split_sn) {   // both legs: one noise-stream call
+      if ((F & LYRA_HIP_STEP_DECODER_NOISE) && rs_out_off_chain && !split_sn) {   // both legs: one noise-stream call
         if ((rc = noise_and_resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise, ext, S->d_ext_out[set]))) return rc;
       } else {
         if (F & LYRA_HIP_STEP_DECODER_NOISE)   // lyra_decoder.cc:304-311: every decoded hop of a received packet
           if ((rc = lyra_hip_noise_receive_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], S->d_is_noise))) return rc;
         if (rs)     // lyra_decoder.cc:107-113 / buffered_resampler.cc: 16 kHz -> external rate
-          if ((rc = rs_off_chain ? resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set])
+          if ((rc = rs_out_off_chain ? resample_deferred(c, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000, ext, S->d_ext_out[set])
                                  : lyra_hip_resample_dev(c, LYRA_HIP_SIDE_DECODER, S->d_stream_ids, S->B, S->d_pcm_out[set], 320, 16000,
                                                          ext, S->d_ext_out[set])))
             return rc;
